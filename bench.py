@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py — TFHE gate bootstraps/sec on MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1], SURVEY.md §8d "Config 2"): a flat DAG of independent
+HomNAND gates at the 128-bit parameter set, inputs are FRESH encryptions (never trivial
+ciphertexts, which skip every CMUX).  One "step" = one pass of the hot path over the whole
+batch: iyk_hip_gate_batch -> {blind_rotate kernel, keyswitch kernel}, inputs and keys already
+resident in HBM.  With N > 1 (one process per GPU, launched by torch.distributed.run) the batch
+is sharded by replication of the per-GPU work: every rank processes its own `--gates` gates,
+there is no data-path collective for a flat DAG ("scaling": "weak"); the key material is
+generated on rank 0 and broadcast once over RCCL.
+
+Prints ONE JSON line on rank 0 (see README of the contract in DESIGN.md §Measurement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_BYTES_PER_S = 8.0e12  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--gates", type=int, default=65536, help="gates per step per GPU")
+    ap.add_argument("--params", default="128bit", choices=["128bit", "80bit"])
+    ap.add_argument("--op", default="NAND")
+    ap.add_argument("--cpu-sample", type=int, default=-1,
+                    help="gates timed on the CPU oracle for cpu_baseline (-1: 16 per core, 0: skip)")
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="measured HBM bytes per blind_rotate launch from a separate rocprofv3 --pmc pass")
+    return ap.parse_args()
+
+
+def cpu_baseline(keys, params, op_code, sample, data_seed):
+    """Oracle (kind 'port') timed on this host's cores on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    from iyokan_amd import client
+
+    cores = os.cpu_count() or 1
+    if sample < 0:
+        sample = 16 * cores
+    rng = np.random.default_rng(data_seed)
+    bits = rng.integers(0, 2, size=2 * sample).astype(np.uint8)
+    arena = np.zeros((3 * sample, params.n + 1), dtype=np.uint32)
+    arena[: 2 * sample] = client.encrypt_bits(keys, bits, seed=data_seed)
+    orc = oracle_lib.Oracle(keys)
+    idx = np.arange(sample, dtype=np.int32)
+    t0 = time.perf_counter()
+    orc.gate_batch(np.full(sample, op_code, dtype=np.int32), idx, idx + sample, np.full(sample, -1, dtype=np.int32),
+                   idx + 2 * sample, arena, nthreads=cores)
+    dt = time.perf_counter() - t0
+    dec = client.decrypt_bits(keys, arena[2 * sample:])
+    assert np.array_equal(dec, 1 - (bits[:sample] & bits[sample:])), "oracle decrypt mismatch"
+    orc.close()
+    return {"value": sample / dt, "unit": "gates/s", "cores": cores, "kind": "port",
+            "sample": f"{sample} NAND gates of the same workload (own exact-NTT CPU restatement oracle/tfhe_oracle.c, "
+                      f"OpenMP over gates, {dt:.1f} s); not TFHEpp"}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    from iyokan_amd import client, hip
+    from iyokan_amd.params import OPS, params_by_name
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    params = params_by_name(args.params)
+    op_code = OPS[args.op]
+    G = args.gates
+
+    # ---- keys: rank 0 generates, RCCL broadcast (north_star: "bootstrapping key broadcast once") ----
+    if rank == 0:
+        keys = client.keygen(params, seed=1)
+    else:
+        keys = client.KeySet(params, np.zeros(params.n, np.uint32), np.zeros(params.N, np.uint32),
+                             np.zeros(params.bk_words, np.uint32), np.zeros(params.ksk_words, np.uint32))
+    if world > 1:
+        for name in ("s0", "s1", "bk", "ksk"):
+            t = torch.from_numpy(getattr(keys, name).view(np.int32)).to(dev)
+            dist.broadcast(t, src=0)
+            setattr(keys, name, t.cpu().numpy().view(np.uint32))
+            del t
+    hip.initialize(keys, device_ids=(local_rank,))
+
+    # ---- synthetic inputs: 2G fresh encryptions per rank (distinct data seed per rank) ----
+    rng = np.random.default_rng(1000 + rank)
+    bits = rng.integers(0, 2, size=2 * G).astype(np.uint8)
+    enc = client.encrypt_bits(keys, bits, seed=2 + rank)
+    arena_t = torch.zeros((3 * G, params.n + 1), dtype=torch.int32, device=dev)
+    arena_t[: 2 * G].copy_(torch.from_numpy(enc.view(np.int32)))
+    del enc
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    st = hip.Stream(0, hip_stream=tstream.cuda_stream)
+    arena = hip.Arena.from_torch(arena_t)
+    idx = np.arange(G, dtype=np.int32)
+    ops = np.full(G, op_code, dtype=np.int32)
+    in0, in1, in2, out = idx, idx + G, np.full(G, -1, dtype=np.int32), idx + 2 * G
+
+    def step():
+        st.gate_batch(arena, ops, in0, in1, in2, out)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    st.timing_log_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    nb, br_ms, ks_ms = st.timing_log_end()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- correctness of what was just timed: decrypt every output of the last step ----
+    got = arena_t[2 * G:].cpu().numpy().view(np.uint32)
+    from iyokan_amd.params import PLAIN
+
+    want = np.array([PLAIN[args.op](int(a), int(b)) for a, b in zip(bits[:G], bits[G:])], dtype=np.uint8)
+    decrypt_ok = bool(np.array_equal(client.decrypt_bits(keys, got), want))
+
+    if rank == 0:
+        gates_total = G * args.steps * world
+        value = gates_total / elapsed
+        b_gate = params.gate_algorithmic_bytes(rotations=1, inputs=2)
+        # dominant kernel = blind_rotate: its share of B_gate is the BK stream + its own I/O
+        br_bytes_per_gate = params.n * params.trgsw_rows * (params.k + 1) * params.N * 8 \
+            + 2 * (params.n + 1) * 4 + (params.N + 1) * 4
+        br_avg_s = (br_ms / max(nb, 1)) * 1e-3
+        achieved = br_bytes_per_gate * G / br_avg_s if br_avg_s > 0 else 0.0
+        line = {
+            "metric": "TFHE gate bootstraps/sec (128-bit params)" if args.params == "128bit"
+            else "TFHE gate bootstraps/sec (80-bit params)",
+            "value": value,
+            "unit": "gates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 torus; NTT in u64 mod 2^64-2^32+1",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{G} independent Hom{args.op} gates per GPU per step (flat DAG), {args.params} params, "
+                            "fresh encryptions, keys+ciphertexts resident in HBM",
+                "params": {k: v for k, v in params.as_dict().items() if k not in ("alpha0", "alpha1")},
+                "gates_per_step_per_gpu": G,
+                "parallelism": f"frontier sharded over {world} GPU(s), no data-path collective (flat DAG)",
+                "decrypt_check": decrypt_ok,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "blind_rotate_kernel",
+                "achieved": achieved / 1e9,
+                "peak": HBM_PEAK_BYTES_PER_S / 1e9,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_BYTES_PER_S,
+                "traffic": args.traffic_bytes,
+                "algorithmic_bytes_per_launch": br_bytes_per_gate * G,
+                "avg_launch_ms": br_avg_s * 1e3,
+                "keyswitch_avg_launch_ms": ks_ms / max(nb, 1),
+                "gate_bytes": b_gate,
+                "gate_frac": value / world * b_gate / HBM_PEAK_BYTES_PER_S,
+            },
+        }
+        if world == 1 and args.cpu_sample != 0:
+            line["cpu_baseline"] = cpu_baseline(keys, params, op_code, args.cpu_sample, data_seed=99)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+
+    st.destroy()
+    del arena, arena_t
+    hip.cleanup()
+    if world > 1:
+        dist.destroy_process_group()
+    if not decrypt_ok:
+        raise SystemExit("decrypt check failed")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,169 @@
+/* iyokan_hip.h — C ABI of the MI355X gate-bootstrapping backend (libiyokan_hip.so).
+ *
+ * This is the library boundary that replaces the cuFHE C++ API used by Iyokan's GPU worker
+ * (/root/reference/src/iyokan_cufhe.{hpp,cpp}, /root/reference/src/tfhepp_cufhe_wrapper.hpp).
+ * Each entry point cites the reference call it replaces.  Plain C types only: pointers,
+ * sizes, ints.  No function throws or aborts; every function returns an int status
+ * (IYK_OK == 0, negative on error) and iyk_hip_last_error() describes the last failure on
+ * the calling thread.  The reference ignores cuFHE's return values and dies via
+ * error::die() -> exit(1) (/root/reference/src/error.hpp:22-48); the C++ adapter
+ * (iyokan_amd/host/iyokan_hip.hpp) maps non-zero status to the same behaviour.
+ *
+ * Threading contract (= the reference's): all enqueue / query calls for one
+ * stream come from one host thread at a time; enqueue and query never block.
+ *
+ * Data layouts
+ *   TLWE lvl0 ciphertext  u32[n+1], mask a[0..n-1] then body b   (TFHEpp::TLWE<lvl0param>)
+ *   ciphertext arena      u32[slots][n+1] in device memory; gates address slots by index
+ *   bootstrapping key in  u32[n][(k+1)l][k+1][N]  torus domain   (EvalKey::getbk<lvl01param>,
+ *                         required by the GPU path: /root/reference/src/iyokan_cufhe.cpp:734)
+ *   key-switching key in  u32[kN][t][2^basebit-1][n+1]           (EvalKey::getiksk<lvl10param>)
+ */
+#ifndef IYOKAN_HIP_H
+#define IYOKAN_HIP_H
+
+#include <stdint.h>
+
+#include "iyokan_hip_params.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IYK_OK 0
+#define IYK_ERR_INVALID (-1)   /* bad argument / unsupported parameter set */
+#define IYK_ERR_STATE (-2)     /* not initialised, already initialised, stale handle */
+#define IYK_ERR_HIP (-3)       /* a HIP runtime call failed (message in iyk_hip_last_error) */
+#define IYK_ERR_NOMEM (-4)
+
+/* Gate kinds.  Names follow Iyokan's gate tasks (DEFINE_TASK_GATE,
+ * /root/reference/src/iyokan_cufhe.hpp:249-261): ANDNOT = a & ~b (cufhe::AndYN),
+ * ORNOT = a | ~b (cufhe::OrYN), MUX(in0 = A, in1 = B, in2 = S) = S ? B : A
+ * (cufhe::Mux(out, S, B, A)).  COPY is TaskCUFHEGateWIRE's host copy (:168-183). */
+typedef enum iyk_gate_op {
+    IYK_OP_AND = 0,
+    IYK_OP_NAND = 1,
+    IYK_OP_ANDNOT = 2,
+    IYK_OP_OR = 3,
+    IYK_OP_NOR = 4,
+    IYK_OP_ORNOT = 5,
+    IYK_OP_XOR = 6,
+    IYK_OP_XNOR = 7,
+    IYK_OP_MUX = 8,
+    IYK_OP_NOT = 9,
+    IYK_OP_CONSTONE = 10,
+    IYK_OP_CONSTZERO = 11,
+    IYK_OP_COPY = 12,
+    IYK_OP__COUNT = 13
+} iyk_gate_op;
+
+typedef struct iyk_hip_stream iyk_hip_stream; /* opaque; replaces cufhe::Stream */
+
+/* ---- library lifetime ------------------------------------------------------------------ */
+
+/* Replaces cufhe::SetGPUNum(n) + cufhe::Initialize(ek)
+ * (/root/reference/src/iyokan_cufhe.cpp:530-536, /root/reference/src/test0.cpp:679).
+ * device_ids[ngpu] are HIP ordinals (NULL = 0..ngpu-1).  On every listed GPU: uploads the
+ * torus-domain BK, forward-NTTs all n*(k+1)l*(k+1) polynomials on the device, uploads the
+ * KSK (row-padded) and the twiddle tables.  Host buffers may be freed on return.
+ * Requirements: N == 1024, k == 1, l*Bgbit <= 31, n <= 1023. */
+int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params,
+                 const uint32_t* bk_torus, const uint32_t* ksk);
+
+/* Replaces cufhe::CleanUp() (/root/reference/src/iyokan_cufhe.cpp:721).  All streams must
+ * have been destroyed. */
+int iyk_hip_cleanup(void);
+
+int iyk_hip_is_initialized(void);
+int iyk_hip_num_gpus(void);
+int iyk_hip_get_params(iyk_params* out);
+const char* iyk_hip_last_error(void);
+
+/* ---- streams --------------------------------------------------------------------------- */
+
+/* Replaces cufhe::Stream::Create() (/root/reference/src/iyokan_cufhe.hpp:13-16): a
+ * non-blocking stream on GPU gpu_index (0 <= gpu_index < ngpu; the reference round-robins
+ * streams over GPUs — pass `worker_index % ngpu` to reproduce that). */
+int iyk_hip_stream_create(int gpu_index, iyk_hip_stream** out);
+
+/* Adopt an existing hipStream_t (e.g. the one torch.distributed / RCCL work is ordered on)
+ * instead of creating one; the caller keeps ownership of hip_stream. */
+int iyk_hip_stream_wrap(int gpu_index, void* hip_stream, iyk_hip_stream** out);
+
+/* Replaces cufhe::Stream::Destroy() (/root/reference/src/iyokan_cufhe.hpp:18-21). */
+int iyk_hip_stream_destroy(iyk_hip_stream* st);
+
+/* Replaces cufhe::StreamQuery(st) (/root/reference/src/iyokan_cufhe.hpp:196,236): 1 = all
+ * work enqueued so far has finished, 0 = still running, < 0 = error.  Never blocks. */
+int iyk_hip_stream_query(iyk_hip_stream* st);
+
+/* Blocks until the stream is idle (the reference spins on StreamQuery instead:
+ * /root/reference/src/iyokan_cufhe.hpp:723-735). */
+int iyk_hip_stream_sync(iyk_hip_stream* st);
+
+/* ---- device-resident ciphertext arena -------------------------------------------------- */
+
+/* Device buffer of `slots` TLWE lvl0 ciphertexts on the stream's GPU.  Replaces the
+ * per-device mirror behind cufhe::Ctxt<lvl0param> (/root/reference/src/tfhepp_cufhe_wrapper.hpp:43-66);
+ * a caller that already owns device memory (a torch tensor) may pass its pointer to the
+ * batch calls directly instead. */
+int iyk_hip_arena_alloc(int gpu_index, uint64_t slots, uint32_t** d_arena_out);
+int iyk_hip_arena_free(int gpu_index, uint32_t* d_arena);
+
+/* Host <-> arena copies, ordered on the stream (Ctxt::tlwehost <-> device;
+ * /root/reference/src/iyokan_cufhe.hpp:217-222,238-241). */
+int iyk_hip_arena_upload(iyk_hip_stream* st, uint32_t* d_arena, uint64_t first_slot, uint64_t count,
+                         const uint32_t* host_tlwe);
+int iyk_hip_arena_download(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t first_slot,
+                           uint64_t count, uint32_t* host_tlwe);
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+
+/* Evaluate `count` mutually independent gates on arena slots, asynchronously on `st`.
+ * Replaces `count` calls of cufhe::And/Nand/.../Mux/Not<lvl0param>(out, in.., st)
+ * (/root/reference/src/iyokan_cufhe.hpp:249-261) with ONE batched launch sequence:
+ *   linear step -> blind rotation (n CMUX external products, N-point negacyclic NTT over
+ *   2^64-2^32+1) -> sample-extract(0) -> identity key-switch.
+ * ops/in0/in1/in2/out are HOST arrays of length count (copied before return); in1/in2 are
+ * ignored where the gate has fewer inputs (use -1).  No output slot may be an input of a
+ * gate in the same batch.  Results are bit-identical to the CPU restatement in oracle/. */
+int iyk_hip_gate_batch(iyk_hip_stream* st, uint32_t* d_arena, uint64_t count, const int32_t* ops,
+                       const int32_t* in0, const int32_t* in1, const int32_t* in2,
+                       const int32_t* out);
+
+/* One gate on HOST ciphertexts, same shape as cufhe::Nand(out, in0, in1, st): H2D of the
+ * inputs, kernels, D2H of the result, all ordered on `st`; poll with iyk_hip_stream_query.
+ * `out` must stay valid (and should be pinned for true asynchrony) until the stream is idle. */
+int iyk_hip_gate_host(iyk_hip_stream* st, int op, const uint32_t* in0, const uint32_t* in1,
+                      const uint32_t* in2, uint32_t* out);
+
+/* ---- measurement / test hooks ---------------------------------------------------------- */
+
+/* Blind rotation + sample-extract only (cufhe::GateBootstrappingTLWE2TRLWElvl01NTT shape,
+ * /root/reference/src/iyokan_cufhe.hpp:634-635, but extracted at index 0): for each job
+ * lin = sa*arena[ia] + sb*arena[ib] + (0,..,0,off) -> TLWE lvl1 u32[N+1] at d_tlwe1 + job*(N+1).
+ * Host arrays of length count; ib may be -1. */
+int iyk_hip_blind_rotate_batch(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t count,
+                               const int32_t* ia, const int32_t* ib, const int32_t* sa,
+                               const int32_t* sb, const uint32_t* off, uint32_t* d_tlwe1);
+
+/* Kernel-only time of the most recent iyk_hip_gate_batch on this stream, from HIP events
+ * recorded on the stream around the blind-rotate and key-switch launches (milliseconds).
+ * Blocks until those events have completed. */
+int iyk_hip_last_batch_timing(iyk_hip_stream* st, float* blind_rotate_ms, float* keyswitch_ms);
+
+/* Kernel-time log for a whole timed region (bench.py's roofline line): between _begin and
+ * _end every iyk_hip_gate_batch on `st` records its own HIP events on the stream; _end
+ * synchronises the stream and returns the number of batches and the summed blind-rotate /
+ * key-switch kernel durations in milliseconds. */
+int iyk_hip_timing_log_begin(iyk_hip_stream* st);
+int iyk_hip_timing_log_end(iyk_hip_stream* st, uint64_t* batches, double* blind_rotate_ms,
+                           double* keyswitch_ms);
+
+/* Bytes of device memory holding keys on one GPU (NTT-domain BK + padded KSK + tables). */
+int iyk_hip_resident_key_bytes(uint64_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,82 @@
+"""Key generation / bit encryption / decryption (ctypes over libiyokan_client.so).
+
+Mirrors what `iyokan-packet genkey|genevalkey|enc|dec` does for the reference
+(/root/reference/src/iyokan-packet.cpp:144-178); used to make synthetic, non-trivial inputs.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from .params import IykParams
+
+_LIB = None
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libiyokan_client.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = ctypes.CDLL(path)
+        lib.iyk_client_keygen.argtypes = [ctypes.POINTER(IykParams), ctypes.c_uint64, _u32p, _u32p, _u32p, _u32p]
+        lib.iyk_client_encrypt_bits.argtypes = [ctypes.POINTER(IykParams), _u32p, ctypes.c_uint64, _u8p, ctypes.c_uint64, _u32p]
+        lib.iyk_client_decrypt_bits.argtypes = [ctypes.POINTER(IykParams), _u32p, _u32p, ctypes.c_uint64, _u8p]
+        lib.iyk_client_phases.argtypes = [ctypes.POINTER(IykParams), _u32p, _u32p, ctypes.c_uint64, _u32p]
+        lib.iyk_client_trivial.argtypes = [ctypes.POINTER(IykParams), ctypes.c_int, _u32p]
+        _LIB = lib
+    return _LIB
+
+
+def _p32(a):
+    return a.ctypes.data_as(_u32p)
+
+
+class KeySet:
+    """SecretKey (s0, s1) + EvalKey material the GPU path needs (bk<lvl01> torus, iksk<lvl10>)."""
+
+    def __init__(self, params, s0, s1, bk, ksk):
+        self.params, self.s0, self.s1, self.bk, self.ksk = params, s0, s1, bk, ksk
+
+
+def keygen(params: IykParams, seed: int = 1) -> KeySet:
+    s0 = np.zeros(params.n, dtype=np.uint32)
+    s1 = np.zeros(params.N, dtype=np.uint32)
+    bk = np.zeros(params.bk_words, dtype=np.uint32)
+    ksk = np.zeros(params.ksk_words, dtype=np.uint32)
+    rc = _lib().iyk_client_keygen(ctypes.byref(params), seed, _p32(s0), _p32(s1), _p32(bk), _p32(ksk))
+    if rc != 0:
+        raise RuntimeError(f"iyk_client_keygen failed: {rc}")
+    return KeySet(params, s0, s1, bk, ksk)
+
+
+def encrypt_bits(keys: KeySet, bits, seed: int = 2) -> np.ndarray:
+    bits = np.ascontiguousarray(np.asarray(bits, dtype=np.uint8).ravel())
+    out = np.zeros((bits.size, keys.params.n + 1), dtype=np.uint32)
+    _lib().iyk_client_encrypt_bits(ctypes.byref(keys.params), _p32(keys.s0), seed,
+                                   bits.ctypes.data_as(_u8p), bits.size, _p32(out))
+    return out
+
+
+def decrypt_bits(keys: KeySet, ct) -> np.ndarray:
+    ct = np.ascontiguousarray(ct, dtype=np.uint32).reshape(-1, keys.params.n + 1)
+    bits = np.zeros(ct.shape[0], dtype=np.uint8)
+    _lib().iyk_client_decrypt_bits(ctypes.byref(keys.params), _p32(keys.s0), _p32(ct), ct.shape[0],
+                                   bits.ctypes.data_as(_u8p))
+    return bits
+
+
+def phases(keys: KeySet, ct) -> np.ndarray:
+    ct = np.ascontiguousarray(ct, dtype=np.uint32).reshape(-1, keys.params.n + 1)
+    out = np.zeros(ct.shape[0], dtype=np.uint32)
+    _lib().iyk_client_phases(ctypes.byref(keys.params), _p32(keys.s0), _p32(ct), ct.shape[0], _p32(out))
+    return out
+
+
+def trivial(params: IykParams, bit: int) -> np.ndarray:
+    out = np.zeros(params.n + 1, dtype=np.uint32)
+    _lib().iyk_client_trivial(ctypes.byref(params), int(bit), _p32(out))
+    return out

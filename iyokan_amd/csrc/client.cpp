@@ -1,0 +1,162 @@
+// client.cpp — key generation, bit encryption and decryption for the hot path's inputs.
+//
+// Role in the reference: `iyokan-packet genkey / genevalkey / enc / dec`
+// (/root/reference/src/iyokan-packet.cpp:144-178) and the in-process key set-up of test0
+// (/root/reference/src/test0.cpp:535-546): SecretKey, then EvalKey with iksk<lvl10> and
+// bk<lvl01> (torus-domain TRGSW per lvl0 key bit).  This is NOT on the GPU hot path; it
+// exists so bench.py / tests / the host runtime can make real (non-trivial) ciphertexts —
+// the reference's own GPU tests use trivial ones, which skip every CMUX
+// (/root/reference/src/test0.cpp:702-710).  Built as libiyokan_client.so (plain C ABI).
+//
+// Layouts (shared with include/iyokan_hip.h):
+//   TLWE lvl0      u32[n+1]                      a[0..n-1], b = a[n]
+//   BK (torus)     u32[n][(k+1)l][k+1][N]        row r = c*l + j: TRLWE(0) + s0[i]*2^(32-(j+1)Bgbit) on poly c, coeff 0
+//   KSK            u32[kN][t][2^basebit-1][n+1]  TLWE0( s1[i] * v * 2^(32-(j+1)basebit) ), v = idx+1
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/iyokan_hip_params.h"
+
+namespace {
+
+struct Rng {  // xoshiro256**, seeded with splitmix64
+    uint64_t s[4];
+    explicit Rng(uint64_t seed)
+    {
+        for (auto& v : s) {
+            uint64_t z = (seed += 0x9E3779B97F4A7C15ull);
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            v = z ^ (z >> 31);
+        }
+    }
+    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    uint64_t next()
+    {
+        const uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
+        return r;
+    }
+    uint32_t u32() { return (uint32_t)(next() >> 32); }
+    double unit() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+    double gauss(double sigma)
+    {
+        double u1 = unit(), u2 = unit();
+        if (u1 < 1e-300) u1 = 1e-300;
+        return sigma * std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
+    }
+    // modular Gaussian on the torus, TFHEpp dtot32 convention
+    uint32_t gauss_torus(double sigma)
+    {
+        double d = gauss(sigma);
+        d -= std::floor(d);
+        return (uint32_t)(int64_t)(d * 4294967296.0);
+    }
+};
+
+void tlwe0_encrypt(const iyk_params* p, const uint32_t* s0, uint32_t msg, Rng& rng, uint32_t* ct)
+{
+    uint32_t b = msg + rng.gauss_torus(p->alpha0);
+    for (uint32_t i = 0; i < p->n; ++i) {
+        ct[i] = rng.u32();
+        b += ct[i] * s0[i];
+    }
+    ct[p->n] = b;
+}
+
+// (a, b = a*s1 + e) with binary s1: a*s1 = sum over set bits of X^i * a
+void trlwe_encrypt_zero(const iyk_params* p, const uint32_t* s1, Rng& rng, uint32_t* a, uint32_t* b)
+{
+    const uint32_t N = p->N;
+    for (uint32_t x = 0; x < N; ++x) {
+        a[x] = rng.u32();
+        b[x] = rng.gauss_torus(p->alpha1);
+    }
+    for (uint32_t i = 0; i < N; ++i) {
+        if (!s1[i]) continue;
+        for (uint32_t x = 0; x < N - i; ++x) b[x + i] += a[x];
+        for (uint32_t x = N - i; x < N; ++x) b[x + i - N] -= a[x];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// s0[n], s1[N] are binary secret keys (one u32 per bit); bk / ksk sized by iyk_bk_words / iyk_ksk_words
+int iyk_client_keygen(const iyk_params* p, uint64_t seed, uint32_t* s0, uint32_t* s1, uint32_t* bk,
+                      uint32_t* ksk)
+{
+    if (!p || p->k != 1) return -1;
+    Rng rng(seed);
+    for (uint32_t i = 0; i < p->n; ++i) s0[i] = rng.u32() & 1u;
+    for (uint32_t i = 0; i < p->N; ++i) s1[i] = rng.u32() & 1u;
+
+    const uint32_t N = p->N, rows = (p->k + 1) * p->l;
+    for (uint32_t i = 0; i < p->n; ++i)
+        for (uint32_t r = 0; r < rows; ++r) {
+            uint32_t* row = bk + ((size_t)i * rows + r) * 2 * N;
+            trlwe_encrypt_zero(p, s1, rng, row, row + N);
+            const uint32_t c = r / p->l, j = r % p->l;
+            row[c * N] += s0[i] << (32 - (j + 1) * p->Bgbit);
+        }
+
+    const uint32_t nb = (1u << p->basebit) - 1, n1 = p->n + 1;
+    for (uint32_t i = 0; i < N; ++i)
+        for (uint32_t j = 0; j < p->t; ++j)
+            for (uint32_t v = 1; v <= nb; ++v) {
+                uint32_t* row = ksk + (((size_t)i * p->t + j) * nb + (v - 1)) * n1;
+                const uint32_t msg = (s1[i] * v) << (32 - (j + 1) * p->basebit);
+                tlwe0_encrypt(p, s0, msg, rng, row);
+            }
+    return 0;
+}
+
+// bit b -> TLWE0(+-mu) with fresh noise (TFHEpp bootsSymEncrypt, /root/reference/src/packet.hpp:68-76)
+int iyk_client_encrypt_bits(const iyk_params* p, const uint32_t* s0, uint64_t seed,
+                            const uint8_t* bits, uint64_t count, uint32_t* out)
+{
+    Rng rng(seed);
+    for (uint64_t g = 0; g < count; ++g)
+        tlwe0_encrypt(p, s0, bits[g] ? p->mu : 0u - p->mu, rng, out + g * (p->n + 1));
+    return 0;
+}
+
+// bit = (int32)(b - <a,s>) > 0   (/root/reference/src/tfhepp_cufhe_wrapper.hpp:24-27)
+int iyk_client_decrypt_bits(const iyk_params* p, const uint32_t* s0, const uint32_t* ct,
+                            uint64_t count, uint8_t* bits)
+{
+    for (uint64_t g = 0; g < count; ++g) {
+        const uint32_t* c = ct + g * (p->n + 1);
+        uint32_t ph = c[p->n];
+        for (uint32_t i = 0; i < p->n; ++i) ph -= c[i] * s0[i];
+        bits[g] = (int32_t)ph > 0;
+    }
+    return 0;
+}
+
+// phases, for noise-margin checks
+int iyk_client_phases(const iyk_params* p, const uint32_t* s0, const uint32_t* ct, uint64_t count,
+                      uint32_t* phases)
+{
+    for (uint64_t g = 0; g < count; ++g) {
+        const uint32_t* c = ct + g * (p->n + 1);
+        uint32_t ph = c[p->n];
+        for (uint32_t i = 0; i < p->n; ++i) ph -= c[i] * s0[i];
+        phases[g] = ph;
+    }
+    return 0;
+}
+
+// trivial ciphertext (a = 0, b = +-mu): HomCONSTANTONE / ZERO
+// (/root/reference/src/tfhepp_cufhe_wrapper.hpp:29-37)
+int iyk_client_trivial(const iyk_params* p, int bit, uint32_t* out)
+{
+    std::memset(out, 0, sizeof(uint32_t) * (p->n + 1));
+    out[p->n] = bit ? p->mu : 0u - p->mu;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,167 @@
+// host_selftest.cpp — CPU unit test of the exact code the HIP kernels run
+// (goldilocks.hpp, ntt32.hpp), with the 32 lanes of a pass emulated by a loop and the
+// LDS transpose by an array.  Built and run by tests/test_device_math.py; no GPU needed.
+//
+// Checks: field ops vs unsigned __int128; gl_mul_pow2 for every shift; the two-pass
+// N=1024 transform vs the defining sum; inverse(forward) == identity; NTT product ==
+// schoolbook negacyclic product mod 2^32 (the exactness anchor).
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "ntt32.hpp"
+
+using namespace iyk;
+
+static u64 rng_state = 0x9E3779B97F4A7C15ull;
+static u64 rnd()
+{
+    u64 z = (rng_state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static u64 rnd_fe()
+{
+    switch (rnd() % 8) {
+    case 0: return GL_P - 1 - rnd() % 4;
+    case 1: return rnd() % 4;
+    case 2: return (0xFFFFFFFFull << 32) - rnd() % 3;
+    case 3: return 0xFFFFFFFFull + rnd() % 3 - 1;
+    default: return rnd() % GL_P;
+    }
+}
+
+#define CHECK(c)                                                        \
+    do {                                                                \
+        if (!(c)) {                                                     \
+            std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c);    \
+            std::exit(1);                                               \
+        }                                                               \
+    } while (0)
+
+typedef unsigned __int128 u128;
+
+static void test_field()
+{
+    for (int it = 0; it < 2000000; ++it) {
+        u64 a = rnd_fe(), b = rnd_fe();
+        CHECK(gl_add(a, b) == (u64)(((u128)a + b) % GL_P));
+        CHECK(gl_sub(a, b) == (u64)(((u128)a + GL_P - b) % GL_P));
+        CHECK(gl_mul(a, b) == (u64)(((u128)a * b) % GL_P));
+        u64 hi = rnd(), lo = rnd();
+        CHECK(gl_reduce128(hi, lo) == (u64)((((u128)hi << 64) | lo) % GL_P));
+    }
+    for (unsigned s = 0; s < 192; ++s) {
+        u64 p2 = gl_pow(2, s);
+        for (int it = 0; it < 2000; ++it) {
+            u64 a = rnd_fe();
+            CHECK(gl_mul_pow2(a, s) == gl_mul(a, p2));
+        }
+    }
+    CHECK(gl_pow(2, 96) == GL_P - 1);
+    CHECK(gl_to_torus32(gl_from_i32(-5)) == (u32)-5);
+    CHECK(gl_to_torus32(gl_from_i32(7)) == 7u);
+    std::printf("field ok\n");
+}
+
+// emulate the wave: 32 lanes, registers x[lane][32], LDS transpose buffer with row pad 33
+static void emul_forward(const u64* in, u64* out, const u64* tw_fwd)
+{
+    static u64 reg[32][32];
+    static u64 xbuf[32 * 33];
+    for (int t = 0; t < 32; ++t) {  // lane = j1
+        u64(&x)[32] = reg[t];
+        for (int j2 = 0; j2 < 32; ++j2) x[j2] = in[t + 32 * j2];
+        ntt_fwd_pass1(x, tw_fwd + t * 32);
+        for (int p = 0; p < 32; ++p) xbuf[brv5(p) * 33 + t] = x[p];
+    }
+    for (int t = 0; t < 32; ++t) {  // lane = k2
+        u64(&x)[32] = reg[t];
+        for (int j1 = 0; j1 < 32; ++j1) x[j1] = xbuf[t * 33 + j1];
+        ntt_fwd_pass2(x);
+        for (int p = 0; p < 32; ++p) out[t + 32 * brv5(p)] = x[p];
+    }
+}
+
+static void emul_inverse(const u64* in, u64* out, const u64* tw_inv)
+{
+    static u64 reg[32][32];
+    static u64 xbuf[32 * 33];
+    for (int t = 0; t < 32; ++t) {  // lane = k2
+        u64(&x)[32] = reg[t];
+        for (int p = 0; p < 32; ++p) x[p] = in[t + 32 * brv5(p)];
+        ntt_inv_pass1(x, tw_inv + t * 32);
+        for (int j1 = 0; j1 < 32; ++j1) xbuf[j1 * 33 + t] = x[j1];
+    }
+    for (int t = 0; t < 32; ++t) {  // lane = j1
+        u64(&x)[32] = reg[t];
+        for (int k2 = 0; k2 < 32; ++k2) x[k2] = xbuf[t * 33 + k2];
+        ntt_inv_pass2(x);
+        for (int p = 0; p < 32; ++p) out[t + 32 * brv5(p)] = x[p];
+    }
+}
+
+static void test_ntt()
+{
+    std::vector<u64> twf(1024), twi(1024);
+    ntt_make_tables(twf.data(), twi.data());
+    const u64 psi = ntt_find_psi();
+    CHECK(psi != 0);
+    CHECK(gl_pow(psi, 1024) == GL_P - 1);
+    CHECK(gl_pow(psi, 32) == 8);
+
+    std::vector<u64> x(1024), X(1024), y(1024);
+    for (auto& v : x) v = rnd_fe();
+    emul_forward(x.data(), X.data(), twf.data());
+    // defining sum on a sample of outputs (full O(N^2) would be 1M pow's)
+    std::vector<u64> psipow(2048);
+    psipow[0] = 1;
+    for (int i = 1; i < 2048; ++i) psipow[i] = gl_mul(psipow[i - 1], psi);
+    for (int k = 0; k < 1024; k += 7) {
+        u64 acc = 0;
+        for (int j = 0; j < 1024; ++j)
+            acc = gl_add(acc, gl_mul(x[j], psipow[(u64)j * (2 * k + 1) % 2048]));
+        CHECK(acc == X[k]);
+    }
+    emul_inverse(X.data(), y.data(), twi.data());
+    for (int j = 0; j < 1024; ++j) CHECK(x[j] == y[j]);
+    std::printf("ntt ok\n");
+
+    // exactness anchor: digit poly (|d| <= 512) times torus32 poly, negacyclic, mod 2^32
+    for (int rep = 0; rep < 3; ++rep) {
+        std::vector<i32> d(1024);
+        std::vector<u32> b(1024), ref(1024);
+        const int half = rep == 0 ? 32 : 512;
+        for (auto& v : d) v = (i32)(rnd() % (2 * half)) - half;
+        for (auto& v : b) v = (u32)rnd();
+        for (int i = 0; i < 1024; ++i) {
+            u32 acc = 0;
+            for (int j = 0; j < 1024; ++j) {
+                int kidx = i - j;
+                u32 term = (u32)d[j] * b[(kidx + 1024) % 1024];
+                acc += (kidx >= 0) ? term : (u32)(0u - term);
+            }
+            ref[i] = acc;
+        }
+        std::vector<u64> fd(1024), fb(1024), Fd(1024), Fb(1024), prod(1024), res(1024);
+        for (int i = 0; i < 1024; ++i) {
+            fd[i] = gl_from_i32(d[i]);
+            fb[i] = b[i];
+        }
+        emul_forward(fd.data(), Fd.data(), twf.data());
+        emul_forward(fb.data(), Fb.data(), twf.data());
+        for (int i = 0; i < 1024; ++i) prod[i] = gl_mul(Fd[i], Fb[i]);
+        emul_inverse(prod.data(), res.data(), twi.data());
+        for (int i = 0; i < 1024; ++i) CHECK(gl_to_torus32(res[i]) == ref[i]);
+    }
+    std::printf("negacyclic product ok\n");
+}
+
+int main()
+{
+    test_field();
+    test_ntt();
+    std::printf("ALL OK\n");
+    return 0;
+}

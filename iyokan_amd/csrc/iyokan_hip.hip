@@ -1,0 +1,573 @@
+// iyokan_hip.hip — implementation of the C ABI in include/iyokan_hip.h (libiyokan_hip.so).
+//
+// Host side of the MI355X backend: owns device-resident keys (NTT-domain BK, padded KSK,
+// twiddle tables) per GPU, streams with their staging buffers, and turns a batch of gate
+// descriptors into three launches: elementwise (NOT/COPY/CONST), blind_rotate (one wave per
+// rotation), keyswitch (one workgroup per gate).  Replaces the cuFHE host API used at
+// /root/reference/src/iyokan_cufhe.cpp:530-536,721 and /root/reference/src/iyokan_cufhe.hpp:8-27,249-261.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/iyokan_hip.h"
+#include "kernels.hpp"
+
+using namespace iyk;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(IYK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+struct Device {
+    int ordinal = -1;
+    u64* bk_ntt = nullptr;
+    u32* ksk = nullptr;
+    u64* tw_fwd = nullptr;
+    u64* tw_inv = nullptr;
+};
+
+struct Global {
+    std::mutex mu;
+    bool init = false;
+    iyk_params p{};
+    u32 ksk_stride = 0;
+    std::vector<Device> devs;
+    std::atomic<int> nstreams{0};
+    uint64_t key_bytes = 0;
+} G;
+
+}  // namespace
+
+struct iyk_hip_stream {
+    int gpu = 0;
+    hipStream_t s = nullptr;
+    bool owned = false;
+    // descriptor staging (pinned host + device), reused batch after batch
+    char* h_stage = nullptr;
+    char* d_stage = nullptr;
+    size_t stage_cap = 0;
+    hipEvent_t stage_free = nullptr;  // last H2D descriptor copy done -> pinned buffer reusable
+    // blind-rotation outputs (TLWE lvl1), one row per rotation job
+    u32* d_rot = nullptr;
+    size_t rot_cap = 0;
+    // timing of the most recent batch
+    hipEvent_t ev_br0 = nullptr, ev_br1 = nullptr, ev_ks1 = nullptr;
+    bool timing_valid = false, timing_has_ks = false;
+    // optional log of per-batch kernel durations (bench.py): event triples per batch
+    bool log_on = false;
+    std::vector<hipEvent_t> log_events;  // br0, br1, ks1 per logged batch
+    // scratch arena for iyk_hip_gate_host: slot 0 = out, 1..3 = inputs
+    u32* d_scratch = nullptr;
+};
+
+namespace {
+
+int set_device(int gpu)
+{
+    if (gpu < 0 || gpu >= (int)G.devs.size()) return fail(IYK_ERR_INVALID, "gpu_index out of range");
+    HIP_TRY(hipSetDevice(G.devs[gpu].ordinal));
+    return IYK_OK;
+}
+
+int ensure_stage(iyk_hip_stream* st, size_t bytes)
+{
+    if (bytes <= st->stage_cap) return IYK_OK;
+    HIP_TRY(hipStreamSynchronize(st->s));
+    if (st->h_stage) HIP_TRY(hipHostFree(st->h_stage));
+    if (st->d_stage) HIP_TRY(hipFree(st->d_stage));
+    st->h_stage = nullptr;
+    st->d_stage = nullptr;
+    size_t cap = bytes + bytes / 2 + 4096;
+    HIP_TRY(hipHostMalloc((void**)&st->h_stage, cap, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&st->d_stage, cap));
+    st->stage_cap = cap;
+    return IYK_OK;
+}
+
+int ensure_rot(iyk_hip_stream* st, size_t jobs)
+{
+    if (jobs <= st->rot_cap) return IYK_OK;
+    HIP_TRY(hipStreamSynchronize(st->s));
+    if (st->d_rot) HIP_TRY(hipFree(st->d_rot));
+    st->d_rot = nullptr;
+    size_t cap = jobs + jobs / 2 + 64;
+    HIP_TRY(hipMalloc((void**)&st->d_rot, cap * (NTT_N + 1) * sizeof(u32)));
+    st->rot_cap = cap;
+    return IYK_OK;
+}
+
+int launch_blind_rotate(iyk_hip_stream* st, const u32* d_arena, const RotJob* d_jobs, int njobs,
+                        u32* d_tlwe1)
+{
+    const Device& D = G.devs[st->gpu];
+    const iyk_params& p = G.p;
+    dim3 grid((njobs + BR_WAVES - 1) / BR_WAVES), block(64 * BR_WAVES);
+    if (p.l == 3 && p.Bgbit == 6)
+        hipLaunchKernelGGL((blind_rotate_kernel<3, 6>), grid, block, 0, st->s, d_arena, d_jobs, njobs,
+                           D.bk_ntt, D.tw_fwd, D.tw_inv, d_tlwe1, p.n, p.mu);
+    else if (p.l == 2 && p.Bgbit == 10)
+        hipLaunchKernelGGL((blind_rotate_kernel<2, 10>), grid, block, 0, st->s, d_arena, d_jobs, njobs,
+                           D.bk_ntt, D.tw_fwd, D.tw_inv, d_tlwe1, p.n, p.mu);
+    else
+        return fail(IYK_ERR_INVALID, "unsupported (l, Bgbit)");
+    HIP_TRY(hipGetLastError());
+    return IYK_OK;
+}
+
+// linear-step coefficients of TFHEpp HomGate (SURVEY.md §8 a-ext)
+bool gate_coeffs(int op, u32 mu, int32_t& sa, int32_t& sb, u32& off)
+{
+    switch (op) {
+    case IYK_OP_AND: sa = 1; sb = 1; off = 0u - mu; return true;
+    case IYK_OP_NAND: sa = -1; sb = -1; off = mu; return true;
+    case IYK_OP_ANDNOT: sa = 1; sb = -1; off = 0u - mu; return true;
+    case IYK_OP_OR: sa = 1; sb = 1; off = mu; return true;
+    case IYK_OP_NOR: sa = -1; sb = -1; off = 0u - mu; return true;
+    case IYK_OP_ORNOT: sa = 1; sb = -1; off = mu; return true;
+    case IYK_OP_XOR: sa = 2; sb = 2; off = 2u * mu; return true;
+    case IYK_OP_XNOR: sa = -2; sb = -2; off = 0u - 2u * mu; return true;
+    default: return false;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* iyk_hip_last_error(void) { return g_last_error.c_str(); }
+
+int iyk_hip_is_initialized(void) { return G.init ? 1 : 0; }
+
+int iyk_hip_num_gpus(void) { return G.init ? (int)G.devs.size() : 0; }
+
+int iyk_hip_get_params(iyk_params* out)
+{
+    if (!G.init) return fail(IYK_ERR_STATE, "not initialised");
+    if (!out) return fail(IYK_ERR_INVALID, "null out");
+    *out = G.p;
+    return IYK_OK;
+}
+
+int iyk_hip_resident_key_bytes(uint64_t* out)
+{
+    if (!G.init) return fail(IYK_ERR_STATE, "not initialised");
+    *out = G.key_bytes;
+    return IYK_OK;
+}
+
+int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, const uint32_t* bk_torus,
+                 const uint32_t* ksk)
+{
+    std::lock_guard<std::mutex> lock(G.mu);
+    if (G.init) return fail(IYK_ERR_STATE, "already initialised");
+    if (!params || !bk_torus || !ksk || ngpu < 1) return fail(IYK_ERR_INVALID, "null/invalid argument");
+    const iyk_params& p = *params;
+    if (p.N != (u32)NTT_N || p.k != 1) return fail(IYK_ERR_INVALID, "kernels require N == 1024, k == 1");
+    if (!((p.l == 3 && p.Bgbit == 6) || (p.l == 2 && p.Bgbit == 10)))
+        return fail(IYK_ERR_INVALID, "supported (l, Bgbit): (3, 6) [128-bit], (2, 10) [80-bit]");
+    if (p.n < 256 || p.n >= (u32)ABAR_WORDS || p.n + 1 > 3 * KS_THREADS)
+        return fail(IYK_ERR_INVALID, "n out of supported range [256, 767]");
+    if (p.basebit * p.t > 31 || p.basebit == 0 || p.t == 0) return fail(IYK_ERR_INVALID, "bad key-switch params");
+    int avail = 0;
+    HIP_TRY(hipGetDeviceCount(&avail));
+    if (avail < 1) return fail(IYK_ERR_HIP, "no HIP device visible");
+
+    std::vector<u64> twf(NTT_N), twi(NTT_N);
+    ntt_make_tables(twf.data(), twi.data());
+
+    const size_t bk_words = (size_t)iyk_bk_words(&p);
+    const size_t polys = bk_words / NTT_N;
+    const u32 nb = (1u << p.basebit) - 1;
+    const size_t ksk_rows = (size_t)p.N * p.t * nb;
+    const u32 stride = (p.n + 1 + 3u) & ~3u;
+    std::vector<u32> ksk_pad(ksk_rows * stride, 0u);
+    for (size_t r = 0; r < ksk_rows; ++r)
+        std::memcpy(&ksk_pad[r * stride], ksk + r * (p.n + 1), sizeof(u32) * (p.n + 1));
+
+    std::vector<Device> devs(ngpu);
+    for (int g = 0; g < ngpu; ++g) {
+        Device& D = devs[g];
+        D.ordinal = device_ids ? device_ids[g] : g;
+        if (D.ordinal < 0 || D.ordinal >= avail) return fail(IYK_ERR_INVALID, "device ordinal out of range");
+        HIP_TRY(hipSetDevice(D.ordinal));
+        u32* d_bk = nullptr;
+        HIP_TRY(hipMalloc((void**)&d_bk, bk_words * sizeof(u32)));
+        HIP_TRY(hipMalloc((void**)&D.bk_ntt, bk_words * sizeof(u64)));
+        HIP_TRY(hipMalloc((void**)&D.ksk, ksk_pad.size() * sizeof(u32)));
+        HIP_TRY(hipMalloc((void**)&D.tw_fwd, NTT_N * sizeof(u64)));
+        HIP_TRY(hipMalloc((void**)&D.tw_inv, NTT_N * sizeof(u64)));
+        HIP_TRY(hipMemcpy(d_bk, bk_torus, bk_words * sizeof(u32), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(D.ksk, ksk_pad.data(), ksk_pad.size() * sizeof(u32), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(D.tw_fwd, twf.data(), NTT_N * sizeof(u64), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(D.tw_inv, twi.data(), NTT_N * sizeof(u64), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(bk_ntt_kernel, dim3((unsigned)((polys + 1) / 2)), dim3(64), 0, 0, d_bk, D.bk_ntt,
+                           D.tw_fwd, polys);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(d_bk));
+    }
+    G.p = p;
+    G.ksk_stride = stride;
+    G.devs = devs;
+    G.key_bytes = bk_words * sizeof(u64) + ksk_pad.size() * sizeof(u32) + 2 * NTT_N * sizeof(u64);
+    G.init = true;
+    return IYK_OK;
+}
+
+int iyk_hip_cleanup(void)
+{
+    std::lock_guard<std::mutex> lock(G.mu);
+    if (!G.init) return fail(IYK_ERR_STATE, "not initialised");
+    if (G.nstreams.load() != 0) return fail(IYK_ERR_STATE, "streams still alive");
+    for (Device& D : G.devs) {
+        HIP_TRY(hipSetDevice(D.ordinal));
+        HIP_TRY(hipFree(D.bk_ntt));
+        HIP_TRY(hipFree(D.ksk));
+        HIP_TRY(hipFree(D.tw_fwd));
+        HIP_TRY(hipFree(D.tw_inv));
+    }
+    G.devs.clear();
+    G.init = false;
+    return IYK_OK;
+}
+
+static int stream_new(int gpu_index, void* wrap, bool do_wrap, iyk_hip_stream** out)
+{
+    if (!G.init) return fail(IYK_ERR_STATE, "not initialised");
+    if (!out) return fail(IYK_ERR_INVALID, "null out");
+    int rc = set_device(gpu_index);
+    if (rc) return rc;
+    iyk_hip_stream* st = new (std::nothrow) iyk_hip_stream();
+    if (!st) return fail(IYK_ERR_NOMEM, "out of host memory");
+    st->gpu = gpu_index;
+    if (do_wrap) {
+        st->s = (hipStream_t)wrap;
+        st->owned = false;
+    }
+    else {
+        hipError_t e = hipStreamCreateWithFlags(&st->s, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete st;
+            return fail(IYK_ERR_HIP, std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(e));
+        }
+        st->owned = true;
+    }
+    (void)hipEventCreateWithFlags(&st->stage_free, hipEventDisableTiming);
+    (void)hipEventCreate(&st->ev_br0);
+    (void)hipEventCreate(&st->ev_br1);
+    (void)hipEventCreate(&st->ev_ks1);
+    G.nstreams.fetch_add(1);
+    *out = st;
+    return IYK_OK;
+}
+
+int iyk_hip_stream_create(int gpu_index, iyk_hip_stream** out) { return stream_new(gpu_index, nullptr, false, out); }
+
+int iyk_hip_stream_wrap(int gpu_index, void* hip_stream, iyk_hip_stream** out)
+{
+    return stream_new(gpu_index, hip_stream, true, out);
+}
+
+int iyk_hip_stream_destroy(iyk_hip_stream* st)
+{
+    if (!st) return fail(IYK_ERR_INVALID, "null stream");
+    int rc = set_device(st->gpu);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(st->s));
+    if (st->h_stage) (void)hipHostFree(st->h_stage);
+    if (st->d_stage) (void)hipFree(st->d_stage);
+    if (st->d_rot) (void)hipFree(st->d_rot);
+    if (st->d_scratch) (void)hipFree(st->d_scratch);
+    (void)hipEventDestroy(st->stage_free);
+    if (st->log_on) {
+        for (hipEvent_t e : st->log_events) (void)hipEventDestroy(e);
+    }
+    else {
+        (void)hipEventDestroy(st->ev_br0);
+        (void)hipEventDestroy(st->ev_br1);
+        (void)hipEventDestroy(st->ev_ks1);
+    }
+    if (st->owned) HIP_TRY(hipStreamDestroy(st->s));
+    delete st;
+    G.nstreams.fetch_sub(1);
+    return IYK_OK;
+}
+
+int iyk_hip_stream_query(iyk_hip_stream* st)
+{
+    if (!st) return fail(IYK_ERR_INVALID, "null stream");
+    hipError_t e = hipStreamQuery(st->s);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) return 0;
+    return fail(IYK_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(e));
+}
+
+int iyk_hip_stream_sync(iyk_hip_stream* st)
+{
+    if (!st) return fail(IYK_ERR_INVALID, "null stream");
+    HIP_TRY(hipStreamSynchronize(st->s));
+    return IYK_OK;
+}
+
+int iyk_hip_arena_alloc(int gpu_index, uint64_t slots, uint32_t** d_arena_out)
+{
+    if (!G.init) return fail(IYK_ERR_STATE, "not initialised");
+    if (!d_arena_out || slots == 0) return fail(IYK_ERR_INVALID, "bad argument");
+    int rc = set_device(gpu_index);
+    if (rc) return rc;
+    HIP_TRY(hipMalloc((void**)d_arena_out, slots * (G.p.n + 1) * sizeof(u32)));
+    return IYK_OK;
+}
+
+int iyk_hip_arena_free(int gpu_index, uint32_t* d_arena)
+{
+    if (!G.init) return fail(IYK_ERR_STATE, "not initialised");
+    int rc = set_device(gpu_index);
+    if (rc) return rc;
+    HIP_TRY(hipFree(d_arena));
+    return IYK_OK;
+}
+
+int iyk_hip_arena_upload(iyk_hip_stream* st, uint32_t* d_arena, uint64_t first_slot, uint64_t count,
+                         const uint32_t* host_tlwe)
+{
+    if (!st || !d_arena || !host_tlwe) return fail(IYK_ERR_INVALID, "null argument");
+    int rc = set_device(st->gpu);
+    if (rc) return rc;
+    const size_t n1 = G.p.n + 1;
+    HIP_TRY(hipMemcpyAsync(d_arena + first_slot * n1, host_tlwe, count * n1 * sizeof(u32),
+                           hipMemcpyHostToDevice, st->s));
+    return IYK_OK;
+}
+
+int iyk_hip_arena_download(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t first_slot, uint64_t count,
+                           uint32_t* host_tlwe)
+{
+    if (!st || !d_arena || !host_tlwe) return fail(IYK_ERR_INVALID, "null argument");
+    int rc = set_device(st->gpu);
+    if (rc) return rc;
+    const size_t n1 = G.p.n + 1;
+    HIP_TRY(hipMemcpyAsync(host_tlwe, d_arena + first_slot * n1, count * n1 * sizeof(u32),
+                           hipMemcpyDeviceToHost, st->s));
+    return IYK_OK;
+}
+
+int iyk_hip_gate_batch(iyk_hip_stream* st, uint32_t* d_arena, uint64_t count, const int32_t* ops,
+                       const int32_t* in0, const int32_t* in1, const int32_t* in2, const int32_t* out)
+{
+    if (!G.init) return fail(IYK_ERR_STATE, "not initialised");
+    if (!st || !d_arena) return fail(IYK_ERR_INVALID, "null argument");
+    if (count == 0) return IYK_OK;
+    if (!ops || !in0 || !in1 || !in2 || !out) return fail(IYK_ERR_INVALID, "null descriptor array");
+    if (count > (1u << 30)) return fail(IYK_ERR_INVALID, "batch too large");
+    int rc = set_device(st->gpu);
+    if (rc) return rc;
+    const iyk_params& p = G.p;
+
+    std::vector<RotJob> rot;
+    std::vector<KsJob> ks;
+    std::vector<EwJob> ew;
+    rot.reserve(count);
+    ks.reserve(count);
+    for (uint64_t g = 0; g < count; ++g) {
+        const int op = ops[g];
+        if (out[g] < 0) return fail(IYK_ERR_INVALID, "negative output slot");
+        int32_t sa, sb;
+        u32 off;
+        if (gate_coeffs(op, p.mu, sa, sb, off)) {
+            if (in0[g] < 0 || in1[g] < 0) return fail(IYK_ERR_INVALID, "binary gate needs two inputs");
+            ks.push_back(KsJob{(int32_t)rot.size(), -1, 0u, out[g]});
+            rot.push_back(RotJob{in0[g], in1[g], sa, sb, off});
+        }
+        else if (op == IYK_OP_MUX) {
+            // HomMUX(cs = in2, c1 = in1, c0 = in0): BR(cs + c1 - mu) + BR(c0 - cs - mu) + (0, mu) -> KS
+            if (in0[g] < 0 || in1[g] < 0 || in2[g] < 0) return fail(IYK_ERR_INVALID, "MUX needs three inputs");
+            ks.push_back(KsJob{(int32_t)rot.size(), (int32_t)rot.size() + 1, p.mu, out[g]});
+            rot.push_back(RotJob{in2[g], in1[g], 1, 1, 0u - p.mu});
+            rot.push_back(RotJob{in0[g], in2[g], 1, -1, 0u - p.mu});
+        }
+        else if (op == IYK_OP_NOT || op == IYK_OP_COPY) {
+            if (in0[g] < 0) return fail(IYK_ERR_INVALID, "NOT/COPY needs one input");
+            ew.push_back(EwJob{op, in0[g], out[g]});
+        }
+        else if (op == IYK_OP_CONSTONE || op == IYK_OP_CONSTZERO) {
+            ew.push_back(EwJob{op, -1, out[g]});
+        }
+        else {
+            return fail(IYK_ERR_INVALID, "unknown gate op");
+        }
+    }
+
+    const size_t rot_bytes = rot.size() * sizeof(RotJob);
+    const size_t ks_bytes = ks.size() * sizeof(KsJob);
+    const size_t ew_bytes = ew.size() * sizeof(EwJob);
+    const size_t ks_off = (rot_bytes + 15) & ~(size_t)15;
+    const size_t ew_off = (ks_off + ks_bytes + 15) & ~(size_t)15;
+    const size_t total = ew_off + ew_bytes;
+    if ((rc = ensure_stage(st, total))) return rc;
+    if ((rc = ensure_rot(st, rot.size()))) return rc;
+    HIP_TRY(hipEventSynchronize(st->stage_free));  // previous descriptor copy has left the pinned buffer
+    if (rot_bytes) std::memcpy(st->h_stage, rot.data(), rot_bytes);
+    if (ks_bytes) std::memcpy(st->h_stage + ks_off, ks.data(), ks_bytes);
+    if (ew_bytes) std::memcpy(st->h_stage + ew_off, ew.data(), ew_bytes);
+    HIP_TRY(hipMemcpyAsync(st->d_stage, st->h_stage, total, hipMemcpyHostToDevice, st->s));
+    HIP_TRY(hipEventRecord(st->stage_free, st->s));
+
+    const Device& D = G.devs[st->gpu];
+    if (!ew.empty()) {
+        hipLaunchKernelGGL(elementwise_kernel, dim3((unsigned)ew.size()), dim3(256), 0, st->s, d_arena,
+                           (const EwJob*)(st->d_stage + ew_off), p.n, p.mu);
+        HIP_TRY(hipGetLastError());
+    }
+    st->timing_valid = false;
+    if (!rot.empty()) {
+        if (st->log_on) {  // fresh events per batch so a whole timed region can be summed afterwards
+            hipEvent_t e3[3];
+            for (auto& e : e3) HIP_TRY(hipEventCreate(&e));
+            st->log_events.insert(st->log_events.end(), e3, e3 + 3);
+            st->ev_br0 = e3[0];
+            st->ev_br1 = e3[1];
+            st->ev_ks1 = e3[2];
+        }
+        HIP_TRY(hipEventRecord(st->ev_br0, st->s));
+        if ((rc = launch_blind_rotate(st, d_arena, (const RotJob*)st->d_stage, (int)rot.size(), st->d_rot)))
+            return rc;
+        HIP_TRY(hipEventRecord(st->ev_br1, st->s));
+        hipLaunchKernelGGL(keyswitch_kernel, dim3((unsigned)ks.size()), dim3(KS_THREADS), 0, st->s, st->d_rot,
+                           (const KsJob*)(st->d_stage + ks_off), D.ksk, d_arena, p.n, p.t, p.basebit,
+                           G.ksk_stride);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(st->ev_ks1, st->s));
+        st->timing_valid = true;
+        st->timing_has_ks = true;
+    }
+    return IYK_OK;
+}
+
+int iyk_hip_gate_host(iyk_hip_stream* st, int op, const uint32_t* in0, const uint32_t* in1,
+                      const uint32_t* in2, uint32_t* out)
+{
+    if (!G.init) return fail(IYK_ERR_STATE, "not initialised");
+    if (!st || !out) return fail(IYK_ERR_INVALID, "null argument");
+    int rc = set_device(st->gpu);
+    if (rc) return rc;
+    const size_t n1 = G.p.n + 1;
+    if (!st->d_scratch) HIP_TRY(hipMalloc((void**)&st->d_scratch, 4 * n1 * sizeof(u32)));
+    const uint32_t* ins[3] = {in0, in1, in2};
+    int32_t idx[3] = {-1, -1, -1};
+    for (int k = 0; k < 3; ++k)
+        if (ins[k]) {
+            HIP_TRY(hipMemcpyAsync(st->d_scratch + (k + 1) * n1, ins[k], n1 * sizeof(u32), hipMemcpyHostToDevice,
+                                   st->s));
+            idx[k] = k + 1;
+        }
+    const int32_t o = 0, opv = op;
+    if ((rc = iyk_hip_gate_batch(st, st->d_scratch, 1, &opv, &idx[0], &idx[1], &idx[2], &o))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, st->d_scratch, n1 * sizeof(u32), hipMemcpyDeviceToHost, st->s));
+    return IYK_OK;
+}
+
+int iyk_hip_blind_rotate_batch(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t count, const int32_t* ia,
+                               const int32_t* ib, const int32_t* sa, const int32_t* sb, const uint32_t* off,
+                               uint32_t* d_tlwe1)
+{
+    if (!G.init) return fail(IYK_ERR_STATE, "not initialised");
+    if (!st || !d_arena || !d_tlwe1 || !ia || !ib || !sa || !sb || !off) return fail(IYK_ERR_INVALID, "null argument");
+    if (count == 0) return IYK_OK;
+    int rc = set_device(st->gpu);
+    if (rc) return rc;
+    std::vector<RotJob> rot(count);
+    for (uint64_t g = 0; g < count; ++g) rot[g] = RotJob{ia[g], ib[g], sa[g], sb[g], off[g]};
+    const size_t bytes = rot.size() * sizeof(RotJob);
+    if ((rc = ensure_stage(st, bytes))) return rc;
+    HIP_TRY(hipEventSynchronize(st->stage_free));
+    std::memcpy(st->h_stage, rot.data(), bytes);
+    HIP_TRY(hipMemcpyAsync(st->d_stage, st->h_stage, bytes, hipMemcpyHostToDevice, st->s));
+    HIP_TRY(hipEventRecord(st->stage_free, st->s));
+    HIP_TRY(hipEventRecord(st->ev_br0, st->s));
+    if ((rc = launch_blind_rotate(st, d_arena, (const RotJob*)st->d_stage, (int)count, d_tlwe1))) return rc;
+    HIP_TRY(hipEventRecord(st->ev_br1, st->s));
+    st->timing_valid = true;
+    st->timing_has_ks = false;
+    return IYK_OK;
+}
+
+int iyk_hip_last_batch_timing(iyk_hip_stream* st, float* blind_rotate_ms, float* keyswitch_ms)
+{
+    if (!st) return fail(IYK_ERR_INVALID, "null stream");
+    if (!st->timing_valid) return fail(IYK_ERR_STATE, "no timed batch on this stream");
+    float br = 0.f, ksm = 0.f;
+    if (st->timing_has_ks) {
+        HIP_TRY(hipEventSynchronize(st->ev_ks1));
+        HIP_TRY(hipEventElapsedTime(&ksm, st->ev_br1, st->ev_ks1));
+    }
+    else {
+        HIP_TRY(hipEventSynchronize(st->ev_br1));
+    }
+    HIP_TRY(hipEventElapsedTime(&br, st->ev_br0, st->ev_br1));
+    if (blind_rotate_ms) *blind_rotate_ms = br;
+    if (keyswitch_ms) *keyswitch_ms = ksm;
+    return IYK_OK;
+}
+
+int iyk_hip_timing_log_begin(iyk_hip_stream* st)
+{
+    if (!st) return fail(IYK_ERR_INVALID, "null stream");
+    if (st->log_on) return fail(IYK_ERR_STATE, "timing log already active");
+    (void)hipEventDestroy(st->ev_br0);
+    (void)hipEventDestroy(st->ev_br1);
+    (void)hipEventDestroy(st->ev_ks1);
+    st->ev_br0 = st->ev_br1 = st->ev_ks1 = nullptr;
+    st->timing_valid = false;
+    st->log_on = true;
+    st->log_events.clear();
+    return IYK_OK;
+}
+
+int iyk_hip_timing_log_end(iyk_hip_stream* st, uint64_t* batches, double* blind_rotate_ms, double* keyswitch_ms)
+{
+    if (!st) return fail(IYK_ERR_INVALID, "null stream");
+    if (!st->log_on) return fail(IYK_ERR_STATE, "timing log not active");
+    HIP_TRY(hipStreamSynchronize(st->s));
+    double br = 0.0, ks = 0.0;
+    const size_t nb = st->log_events.size() / 3;
+    for (size_t b = 0; b < nb; ++b) {
+        float t0 = 0.f, t1 = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t0, st->log_events[3 * b], st->log_events[3 * b + 1]));
+        HIP_TRY(hipEventElapsedTime(&t1, st->log_events[3 * b + 1], st->log_events[3 * b + 2]));
+        br += t0;
+        ks += t1;
+    }
+    for (hipEvent_t e : st->log_events) (void)hipEventDestroy(e);
+    st->log_events.clear();
+    st->log_on = false;
+    // the stream's standing events were replaced by logged ones: make fresh ones
+    HIP_TRY(hipEventCreate(&st->ev_br0));
+    HIP_TRY(hipEventCreate(&st->ev_br1));
+    HIP_TRY(hipEventCreate(&st->ev_ks1));
+    st->timing_valid = false;
+    if (batches) *batches = nb;
+    if (blind_rotate_ms) *blind_rotate_ms = br;
+    if (keyswitch_ms) *keyswitch_ms = ks;
+    return IYK_OK;
+}
+
+}  // extern "C"

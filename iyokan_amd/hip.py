@@ -1,0 +1,222 @@
+"""ctypes binding of libiyokan_hip.so — the C ABI declared in include/iyokan_hip.h.
+
+Host-side mirror of the cuFHE surface Iyokan's GPU worker uses
+(/root/reference/src/iyokan_cufhe.hpp:8-32,249-261; /root/reference/src/iyokan_cufhe.cpp:530-536,721):
+`initialize()` = cufhe::SetGPUNum + cufhe::Initialize, `Stream` = CUFHEStream,
+`Stream.gate_batch` = N x cufhe::Nand/And/.../Mux, `Stream.query` = cufhe::StreamQuery,
+`cleanup()` = cufhe::CleanUp.  There is no CPU fallback: every call goes to the HIP library
+and raises IykHipError if it is missing or reports an error.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from .params import IykParams, OPS
+
+_LIB = None
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_vp = ctypes.c_void_p
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libiyokan_hip.so")
+
+# every symbol include/iyokan_hip.h declares (tests check the built library exports them all)
+EXPORTS = [
+    "iyk_hip_init", "iyk_hip_cleanup", "iyk_hip_is_initialized", "iyk_hip_num_gpus", "iyk_hip_get_params",
+    "iyk_hip_last_error", "iyk_hip_stream_create", "iyk_hip_stream_wrap", "iyk_hip_stream_destroy",
+    "iyk_hip_stream_query", "iyk_hip_stream_sync", "iyk_hip_arena_alloc", "iyk_hip_arena_free",
+    "iyk_hip_arena_upload", "iyk_hip_arena_download", "iyk_hip_gate_batch", "iyk_hip_gate_host",
+    "iyk_hip_blind_rotate_batch", "iyk_hip_last_batch_timing", "iyk_hip_resident_key_bytes",
+    "iyk_hip_timing_log_begin", "iyk_hip_timing_log_end",
+]
+
+
+class IykHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise IykHipError(f"{LIB_PATH} is missing — build it with __graft_entry__.build(); there is no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        L.iyk_hip_last_error.restype = ctypes.c_char_p
+        L.iyk_hip_init.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(IykParams), _u32p, _u32p]
+        L.iyk_hip_get_params.argtypes = [ctypes.POINTER(IykParams)]
+        L.iyk_hip_stream_create.argtypes = [ctypes.c_int, ctypes.POINTER(_vp)]
+        L.iyk_hip_stream_wrap.argtypes = [ctypes.c_int, _vp, ctypes.POINTER(_vp)]
+        for f in ("iyk_hip_stream_destroy", "iyk_hip_stream_query", "iyk_hip_stream_sync"):
+            getattr(L, f).argtypes = [_vp]
+        L.iyk_hip_arena_alloc.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(_vp)]
+        L.iyk_hip_arena_free.argtypes = [ctypes.c_int, _vp]
+        L.iyk_hip_arena_upload.argtypes = [_vp, _vp, ctypes.c_uint64, ctypes.c_uint64, _u32p]
+        L.iyk_hip_arena_download.argtypes = [_vp, _vp, ctypes.c_uint64, ctypes.c_uint64, _u32p]
+        L.iyk_hip_gate_batch.argtypes = [_vp, _vp, ctypes.c_uint64, _i32p, _i32p, _i32p, _i32p, _i32p]
+        L.iyk_hip_gate_host.argtypes = [_vp, ctypes.c_int, _u32p, _u32p, _u32p, _u32p]
+        L.iyk_hip_blind_rotate_batch.argtypes = [_vp, _vp, ctypes.c_uint64, _i32p, _i32p, _i32p, _i32p, _u32p, _vp]
+        L.iyk_hip_last_batch_timing.argtypes = [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+        L.iyk_hip_resident_key_bytes.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+        L.iyk_hip_timing_log_begin.argtypes = [_vp]
+        L.iyk_hip_timing_log_end.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double),
+                                             ctypes.POINTER(ctypes.c_double)]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise IykHipError(f"{what} failed ({rc}): {lib().iyk_hip_last_error().decode()}")
+    return rc
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def initialize(keys, device_ids=(0,)):
+    """cufhe::SetGPUNum(len(device_ids)) + cufhe::Initialize(ek)."""
+    ids = (ctypes.c_int * len(device_ids))(*device_ids)
+    bk = np.ascontiguousarray(keys.bk, dtype=np.uint32)
+    ksk = np.ascontiguousarray(keys.ksk, dtype=np.uint32)
+    _check(lib().iyk_hip_init(len(device_ids), ids, ctypes.byref(keys.params),
+                              bk.ctypes.data_as(_u32p), ksk.ctypes.data_as(_u32p)), "iyk_hip_init")
+
+
+def cleanup():
+    _check(lib().iyk_hip_cleanup(), "iyk_hip_cleanup")
+
+
+def is_initialized():
+    return bool(lib().iyk_hip_is_initialized())
+
+
+def resident_key_bytes():
+    v = ctypes.c_uint64()
+    _check(lib().iyk_hip_resident_key_bytes(ctypes.byref(v)), "iyk_hip_resident_key_bytes")
+    return v.value
+
+
+def current_params():
+    p = IykParams()
+    _check(lib().iyk_hip_get_params(ctypes.byref(p)), "iyk_hip_get_params")
+    return p
+
+
+class Arena:
+    """Device-resident array of TLWE lvl0 ciphertexts, addressed by slot index."""
+
+    def __init__(self, slots, gpu_index=0, device_ptr=None, owner=None):
+        self.slots, self.gpu_index = int(slots), gpu_index
+        self.n1 = current_params().n + 1
+        self._owner = owner  # e.g. the torch tensor backing device_ptr
+        if device_ptr is None:
+            ptr = _vp()
+            _check(lib().iyk_hip_arena_alloc(gpu_index, self.slots, ctypes.byref(ptr)), "iyk_hip_arena_alloc")
+            self.ptr, self._owned = ptr.value, True
+        else:
+            self.ptr, self._owned = int(device_ptr), False
+
+    @classmethod
+    def from_torch(cls, tensor, gpu_index=0):
+        """Wrap a contiguous int32/uint32-sized CUDA tensor of shape (slots, n+1)."""
+        assert tensor.is_cuda and tensor.is_contiguous() and tensor.element_size() == 4
+        return cls(tensor.shape[0], gpu_index, tensor.data_ptr(), owner=tensor)
+
+    def free(self):
+        if self._owned and self.ptr:
+            _check(lib().iyk_hip_arena_free(self.gpu_index, self.ptr), "iyk_hip_arena_free")
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            if is_initialized():
+                self.free()
+        except Exception:
+            pass
+
+
+class Stream:
+    """CUFHEStream equivalent (/root/reference/src/iyokan_cufhe.hpp:8-27)."""
+
+    def __init__(self, gpu_index=0, hip_stream=None):
+        h = _vp()
+        if hip_stream is None:
+            _check(lib().iyk_hip_stream_create(gpu_index, ctypes.byref(h)), "iyk_hip_stream_create")
+        else:
+            _check(lib().iyk_hip_stream_wrap(gpu_index, _vp(int(hip_stream)), ctypes.byref(h)), "iyk_hip_stream_wrap")
+        self.h, self.gpu_index = h, gpu_index
+
+    def destroy(self):
+        if self.h:
+            _check(lib().iyk_hip_stream_destroy(self.h), "iyk_hip_stream_destroy")
+            self.h = None
+
+    def query(self):
+        """cufhe::StreamQuery: True once everything enqueued so far has finished."""
+        return bool(_check(lib().iyk_hip_stream_query(self.h), "iyk_hip_stream_query"))
+
+    def sync(self):
+        _check(lib().iyk_hip_stream_sync(self.h), "iyk_hip_stream_sync")
+
+    def upload(self, arena, first_slot, host):
+        host = np.ascontiguousarray(host, dtype=np.uint32).reshape(-1, arena.n1)
+        assert first_slot + host.shape[0] <= arena.slots
+        _check(lib().iyk_hip_arena_upload(self.h, arena.ptr, first_slot, host.shape[0],
+                                          host.ctypes.data_as(_u32p)), "iyk_hip_arena_upload")
+        self.sync()  # host buffer is pageable: finish before it can be garbage collected
+
+    def download(self, arena, first_slot, count):
+        assert first_slot + count <= arena.slots
+        out = np.zeros((count, arena.n1), dtype=np.uint32)
+        _check(lib().iyk_hip_arena_download(self.h, arena.ptr, first_slot, count,
+                                            out.ctypes.data_as(_u32p)), "iyk_hip_arena_download")
+        self.sync()
+        return out
+
+    def gate_batch(self, arena, ops, in0, in1, in2, out):
+        """`len(ops)` independent gates on arena slots; asynchronous (poll query() / sync())."""
+        ops, in0, in1, in2, out = map(_i32, (ops, in0, in1, in2, out))
+        n = len(ops)
+        assert len(in0) == len(in1) == len(in2) == len(out) == n
+        p = lambda a: a.ctypes.data_as(_i32p)
+        _check(lib().iyk_hip_gate_batch(self.h, arena.ptr, n, p(ops), p(in0), p(in1), p(in2), p(out)),
+               "iyk_hip_gate_batch")
+
+    def gate_host(self, op, in0=None, in1=None, in2=None):
+        """cufhe::Nand(out, in0, in1, st) shape: host in, host out (synchronised here)."""
+        n1 = current_params().n + 1
+        out = np.zeros(n1, dtype=np.uint32)
+        args = [None if a is None else np.ascontiguousarray(a, dtype=np.uint32) for a in (in0, in1, in2)]
+        ptr = lambda a: a.ctypes.data_as(_u32p) if a is not None else None
+        code = OPS[op] if isinstance(op, str) else int(op)
+        _check(lib().iyk_hip_gate_host(self.h, code, ptr(args[0]), ptr(args[1]), ptr(args[2]),
+                                       out.ctypes.data_as(_u32p)), "iyk_hip_gate_host")
+        self.sync()
+        return out
+
+    def blind_rotate_batch(self, arena, ia, ib, sa, sb, off, d_tlwe1_ptr):
+        ia, ib, sa, sb = map(_i32, (ia, ib, sa, sb))
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        p = lambda a: a.ctypes.data_as(_i32p)
+        _check(lib().iyk_hip_blind_rotate_batch(self.h, arena.ptr, len(ia), p(ia), p(ib), p(sa), p(sb),
+                                                off.ctypes.data_as(_u32p), _vp(int(d_tlwe1_ptr))),
+               "iyk_hip_blind_rotate_batch")
+
+    def last_batch_timing(self):
+        """(blind_rotate_ms, keyswitch_ms) of the most recent batch, from HIP events on this stream."""
+        br, ks = ctypes.c_float(), ctypes.c_float()
+        _check(lib().iyk_hip_last_batch_timing(self.h, ctypes.byref(br), ctypes.byref(ks)),
+               "iyk_hip_last_batch_timing")
+        return br.value, ks.value
+
+    def timing_log_begin(self):
+        _check(lib().iyk_hip_timing_log_begin(self.h), "iyk_hip_timing_log_begin")
+
+    def timing_log_end(self):
+        """(batches, blind_rotate_ms_total, keyswitch_ms_total) since timing_log_begin(); synchronises."""
+        nb, br, ks = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_double()
+        _check(lib().iyk_hip_timing_log_end(self.h, ctypes.byref(nb), ctypes.byref(br), ctypes.byref(ks)),
+               "iyk_hip_timing_log_end")
+        return nb.value, br.value, ks.value

@@ -1,0 +1,88 @@
+"""ctypes binding of oracle/libiyk_oracle.so — test infrastructure only (see oracle/tfhe_oracle.c)."""
+import ctypes
+import os
+
+import numpy as np
+
+from iyokan_amd.params import IykParams
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_ROOT, "oracle", "libiyk_oracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `make -C oracle`")
+        L = ctypes.CDLL(path)
+        L.orc_new.restype = ctypes.c_void_p
+        L.orc_new.argtypes = [ctypes.POINTER(IykParams), _u32p, _u32p]
+        L.orc_free.argtypes = [ctypes.c_void_p]
+        L.orc_gate.argtypes = [ctypes.c_void_p, ctypes.c_int, _u32p, _u32p, _u32p, _u32p, ctypes.c_int]
+        L.orc_gate_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint32, _i32p, _i32p, _i32p, _i32p, _i32p, _u32p, ctypes.c_int]
+        L.orc_blind_rotate.argtypes = [ctypes.c_void_p, _u32p, _u32p, ctypes.c_int]
+        L.orc_sample_extract0.argtypes = [ctypes.c_void_p, _u32p, _u32p]
+        L.orc_keyswitch.argtypes = [ctypes.c_void_p, _u32p, _u32p]
+        L.orc_tlwe1_phase.restype = ctypes.c_uint32
+        L.orc_tlwe1_phase.argtypes = [ctypes.POINTER(IykParams), _u32p, _u32p]
+        L.orc_selfcheck_product.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64]
+        L.orc_selfcheck_field.argtypes = [ctypes.c_uint64, ctypes.c_uint32]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(_u32p) if a is not None else None
+
+
+class Oracle:
+    def __init__(self, keys):
+        self.keys = keys
+        self.p = keys.params
+        self.ctx = lib().orc_new(ctypes.byref(self.p), _p(keys.bk), _p(keys.ksk))
+
+    def close(self):
+        if self.ctx:
+            lib().orc_free(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        self.close()
+
+    def gate(self, op, in0=None, in1=None, in2=None, schoolbook=False):
+        out = np.zeros(self.p.n + 1, dtype=np.uint32)
+        args = [None if a is None else np.ascontiguousarray(a, dtype=np.uint32) for a in (in0, in1, in2)]
+        lib().orc_gate(self.ctx, int(op), _p(args[0]), _p(args[1]), _p(args[2]), _p(out), int(schoolbook))
+        return out
+
+    def gate_batch(self, ops, in0, in1, in2, out, arena, nthreads=1):
+        """Same addressing as iyk_hip_gate_batch; arena (slots, n+1) uint32 is updated in place."""
+        conv = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        ops, in0, in1, in2, out = map(conv, (ops, in0, in1, in2, out))
+        assert arena.dtype == np.uint32 and arena.flags["C_CONTIGUOUS"]
+        ip = lambda a: a.ctypes.data_as(_i32p)
+        lib().orc_gate_batch(self.ctx, len(ops), ip(ops), ip(in0), ip(in1), ip(in2), ip(out), _p(arena), nthreads)
+        return arena
+
+    def bootstrap_lvl1(self, lin, schoolbook=False):
+        """blind rotate + sample extract(0): lvl0 TLWE -> lvl1 TLWE (N+1 words)."""
+        lin = np.ascontiguousarray(lin, dtype=np.uint32)
+        acc = np.zeros((self.p.k + 1) * self.p.N, dtype=np.uint32)
+        lib().orc_blind_rotate(self.ctx, _p(lin), _p(acc), int(schoolbook))
+        t1 = np.zeros(self.p.N + 1, dtype=np.uint32)
+        lib().orc_sample_extract0(self.ctx, _p(acc), _p(t1))
+        return t1
+
+    def keyswitch(self, tlwe1):
+        tlwe1 = np.ascontiguousarray(tlwe1, dtype=np.uint32)
+        out = np.zeros(self.p.n + 1, dtype=np.uint32)
+        lib().orc_keyswitch(self.ctx, _p(tlwe1), _p(out))
+        return out
+
+    def tlwe1_phase(self, t1):
+        t1 = np.ascontiguousarray(t1, dtype=np.uint32)
+        return lib().orc_tlwe1_phase(ctypes.byref(self.p), _p(t1), _p(self.keys.s1))

@@ -1,0 +1,213 @@
+"""GPU parity proper: the HIP path, called through the C ABI, against the oracle on the same
+seeded inputs (bit-exact), against the committed golden digests, and through size-independent
+properties at the full BASELINE size."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from iyokan_amd import client
+from iyokan_amd.params import OPS, PLAIN
+
+pytestmark = pytest.mark.gpu
+GOLD_DIR = os.path.join(os.path.dirname(__file__), "golden")
+TT = json.load(open(os.path.join(GOLD_DIR, "truth_tables.json")))
+BINOPS = ["AND", "NAND", "ANDNOT", "OR", "NOR", "ORNOT", "XOR", "XNOR"]
+
+
+@pytest.fixture(scope="module")
+def gpu128(keys128):
+    from iyokan_amd import hip
+
+    hip.initialize(keys128, device_ids=(0,))
+    st = hip.Stream(0)
+    yield hip, st
+    st.destroy()
+    hip.cleanup()
+
+
+def _run(hip, st, arena_host, ops, in0, in1, in2, out):
+    arena = hip.Arena(arena_host.shape[0])
+    st.upload(arena, 0, arena_host)
+    st.gate_batch(arena, ops, in0, in1, in2, out)
+    st.sync()
+    got = st.download(arena, 0, arena_host.shape[0])
+    arena.free()
+    return got
+
+
+def test_all_gate_kinds_bit_exact_vs_oracle(gpu128, keys128, oracle128):
+    hip, st = gpu128
+    p = keys128.params
+    rng = np.random.default_rng(3)
+    nin = 64
+    bits = rng.integers(0, 2, size=nin).astype(np.uint8)
+    kinds = BINOPS * 3 + ["MUX"] * 6 + ["NOT", "COPY", "CONSTONE", "CONSTZERO"]
+    ops, in0, in1, in2, out, want = [], [], [], [], [], []
+    for g, kind in enumerate(kinds):
+        a, b, s = (int(v) for v in rng.integers(0, nin, size=3))
+        ops.append(OPS[kind])
+        out.append(nin + g)
+        if kind in BINOPS:
+            in0.append(a); in1.append(b); in2.append(-1); want.append(PLAIN[kind](int(bits[a]), int(bits[b])))
+        elif kind == "MUX":
+            in0.append(a); in1.append(b); in2.append(s); want.append(PLAIN["MUX"](int(bits[a]), int(bits[b]), int(bits[s])))
+        elif kind in ("NOT", "COPY"):
+            in0.append(a); in1.append(-1); in2.append(-1); want.append(PLAIN[kind](int(bits[a])))
+        else:
+            in0.append(-1); in1.append(-1); in2.append(-1); want.append(PLAIN[kind]())
+    host = np.zeros((nin + len(kinds), p.n + 1), dtype=np.uint32)
+    host[:nin] = client.encrypt_bits(keys128, bits, seed=2)
+    got = _run(hip, st, host, ops, in0, in1, in2, out)
+    ref = host.copy()
+    oracle128.gate_batch(ops, in0, in1, in2, out, ref, nthreads=os.cpu_count() or 1)
+    assert np.array_equal(got[:nin], host[:nin])             # inputs untouched
+    assert np.array_equal(got[nin:], ref[nin:])              # bit-exact vs oracle
+    assert list(client.decrypt_bits(keys128, got[nin:])) == want
+
+
+def test_reference_truth_tables_on_gpu(gpu128, keys128):
+    """test0-style known answers (/root/reference/src/test0.cpp:86-94,130-136) on fresh encryptions."""
+    hip, st = gpu128
+    p = keys128.params
+    host = np.zeros((2 + 32 + 8 + 2, p.n + 1), dtype=np.uint32)
+    host[:2] = client.encrypt_bits(keys128, [0, 1], seed=5)
+    ops, in0, in1, in2, out, want = [], [], [], [], [], []
+    slot = 2
+    for kind in BINOPS:
+        for (a, b), w in zip(TT["binary_inputs"], TT[kind]):
+            ops.append(OPS[kind]); in0.append(a); in1.append(b); in2.append(-1); out.append(slot); want.append(w); slot += 1
+    for a, b, s, w in TT["MUX"]:
+        ops.append(OPS["MUX"]); in0.append(a); in1.append(b); in2.append(s); out.append(slot); want.append(w); slot += 1
+    for a, w in TT["NOT"]:
+        ops.append(OPS["NOT"]); in0.append(a); in1.append(-1); in2.append(-1); out.append(slot); want.append(w); slot += 1
+    got = _run(hip, st, host, ops, in0, in1, in2, out)
+    assert list(client.decrypt_bits(keys128, got[2:])) == want
+
+
+def test_trivial_inputs(gpu128, keys128, oracle128):
+    """The reference's own GPU tests use trivial ciphertexts (test0.cpp:702-710): every abar is 0."""
+    hip, st = gpu128
+    p = keys128.params
+    host = np.zeros((6, p.n + 1), dtype=np.uint32)
+    host[0], host[1] = client.trivial(p, 0), client.trivial(p, 1)
+    ops = [OPS["NAND"]] * 4
+    in0, in1 = [0, 0, 1, 1], [0, 1, 0, 1]
+    got = _run(hip, st, host, ops, in0, in1, [-1] * 4, [2, 3, 4, 5])
+    ref = host.copy()
+    oracle128.gate_batch(ops, in0, in1, [-1] * 4, [2, 3, 4, 5], ref, nthreads=4)
+    assert np.array_equal(got, ref)
+    assert list(client.decrypt_bits(keys128, got[2:])) == TT["NAND"]
+
+
+def test_golden_digests(gpu128, keys128):
+    """Committed fixture (tests/golden/make_vectors.py, generated with the oracle in the build
+    container): sha256 of each output ciphertext for seeded keys/inputs."""
+    hip, st = gpu128
+    gold = json.load(open(os.path.join(GOLD_DIR, "gate_vectors_128.json")))
+    p = keys128.params
+    assert gold["key_seed"] == 1 and gold["params"]["n"] == p.n
+    bits = np.array(gold["input_bits"], dtype=np.uint8)
+    host = np.zeros((len(bits) + len(gold["gates"]), p.n + 1), dtype=np.uint32)
+    host[: len(bits)] = client.encrypt_bits(keys128, bits, seed=gold["data_seed"])
+    assert hashlib.sha256(host[: len(bits)].tobytes()).hexdigest() == gold["inputs_sha256"]
+    g = gold["gates"]
+    got = _run(hip, st, host, [OPS[x["op"]] for x in g], [x["in0"] for x in g], [x["in1"] for x in g],
+               [x["in2"] for x in g], [x["out"] for x in g])
+    for x in g:
+        assert hashlib.sha256(got[x["out"]].tobytes()).hexdigest() == x["sha256"], x
+        assert int(client.decrypt_bits(keys128, got[x["out"]])[0]) == x["bit"]
+
+
+def test_host_pointer_gate_and_stream_query(gpu128, keys128, oracle128):
+    """cufhe::Nand(out, in0, in1, st) shape + StreamQuery polling."""
+    hip, st = gpu128
+    ca, cb = client.encrypt_bits(keys128, [1, 0], seed=77)
+    got = st.gate_host("NAND", ca, cb)
+    assert st.query() is True
+    assert np.array_equal(got, oracle128.gate(OPS["NAND"], ca, cb))
+    st2 = hip.Stream(0)
+    got2 = st2.gate_host("MUX", ca, cb, ca)
+    assert np.array_equal(got2, oracle128.gate(OPS["MUX"], ca, cb, ca))
+    st2.destroy()
+
+
+def test_ragged_and_empty_batches(gpu128, keys128, oracle128):
+    hip, st = gpu128
+    p = keys128.params
+    bits = np.array([1, 0, 1], dtype=np.uint8)
+    host = np.zeros((3 + 5, p.n + 1), dtype=np.uint32)
+    host[:3] = client.encrypt_bits(keys128, bits, seed=31)
+    arena = hip.Arena(8)
+    st.upload(arena, 0, host)
+    st.gate_batch(arena, [], [], [], [], [])            # empty batch is a no-op
+    for count in (1, 3, 5):                             # odd sizes: last workgroup is partly idle
+        ops = [OPS["XOR"]] * count
+        in0 = [i % 3 for i in range(count)]
+        in1 = [(i + 1) % 3 for i in range(count)]
+        out = [3 + i for i in range(count)]
+        st.gate_batch(arena, ops, in0, in1, [-1] * count, out)
+        st.sync()
+        got = st.download(arena, 0, 8)
+        ref = host.copy()
+        oracle128.gate_batch(ops, in0, in1, [-1] * count, out, ref, nthreads=4)
+        assert np.array_equal(got[3:3 + count], ref[3:3 + count])
+    arena.free()
+    with pytest.raises(hip.IykHipError):
+        st.gate_batch(hip.Arena(1), [OPS["NAND"]], [0], [-1], [-1], [0])  # binary gate without in1
+
+
+def test_chained_levels_stay_on_device(gpu128, keys128):
+    """Depth-4 NAND chain on the arena without host round trips; decrypts like the plaintext."""
+    hip, st = gpu128
+    p = keys128.params
+    rng = np.random.default_rng(11)
+    width = 16
+    bits = rng.integers(0, 2, size=2 * width).astype(np.uint8)
+    arena = hip.Arena(2 * width + 4 * width)
+    st.upload(arena, 0, client.encrypt_bits(keys128, bits, seed=4))
+    plain = list(map(int, bits))
+    prev = list(range(2 * width))
+    base = 2 * width
+    for level in range(4):
+        in0 = [prev[(2 * i) % len(prev)] for i in range(width)]
+        in1 = [prev[(2 * i + 1 + level) % len(prev)] for i in range(width)]
+        out = [base + i for i in range(width)]
+        st.gate_batch(arena, [OPS["NAND"]] * width, in0, in1, [-1] * width, out)
+        plain += [1 - (plain[a] & plain[b]) for a, b in zip(in0, in1)]
+        prev, base = out, base + width
+    st.sync()
+    got = st.download(arena, 0, 6 * width)
+    assert list(client.decrypt_bits(keys128, got)) == plain
+    arena.free()
+
+
+def test_full_size_flat_nand_property(gpu128, keys128, oracle128):
+    """BASELINE config #2 shape (65 536 independent NANDs, fresh encryptions): every output
+    decrypts to NAND of the plaintexts; a 64-gate sample is bit-equal to the oracle."""
+    hip, st = gpu128
+    p = keys128.params
+    G = 65536
+    rng = np.random.default_rng(2)
+    nin = 4096                                # inputs are re-used across gates to bound host keygen time
+    bits = rng.integers(0, 2, size=nin).astype(np.uint8)
+    ia = rng.integers(0, nin, size=G).astype(np.int32)
+    ib = rng.integers(0, nin, size=G).astype(np.int32)
+    arena = hip.Arena(nin + G)
+    enc = client.encrypt_bits(keys128, bits, seed=2)
+    st.upload(arena, 0, enc)
+    out = np.arange(nin, nin + G, dtype=np.int32)
+    st.gate_batch(arena, np.full(G, OPS["NAND"], dtype=np.int32), ia, ib, np.full(G, -1, dtype=np.int32), out)
+    st.sync()
+    got = st.download(arena, nin, G)
+    arena.free()
+    want = 1 - (bits[ia] & bits[ib])
+    assert np.array_equal(client.decrypt_bits(keys128, got), want)
+    sample = rng.choice(G, size=64, replace=False)
+    ref = np.zeros((nin + 64, p.n + 1), dtype=np.uint32)
+    ref[:nin] = enc
+    oracle128.gate_batch([OPS["NAND"]] * 64, ia[sample], ib[sample], [-1] * 64,
+                         list(range(nin, nin + 64)), ref, nthreads=os.cpu_count() or 1)
+    assert np.array_equal(got[sample], ref[nin:])

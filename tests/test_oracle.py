@@ -1,0 +1,91 @@
+"""Oracle pinning (CPU): the reference's decrypt-level truth tables, the schoolbook anchor,
+and noise margins.  Ciphertext-level parity with TFHEpp is unpinned (see oracle header)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from iyokan_amd import client
+from iyokan_amd.params import OPS, PLAIN
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "truth_tables.json")))
+BINOPS = ["AND", "NAND", "ANDNOT", "OR", "NOR", "ORNOT", "XOR", "XNOR"]
+
+
+def test_selfchecks():
+    L = oracle_lib.lib()
+    assert L.orc_selfcheck_field(123, 2_000_000) == 0
+    assert L.orc_selfcheck_product(1024, 32, 5) == 0     # Bg/2 = 32 (128-bit set)
+    assert L.orc_selfcheck_product(1024, 512, 6) == 0    # Bg/2 = 512 (80-bit set)
+    assert L.orc_selfcheck_product(256, 512, 7) == 0
+
+
+def test_plain_semantics_match_reference_tables():
+    for op in BINOPS:
+        assert [PLAIN[op](a, b) for a, b in GOLD["binary_inputs"]] == GOLD[op]
+    assert all(PLAIN["MUX"](a, b, s) == o for a, b, s, o in GOLD["MUX"])
+    assert all(PLAIN["NOT"](a) == o for a, o in GOLD["NOT"])
+
+
+@pytest.mark.parametrize("op", BINOPS)
+def test_binary_gate_truth_table(op, keys128, oracle128):
+    for (a, b), want in zip(GOLD["binary_inputs"], GOLD[op]):
+        ca = client.encrypt_bits(keys128, [a], seed=100 + a)[0]
+        cb = client.encrypt_bits(keys128, [b], seed=200 + b)[0]
+        out = oracle128.gate(OPS[op], ca, cb)
+        assert int(client.decrypt_bits(keys128, out)[0]) == want
+        # comfortable margin: |phase| within 1/16 of +-1/8
+        ph = np.int32(client.phases(keys128, out)[0])
+        assert abs(abs(int(ph)) - (1 << 29)) < (1 << 28)
+
+
+def test_mux_not_const_truth_tables(keys128, oracle128):
+    for a, b, s, want in GOLD["MUX"]:
+        ca, cb, cs = (client.encrypt_bits(keys128, [v], seed=300 + i)[0] for i, v in enumerate((a, b, s)))
+        out = oracle128.gate(OPS["MUX"], ca, cb, cs)
+        assert int(client.decrypt_bits(keys128, out)[0]) == want
+    for a, want in GOLD["NOT"]:
+        ca = client.encrypt_bits(keys128, [a], seed=400)[0]
+        assert int(client.decrypt_bits(keys128, oracle128.gate(OPS["NOT"], ca))[0]) == want
+    assert int(client.decrypt_bits(keys128, oracle128.gate(OPS["CONSTONE"]))[0]) == 1
+    assert int(client.decrypt_bits(keys128, oracle128.gate(OPS["CONSTZERO"]))[0]) == 0
+    assert np.array_equal(oracle128.gate(OPS["CONSTONE"]), client.trivial(keys128.params, 1))
+
+
+def test_trivial_inputs_like_reference_gpu_tests(keys128, oracle128):
+    # /root/reference/src/test0.cpp:702-710 feeds the GPU backend trivial ciphertexts
+    t0, t1 = client.trivial(keys128.params, 0), client.trivial(keys128.params, 1)
+    for (a, b), want in zip(GOLD["binary_inputs"], GOLD["NAND"]):
+        out = oracle128.gate(OPS["NAND"], t1 if a else t0, t1 if b else t0)
+        assert int(client.decrypt_bits(keys128, out)[0]) == want
+
+
+@pytest.mark.slow
+def test_ntt_path_equals_schoolbook_path(keys128, oracle128):
+    """Whole-gate anchor: exact-NTT blind rotation == uint32 schoolbook blind rotation."""
+    ca = client.encrypt_bits(keys128, [1], seed=11)[0]
+    cb = client.encrypt_bits(keys128, [0], seed=12)[0]
+    lin = (np.uint32(0) - ca - cb).astype(np.uint32)
+    lin[-1] += np.uint32(keys128.params.mu)
+    a = oracle128.bootstrap_lvl1(lin, schoolbook=False)
+    b = oracle128.bootstrap_lvl1(lin, schoolbook=True)
+    assert np.array_equal(a, b)
+
+
+def test_80bit_set(keys80, oracle80):
+    for (a, b), want in zip(GOLD["binary_inputs"], GOLD["XOR"]):
+        ca = client.encrypt_bits(keys80, [a], seed=1)[0]
+        cb = client.encrypt_bits(keys80, [b], seed=2)[0]
+        assert int(client.decrypt_bits(keys80, oracle80.gate(OPS["XOR"], ca, cb))[0]) == want
+
+
+def test_gate_batch_addressing(keys128, oracle128):
+    bits = np.array([0, 1, 1, 0], dtype=np.uint8)
+    p = keys128.params
+    arena = np.zeros((8, p.n + 1), dtype=np.uint32)
+    arena[:4] = client.encrypt_bits(keys128, bits, seed=9)
+    oracle128.gate_batch([OPS["NAND"], OPS["MUX"], OPS["NOT"], OPS["COPY"]], [0, 0, 3, 1], [1, 1, -1, -1],
+                         [-1, 2, -1, -1], [4, 5, 6, 7], arena, nthreads=4)
+    assert list(client.decrypt_bits(keys128, arena[4:])) == [1, 1, 1, 1]
