@@ -2,6 +2,7 @@
 // (blind_rotate_core.hpp).  TEST SUPPORT: lets tests/test_kernel_emulation.py check the
 // kernel's exact data flow (index maps, transposes, MAC, lift) against the oracle in this
 // GPU-less container.  Not loaded by the product path.  Built as libiyk_emul.so.
+#include <cstdint>
 #include <cstring>
 #include <vector>
 
@@ -21,10 +22,11 @@ const Tables& tables()
     return t;
 }
 
-void forward_1024(const u64* in, u64* out)
+// forward transform of one polynomial into the device BK layout (bk_dev_index within a polynomial)
+void forward_1024_dev(const u64* in, u64* out)
 {
     const Tables& T = tables();
-    static thread_local u64 xbuf[XB_WORDS];
+    static thread_local u64 xbuf[32 * XB_STRIDE];
     u64 x[32];
     for (int t = 0; t < 32; ++t) {
         for (int j2 = 0; j2 < 32; ++j2) x[j2] = in[t + 32 * j2];
@@ -34,68 +36,118 @@ void forward_1024(const u64* in, u64* out)
     for (int t = 0; t < 32; ++t) {
         for (int j1 = 0; j1 < 32; ++j1) x[j1] = xbuf[t * XB_STRIDE + j1];
         ntt_fwd_pass2(x);
-        for (int p = 0; p < 32; ++p) out[t + 32 * brv5(p)] = x[p];
+        for (int p = 0; p < 32; ++p) {
+            const int k1 = brv5(p);
+            out[(size_t)(k1 >> 1) * 64 + t * 2 + (k1 & 1)] = x[p];
+        }
     }
 }
 
+// lane-by-lane run of kernels.hpp::blind_rotate_kernel (same phase functions, same order,
+// one loop over the 64 lanes wherever the kernel has an lds_sync)
 template <int L, int BGBIT>
 void blind_rotate(const iyk_params* p, const u32* lin, const u64* bk_ntt, u32* tlwe1)
 {
     const Tables& T = tables();
-    std::vector<u32> acc(2 * NTT_N);
-    std::vector<u64> xb(2 * XB_WORDS);
+    std::vector<u64> twf_t(NTT_N), twi_t(NTT_N);
+    for (int e = 0; e < NTT_N; ++e) {
+        const int a = e >> 5, b = e & 31;
+        twf_t[b * 32 + a] = T.fwd[e];
+        twi_t[b * 32 + a] = T.inv[e];
+    }
+    std::vector<u32> wave_lds(BR_WAVE_LDS_WORDS + 2);  // +2: keep the u64 view of xb 8-byte aligned
+    u32* acc_lds = wave_lds.data() + ((reinterpret_cast<uintptr_t>(wave_lds.data()) & 7) ? 1 : 0);
     struct Lane {
-        u32 td[32];
-        u64 x[32];
-        u64 accum[32];
+        u32 lo[32];
+        u64 x[32], accum[32];
     };
     std::vector<Lane> R(64);
+    auto acc_h = [&](int lane) { return acc_lds + (lane >> 5) * NTT_N; };
+    auto xb = [&](int lane) { return acc_lds + 2 * NTT_N + (lane >> 5) * XB_WORDS32; };
+    auto xb64_own = [&](int lane) { return reinterpret_cast<u64*>(xb(lane)); };
+    auto xb64_oth = [&](int lane) {
+        return reinterpret_cast<const u64*>(acc_lds + 2 * NTT_N + (1 - (lane >> 5)) * XB_WORDS32);
+    };
+#define ALL_LANES for (int lane = 0; lane < 64; ++lane)
 
     const u32 bbar = br_modswitch_b(lin[p->n]);
-    for (int lane = 0; lane < 64; ++lane) br_init_acc(lane, bbar, p->mu, acc.data());
+    ALL_LANES br_init_acc(lane >> 5, lane & 31, bbar, p->mu, acc_h(lane));
 
     for (u32 i = 0; i < p->n; ++i) {
         const u32 abar = br_modswitch_a(lin[i]);
         const u64* bk_step = bk_ntt + (size_t)i * (2 * L) * 2 * NTT_N;
-        for (int lane = 0; lane < 64; ++lane) {
-            br_rotate_diff(lane >> 5, lane & 31, abar, acc.data(), R[lane].td);
-            for (int q = 0; q < 32; ++q) R[lane].accum[q] = 0;
+        ALL_LANES for (int q = 0; q < 32; ++q) R[lane].accum[q] = 0;
+        for (int pass = 0; pass < 2 * L + 2; ++pass) {
+            const int lvl = pass >> 1;
+            const bool fwd = pass < 2 * L, first = (pass & 1) == 0;
+            ALL_LANES
+            {
+                Lane& r = R[lane];
+                if (first) {
+                    if (fwd) br_fwd1_pre<L, BGBIT>(lane & 31, lvl, abar, acc_h(lane), r.x);
+                    else
+                        for (int q = 0; q < 32; ++q) r.x[q] = r.accum[q];
+                }
+                ntt32_dif<LOG_W32>(r.x);
+            }
+            if (first) {
+                ALL_LANES
+                {
+                    if (fwd) {
+                        br_fwd1_twiddle(lane & 31, R[lane].x, twf_t.data());
+                        br_xpose_write<false>(lane & 31, R[lane].x, xb(lane), false);
+                    }
+                    else {
+                        br_inv1_twiddle(lane & 31, R[lane].x, twi_t.data());
+                        br_xpose_write<true>(lane & 31, R[lane].x, xb(lane), false);
+                    }
+                }
+                ALL_LANES br_xpose_read_lo(lane & 31, R[lane].lo, xb(lane));
+                ALL_LANES
+                {
+                    if (fwd) br_xpose_write<false>(lane & 31, R[lane].x, xb(lane), true);
+                    else br_xpose_write<true>(lane & 31, R[lane].x, xb(lane), true);
+                }
+                ALL_LANES br_xpose_read_hi(lane & 31, R[lane].x, R[lane].lo, xb(lane));
+            }
+            else if (fwd) {
+                for (int chunk = 0; chunk < 2; ++chunk) {
+                    ALL_LANES br_share_write(lane & 31, chunk, R[lane].x, xb64_own(lane));
+                    ALL_LANES
+                    {
+                        const int h = lane >> 5, t = lane & 31;
+                        const u64* bko = bk_row_own<L>(bk_step, h, t, lvl);
+                        const u64* bkt = bk_row_oth<L>(bk_step, h, t, lvl);
+                        for (int m = chunk * 8; m < chunk * 8 + 8; ++m) {
+                            const u64 bo[2] = {bko[m * 64], bko[m * 64 + 1]};
+                            const u64 bt[2] = {bkt[m * 64], bkt[m * 64 + 1]};
+                            br_mac_pair(t, m, R[lane].x, xb64_oth(lane), bo, bt, R[lane].accum);
+                        }
+                    }
+                }
+            }
+            else {
+                ALL_LANES br_inv2_post(lane & 31, R[lane].x, acc_h(lane));
+            }
         }
-        for (int lvl = 0; lvl < L; ++lvl) {
-            for (int lane = 0; lane < 64; ++lane)
-                br_fwd_pass1<L, BGBIT>(lane & 31, lvl, R[lane].td, R[lane].x, T.fwd.data(),
-                                       xb.data() + (lane >> 5) * XB_WORDS);
-            for (int lane = 0; lane < 64; ++lane)
-                br_read_row(lane & 31, R[lane].x, xb.data() + (lane >> 5) * XB_WORDS);
-            for (int lane = 0; lane < 64; ++lane)
-                br_fwd_pass2_share(lane & 31, R[lane].x, xb.data() + (lane >> 5) * XB_WORDS);
-            for (int lane = 0; lane < 64; ++lane)
-                br_mac<L>(lane >> 5, lane & 31, lvl, R[lane].x,
-                          xb.data() + (1 - (lane >> 5)) * XB_WORDS, bk_step, R[lane].accum);
-        }
-        for (int lane = 0; lane < 64; ++lane)
-            br_inv_pass1(lane & 31, R[lane].accum, T.inv.data(), xb.data() + (lane >> 5) * XB_WORDS);
-        for (int lane = 0; lane < 64; ++lane)
-            br_read_row(lane & 31, R[lane].x, xb.data() + (lane >> 5) * XB_WORDS);
-        for (int lane = 0; lane < 64; ++lane)
-            br_inv_pass2_update(lane >> 5, lane & 31, R[lane].x, acc.data());
     }
-    tlwe1[0] = acc[0];
-    for (u32 j = 1; j < (u32)NTT_N; ++j) tlwe1[j] = 0u - acc[NTT_N - j];
-    tlwe1[NTT_N] = acc[NTT_N];
+    tlwe1[0] = acc_lds[0];
+    for (u32 j = 1; j < (u32)NTT_N; ++j) tlwe1[j] = 0u - acc_lds[NTT_N - j];
+    tlwe1[NTT_N] = acc_lds[NTT_N];
+#undef ALL_LANES
 }
 }  // namespace
 
 extern "C" {
 
-// bk_ntt[q][k] for every polynomial q of the torus-domain BK, natural k order
+// NTT of every polynomial q of the torus-domain BK, stored in the device layout (bk_dev_index)
 int iyk_emul_bk_ntt(const iyk_params* p, const uint32_t* bk, uint64_t* bk_ntt)
 {
     const size_t polys = (size_t)iyk_bk_words(p) / p->N;
     std::vector<u64> in(NTT_N);
     for (size_t q = 0; q < polys; ++q) {
         for (int x = 0; x < NTT_N; ++x) in[x] = bk[q * NTT_N + x];
-        forward_1024(in.data(), bk_ntt + q * NTT_N);
+        forward_1024_dev(in.data(), bk_ntt + q * NTT_N);
     }
     return 0;
 }

@@ -68,11 +68,54 @@ IYK_HD void mul64wide(u64 a, u64 b, u64& hi, u64& lo)
 #endif
 }
 
+// (hi:lo) mod P without the final canonicalisation: result is congruent but may lie in
+// [P, 2^64).  Safe as ONE operand of gl_add (the other canonical); not as an operand of gl_sub.
+IYK_HD u64 gl_reduce128_weak(u64 hi, u64 lo)
+{
+    const u32 hh = (u32)(hi >> 32), hl = (u32)hi;
+    u64 t0 = lo - hh;
+    if (lo < hh) t0 -= GL_EPS;
+    u64 r = (u64)hl * GL_EPS + t0;  // one v_mad_u64_u32
+    if (r < t0) r += GL_EPS;
+    return r;
+}
+
+IYK_HD u64 gl_canon(u64 r) { return r >= GL_P ? r - GL_P : r; }
+
 IYK_HD u64 gl_mul(u64 a, u64 b)
 {
     u64 hi, lo;
     mul64wide(a, b, hi, lo);
-    return gl_reduce128(hi, lo);
+    return gl_canon(gl_reduce128_weak(hi, lo));
+}
+
+IYK_HD u64 gl_mul_weak(u64 a, u64 b)
+{
+    u64 hi, lo;
+    mul64wide(a, b, hi, lo);
+    return gl_reduce128_weak(hi, lo);
+}
+
+// small (< 2^31) times field constant: 32 x 64 -> 96 bits, high limb < 2^31 so the reduction is
+// just lo64 + top * (2^32 - 1); canonical result.
+IYK_HD u64 gl_mul_small(u32 a, u64 c)
+{
+    const u64 p0 = (u64)a * (u32)c;                       // a * c_lo
+    const u64 p1 = (u64)a * (u32)(c >> 32) + (p0 >> 32);  // a * c_hi + carry, < 2^63
+    const u64 lo = (p1 << 32) | (u32)p0;
+    const u32 top = (u32)(p1 >> 32);
+    u64 r = (u64)top * GL_EPS + lo;
+    if (r < lo) r += GL_EPS;
+    return gl_canon(r);
+}
+
+// compile-time 2^s mod P (s < 192) and small multiples of it, for twist constants
+constexpr u64 gl_cmulmod(u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) % GL_P); }
+constexpr u64 gl_cpow2(unsigned s)
+{
+    u64 r = 1;
+    for (unsigned i = 0; i < s; ++i) r = gl_cmulmod(r, 2);
+    return r;
 }
 
 // x * 2^s mod P for 0 <= s < 192.  In the kernels s is a compile-time constant after

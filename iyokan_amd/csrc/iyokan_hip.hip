@@ -67,6 +67,7 @@ struct iyk_hip_stream {
     hipEvent_t stage_free = nullptr;  // last H2D descriptor copy done -> pinned buffer reusable
     // blind-rotation outputs (TLWE lvl1), one row per rotation job
     u32* d_rot = nullptr;
+    u32* d_abar = nullptr;  // mod-switched rotation inputs, one row of ABAR_STRIDE words per job
     size_t rot_cap = 0;
     // timing of the most recent batch
     hipEvent_t ev_br0 = nullptr, ev_br1 = nullptr, ev_ks1 = nullptr;
@@ -79,6 +80,8 @@ struct iyk_hip_stream {
 };
 
 namespace {
+
+constexpr u32 ABAR_STRIDE = 1024;  // words per job in d_abar (n + 1 <= 768 used)
 
 int set_device(int gpu)
 {
@@ -107,29 +110,48 @@ int ensure_rot(iyk_hip_stream* st, size_t jobs)
     if (jobs <= st->rot_cap) return IYK_OK;
     HIP_TRY(hipStreamSynchronize(st->s));
     if (st->d_rot) HIP_TRY(hipFree(st->d_rot));
+    if (st->d_abar) HIP_TRY(hipFree(st->d_abar));
     st->d_rot = nullptr;
+    st->d_abar = nullptr;
     size_t cap = jobs + jobs / 2 + 64;
     HIP_TRY(hipMalloc((void**)&st->d_rot, cap * (NTT_N + 1) * sizeof(u32)));
+    HIP_TRY(hipMalloc((void**)&st->d_abar, cap * ABAR_STRIDE * sizeof(u32)));
     st->rot_cap = cap;
     return IYK_OK;
 }
 
+template <int L, int BGBIT>
+int launch_br(iyk_hip_stream* st, int njobs, u32* d_tlwe1)
+{
+    static bool attr_set[64] = {};
+    const Device& D = G.devs[st->gpu];
+    auto kern = blind_rotate_kernel<L, BGBIT>;
+    if (!attr_set[st->gpu]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)BR_LDS_BYTES));
+        attr_set[st->gpu] = true;
+    }
+    dim3 grid((njobs + BR_WAVES - 1) / BR_WAVES), block(64 * BR_WAVES);
+    hipLaunchKernelGGL(kern, grid, block, BR_LDS_BYTES, st->s, (const u32*)st->d_abar, njobs,
+                       (const u64*)D.bk_ntt, (const u64*)D.tw_fwd, (const u64*)D.tw_inv, d_tlwe1, G.p.n, G.p.mu,
+                       ABAR_STRIDE);
+    HIP_TRY(hipGetLastError());
+    return IYK_OK;
+}
+
+// mod-switch every job into st->d_abar, then one wavefront per job
 int launch_blind_rotate(iyk_hip_stream* st, const u32* d_arena, const RotJob* d_jobs, int njobs,
                         u32* d_tlwe1)
 {
-    const Device& D = G.devs[st->gpu];
     const iyk_params& p = G.p;
-    dim3 grid((njobs + BR_WAVES - 1) / BR_WAVES), block(64 * BR_WAVES);
-    if (p.l == 3 && p.Bgbit == 6)
-        hipLaunchKernelGGL((blind_rotate_kernel<3, 6>), grid, block, 0, st->s, d_arena, d_jobs, njobs,
-                           D.bk_ntt, D.tw_fwd, D.tw_inv, d_tlwe1, p.n, p.mu);
-    else if (p.l == 2 && p.Bgbit == 10)
-        hipLaunchKernelGGL((blind_rotate_kernel<2, 10>), grid, block, 0, st->s, d_arena, d_jobs, njobs,
-                           D.bk_ntt, D.tw_fwd, D.tw_inv, d_tlwe1, p.n, p.mu);
-    else
-        return fail(IYK_ERR_INVALID, "unsupported (l, Bgbit)");
+    int rc = ensure_rot(st, (size_t)njobs);
+    if (rc) return rc;
+    hipLaunchKernelGGL(modswitch_kernel, dim3(njobs), dim3(256), 0, st->s, d_arena, d_jobs, st->d_abar, p.n,
+                       ABAR_STRIDE);
     HIP_TRY(hipGetLastError());
-    return IYK_OK;
+    if (p.l == 3 && p.Bgbit == 6) return launch_br<3, 6>(st, njobs, d_tlwe1);
+    if (p.l == 2 && p.Bgbit == 10) return launch_br<2, 10>(st, njobs, d_tlwe1);
+    return fail(IYK_ERR_INVALID, "unsupported (l, Bgbit)");
 }
 
 // linear-step coefficients of TFHEpp HomGate (SURVEY.md §8 a-ext)
@@ -183,7 +205,7 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
     if (p.N != (u32)NTT_N || p.k != 1) return fail(IYK_ERR_INVALID, "kernels require N == 1024, k == 1");
     if (!((p.l == 3 && p.Bgbit == 6) || (p.l == 2 && p.Bgbit == 10)))
         return fail(IYK_ERR_INVALID, "supported (l, Bgbit): (3, 6) [128-bit], (2, 10) [80-bit]");
-    if (p.n < 256 || p.n >= (u32)ABAR_WORDS || p.n + 1 > 3 * KS_THREADS)
+    if (p.n < 256 || p.n + 1 > 3 * KS_THREADS)
         return fail(IYK_ERR_INVALID, "n out of supported range [256, 767]");
     if (p.basebit * p.t > 31 || p.basebit == 0 || p.t == 0) return fail(IYK_ERR_INVALID, "bad key-switch params");
     int avail = 0;
@@ -295,6 +317,7 @@ int iyk_hip_stream_destroy(iyk_hip_stream* st)
     if (st->h_stage) (void)hipHostFree(st->h_stage);
     if (st->d_stage) (void)hipFree(st->d_stage);
     if (st->d_rot) (void)hipFree(st->d_rot);
+    if (st->d_abar) (void)hipFree(st->d_abar);
     if (st->d_scratch) (void)hipFree(st->d_scratch);
     (void)hipEventDestroy(st->stage_free);
     if (st->log_on) {

@@ -1,8 +1,9 @@
 // kernels.hpp — HIP kernels of the gate-bootstrapping hot path for gfx950 (MI355X).
 //
 //   bk_ntt_kernel        init: torus-domain BK polynomial -> NTT domain (once per GPU)
-//   blind_rotate_kernel  one wavefront per rotation job: linear step, mod-switch, n CMUX
-//                        steps (blind_rotate_core.hpp), sample-extract -> TLWE lvl1
+//   modswitch_kernel     linear step + mod-switch of every rotation job -> abar[job][n+1]
+//   blind_rotate_kernel  one wavefront per rotation job: n CMUX steps
+//                        (blind_rotate_core.hpp), sample-extract -> TLWE lvl1
 //   keyswitch_kernel     one workgroup per gate: lvl1 -> lvl0 identity key switch
 //   elementwise_kernel   NOT / COPY / CONSTONE / CONSTZERO on arena slots
 //
@@ -34,26 +35,40 @@ struct EwJob {
     int32_t op, in, out;
 };
 
-static constexpr int BR_WAVES = 2;  // rotation jobs per workgroup
-static constexpr int ABAR_WORDS = 1024;
+static constexpr int BR_WAVES = 8;  // rotation jobs (wavefronts) per workgroup; one workgroup per CU
 
-// wave-local LDS hand-off: every lane's ds_writes before, every lane's ds_reads after.
-// All waves of the workgroup run the same trip counts, so a workgroup barrier is legal.
-__device__ __forceinline__ void lds_sync() { __syncthreads(); }
+// Wave-local LDS hand-off.  A wavefront's DS instructions execute in issue order, so data
+// written by one lane is visible to another lane of the SAME wave at the next DS read; the
+// only thing to prevent is compiler reordering.  IYK_WG_SYNC=1 swaps in a workgroup barrier
+// (legal: all waves run identical trip counts) to A/B this assumption on hardware.
+#ifndef IYK_WG_SYNC
+#define IYK_WG_SYNC 0
+#endif
+__device__ __forceinline__ void lds_sync()
+{
+#if IYK_WG_SYNC
+    __syncthreads();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
 
 // ------------------------------------------------------------------------------------------
-// BK: [polys][1024] u32 torus -> [polys][1024] u64 NTT domain (natural k order).
+// BK: [polys][1024] u32 torus -> [polys][1024] u64 NTT domain in the device layout of
+// bk_dev_index (pairs of k1 adjacent so the MAC issues 16-byte loads).
 // Half-wave per polynomial, 2 polynomials per 64-thread workgroup.
 __global__ __launch_bounds__(64) void bk_ntt_kernel(const u32* __restrict__ bk,
                                                     u64* __restrict__ bk_ntt,
                                                     const u64* __restrict__ tw_fwd, size_t polys)
 {
-    __shared__ u64 xb[2 * XB_WORDS];
+    __shared__ u64 xb[2 * 32 * XB_STRIDE];
     const int lane = threadIdx.x, h = lane >> 5, t = lane & 31;
     size_t q = (size_t)blockIdx.x * 2 + h;
     const bool live = q < polys;
     if (!live) q = polys - 1;
-    u64* xbo = xb + h * XB_WORDS;
+    u64* xbo = xb + h * 32 * XB_STRIDE;
     u64 x[32];
 #pragma unroll
     for (int j2 = 0; j2 < 32; ++j2) x[j2] = bk[q * NTT_N + t + 32 * j2];
@@ -61,84 +76,173 @@ __global__ __launch_bounds__(64) void bk_ntt_kernel(const u32* __restrict__ bk,
 #pragma unroll
     for (int p = 0; p < 32; ++p) xbo[brv5(p) * XB_STRIDE + t] = x[p];
     __syncthreads();
-    br_read_row(t, x, xbo);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) x[j] = xbo[t * XB_STRIDE + j];
     ntt_fwd_pass2(x);
     if (live) {
 #pragma unroll
-        for (int p = 0; p < 32; ++p) bk_ntt[q * NTT_N + t + 32 * brv5(p)] = x[p];
+        for (int p = 0; p < 32; ++p) {
+            const int k1 = brv5(p);
+            bk_ntt[q * NTT_N + (size_t)(k1 >> 1) * 64 + t * 2 + (k1 & 1)] = x[p];
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-template <int L, int BGBIT>
-__global__ __launch_bounds__(64 * BR_WAVES) void blind_rotate_kernel(
-    const u32* __restrict__ arena, const RotJob* __restrict__ jobs, int njobs,
-    const u64* __restrict__ bk_ntt, const u64* __restrict__ tw_fwd, const u64* __restrict__ tw_inv,
-    u32* __restrict__ tlwe1_out, u32 n, u32 mu)
+// Linear step + mod-switch for every rotation job (TFHEpp HomGate + BlindRotate prologue):
+// abar[job][i] = round-switch(sa*ca[i] + sb*cb[i]) for i < n, abar[job][n] = bbar.
+// A separate tiny launch so the blind-rotate wave can fetch abar_i with scalar loads.
+__global__ __launch_bounds__(256) void modswitch_kernel(const u32* __restrict__ arena,
+                                                        const RotJob* __restrict__ jobs,
+                                                        u32* __restrict__ abar, u32 n, u32 abar_stride)
 {
-    __shared__ u64 s_xb[BR_WAVES * 2 * XB_WORDS];
-    __shared__ u32 s_acc[BR_WAVES * 2 * NTT_N];
-    __shared__ u32 s_abar[BR_WAVES * ABAR_WORDS];
-
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int h = lane >> 5, t = lane & 31;
-    int job = blockIdx.x * BR_WAVES + wave;
-    const bool live = job < njobs;
-    if (!live) job = njobs - 1;  // keep barrier counts uniform; result discarded
-
-    u32* acc = s_acc + wave * 2 * NTT_N;
-    u32* abar = s_abar + wave * ABAR_WORDS;
-    u64* xb_own = s_xb + (wave * 2 + h) * XB_WORDS;
-    const u64* xb_oth = s_xb + (wave * 2 + (1 - h)) * XB_WORDS;
-
-    // linear step + mod-switch (TFHEpp HomGate + BlindRotate prologue)
-    const RotJob jb = jobs[job];
+    const RotJob jb = jobs[blockIdx.x];
     const size_t n1 = (size_t)n + 1;
     const u32* ca = arena + (size_t)jb.ia * n1;
     const u32* cb = jb.ib >= 0 ? arena + (size_t)jb.ib * n1 : ca;
     const u32 sb = jb.ib >= 0 ? (u32)jb.sb : 0u;
-    for (u32 i = lane; i <= n; i += 64) {
-        u32 v = (u32)jb.sa * ca[i] + sb * cb[i];
-        if (i == n) abar[n] = br_modswitch_b(v + jb.off);
-        else abar[i] = br_modswitch_a(v);
-    }
-    lds_sync();
-    br_init_acc(lane, abar[n], mu, acc);
-    lds_sync();
-
-    u32 td[32];
-    u64 x[32];
-    u64 accum[32];
-    for (u32 i = 0; i < n; ++i) {
-        const u64* bk_step = bk_ntt + (size_t)i * (2 * L) * 2 * NTT_N;
-        br_rotate_diff(h, t, abar[i], acc, td);
-#pragma unroll
-        for (int q = 0; q < 32; ++q) accum[q] = 0;
-#pragma unroll 1
-        for (int lvl = 0; lvl < L; ++lvl) {
-            br_fwd_pass1<L, BGBIT>(t, lvl, td, x, tw_fwd, xb_own);
-            lds_sync();
-            br_read_row(t, x, xb_own);
-            lds_sync();
-            br_fwd_pass2_share(t, x, xb_own);
-            lds_sync();
-            br_mac<L>(h, t, lvl, x, xb_oth, bk_step, accum);
-            lds_sync();
-        }
-        br_inv_pass1(t, accum, tw_inv, xb_own);
-        lds_sync();
-        br_read_row(t, x, xb_own);
-        br_inv_pass2_update(h, t, x, acc);
-        lds_sync();
-    }
-
-    // sample extract at index 0 -> TLWE lvl1 (a'[0] = a[0], a'[j] = -a[N-j], b' = b[0])
-    if (live) {
-        u32* out = tlwe1_out + (size_t)job * (NTT_N + 1);
-        for (int j = lane; j < NTT_N; j += 64) out[j] = (j == 0) ? acc[0] : 0u - acc[NTT_N - j];
-        if (lane == 0) out[NTT_N] = acc[NTT_N];
+    u32* out = abar + (size_t)blockIdx.x * abar_stride;
+    for (u32 i = threadIdx.x; i <= n; i += 256) {
+        const u32 v = (u32)jb.sa * ca[i] + sb * cb[i];
+        out[i] = (i == n) ? br_modswitch_b(v + jb.off) : br_modswitch_a(v);
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// One wavefront per rotation job, BR_WAVES jobs per workgroup, one workgroup per CU
+// (LDS: 8 x (8 KiB accumulator + 8.25 KiB transpose/share) + 16 KiB tables = 146 KiB of 160).
+// Per step i < n: td = (X^abar_i - 1) acc; for each gadget level: forward NTT of the digit
+// polynomial (2 passes), MAC against BK_i; then inverse NTT (2 passes) and acc += result.
+template <int L, int BGBIT>
+__global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_kernel(
+    const u32* __restrict__ abar_all, int njobs, const u64* __restrict__ bk_ntt,
+    const u64* __restrict__ tw_fwd, const u64* __restrict__ tw_inv, u32* __restrict__ tlwe1_out, u32 n,
+    u32 mu, u32 abar_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* s_twf = reinterpret_cast<u64*>(smem);            // [k2][j1]
+    u64* s_twi = s_twf + NTT_N;                           // [j1][k2]
+    u32* s_wave = reinterpret_cast<u32*>(s_twi + NTT_N);  // [BR_WAVES][BR_WAVE_LDS_WORDS]
+
+    for (int e = threadIdx.x; e < NTT_N; e += 64 * BR_WAVES) {
+        const int a = e >> 5, b = e & 31;
+        s_twf[b * 32 + a] = tw_fwd[e];  // tw_fwd[j1 = a][k2 = b] -> [k2][j1]
+        s_twi[b * 32 + a] = tw_inv[e];  // tw_inv[k2 = a][j1 = b] -> [j1][k2]
+    }
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int h0 = lane >> 5, t0 = lane & 31;
+    int job = blockIdx.x * BR_WAVES + wave;
+    const bool live = job < njobs;
+    if (!live) job = njobs - 1;  // idle wave of the last workgroup: recompute a real job, discard
+
+    u32* acc_lds = s_wave + wave * BR_WAVE_LDS_WORDS;   // [2][1024] accumulator, then [2][XB_WORDS32]
+    const u32* abar = abar_all + (size_t)job * abar_stride;
+
+    u32 lo[32];
+    u64 x[32], accum[32];
+    br_init_acc(h0, t0, abar[n], mu, acc_lds + h0 * NTT_N);
+    lds_sync();
+
+    for (u32 i = 0; i < n; ++i) {
+        const u32 ab = abar[i];
+        const u64* bk_step = bk_ntt + (size_t)i * (2 * L) * 2 * NTT_N;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) accum[q] = 0;
+
+        // passes 0..2L-1: forward pass 1 / pass 2 of gadget level pass>>1; 2L: inverse 1'; 2L+1: inverse 2'
+#pragma unroll 1
+        for (int pass = 0; pass < 2 * L + 2; ++pass) {
+            const int lvl = pass >> 1;
+            const bool fwd = pass < 2 * L;
+            const bool first = (pass & 1) == 0;   // pass 1 / pass 1'
+            // Re-derive every lane-dependent address inside the pass from an opaque copy of the lane
+            // id: otherwise LICM hoists ~100 loop-invariant address registers out of the step loop
+            // and the allocator spills them (and the live data) to scratch.
+            int t = t0, h = h0;
+            asm volatile("" : "+v"(t), "+v"(h));
+            u32* acc_h = acc_lds + h * NTT_N;
+            u32* xb = acc_lds + 2 * NTT_N + h * XB_WORDS32;
+            u64* xb64_own = reinterpret_cast<u64*>(xb);
+            const u64* xb64_oth = reinterpret_cast<const u64*>(acc_lds + 2 * NTT_N + (1 - h) * XB_WORDS32);
+            const u64* bko = bk_row_own<L>(bk_step, h, t, lvl);
+            const u64* bkt = bk_row_oth<L>(bk_step, h, t, lvl);
+            u64 b0o[2], b0t[2], b1o[2], b1t[2];
+
+            if (first) {
+                if (fwd) br_fwd1_pre<L, BGBIT>(t, lvl, ab, acc_h, x);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 32; ++q) x[q] = accum[q];
+                }
+            }
+            else if (fwd) {  // BK for the first MAC pair is fetched before the transform to hide its latency
+                b0o[0] = bko[0]; b0o[1] = bko[1]; b0t[0] = bkt[0]; b0t[1] = bkt[1];
+            }
+
+            ntt32_dif<LOG_W32>(x);
+
+            if (first) {
+                // twiddle, then hand the 32 x 32 block over to the transposed lanes in two 32-bit rounds
+                if (fwd) {
+                    br_fwd1_twiddle(t, x, s_twf);
+                    br_xpose_write<false>(t, x, xb, false);
+                    lds_sync();
+                    br_xpose_read_lo(t, lo, xb);
+                    lds_sync();
+                    br_xpose_write<false>(t, x, xb, true);
+                }
+                else {
+                    br_inv1_twiddle(t, x, s_twi);
+                    br_xpose_write<true>(t, x, xb, false);
+                    lds_sync();
+                    br_xpose_read_lo(t, lo, xb);
+                    lds_sync();
+                    br_xpose_write<true>(t, x, xb, true);
+                }
+                lds_sync();
+                br_xpose_read_hi(t, x, lo, xb);
+                lds_sync();
+            }
+            else if (fwd) {
+                // MAC in two k1 chunks of 16 (the share buffer holds one chunk), BK double-buffered per pair
+#pragma unroll
+                for (int chunk = 0; chunk < 2; ++chunk) {
+                    br_share_write(t, chunk, x, xb64_own);
+                    lds_sync();
+#pragma unroll
+                    for (int mm = 0; mm < 8; mm += 2) {
+                        const int m = chunk * 8 + mm;
+                        b1o[0] = bko[(m + 1) * 64]; b1o[1] = bko[(m + 1) * 64 + 1];
+                        b1t[0] = bkt[(m + 1) * 64]; b1t[1] = bkt[(m + 1) * 64 + 1];
+                        br_mac_pair(t, m, x, xb64_oth, b0o, b0t, accum);
+                        if (m + 2 < 16) {
+                            b0o[0] = bko[(m + 2) * 64]; b0o[1] = bko[(m + 2) * 64 + 1];
+                            b0t[0] = bkt[(m + 2) * 64]; b0t[1] = bkt[(m + 2) * 64 + 1];
+                        }
+                        br_mac_pair(t, m + 1, x, xb64_oth, b1o, b1t, accum);
+                    }
+                    lds_sync();
+                }
+            }
+            else {
+                br_inv2_post(t, x, acc_h);
+                lds_sync();
+            }
+        }
+    }
+
+    // sample extract at index 0 -> TLWE lvl1: a'[0] = a[0], a'[j] = -a[N-j], b' = b[0]
+    if (live) {
+        u32* out = tlwe1_out + (size_t)job * (NTT_N + 1);
+        for (int j = lane; j < NTT_N; j += 64) out[j] = (j == 0) ? acc_lds[0] : 0u - acc_lds[NTT_N - j];
+        if (lane == 0) out[NTT_N] = acc_lds[NTT_N];
+    }
+}
+
+static constexpr size_t BR_LDS_BYTES = 2 * NTT_N * sizeof(u64) + (size_t)BR_WAVES * BR_WAVE_LDS_WORDS * sizeof(u32);
 
 // ------------------------------------------------------------------------------------------
 // Identity key switch lvl1 -> lvl0 (TFHEpp IdentityKeySwitch<lvl10param>).
