@@ -35,37 +35,52 @@ def parse_args():
     ap.add_argument("--params", default="128bit", choices=["128bit", "80bit"])
     ap.add_argument("--op", default="NAND")
     ap.add_argument("--cpu-sample", type=int, default=-1,
-                    help="gates timed on the CPU oracle for cpu_baseline (-1: 16 per core, 0: skip)")
+                    help="gates timed on the CPU oracle for cpu_baseline (-1: sized for ~15 s, 0: skip)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="measured HBM bytes per blind_rotate launch from a separate rocprofv3 --pmc pass")
     return ap.parse_args()
 
 
-def cpu_baseline(keys, params, op_code, sample, data_seed):
-    """Oracle (kind 'port') timed on this host's cores on a bounded sample of the same workload."""
+def cpu_baseline(keys, params, op_code, sample, data_seed, budget_s=15.0):
+    """Oracle (kind 'port') timed on this host's cores on a bounded sample of the same workload.
+
+    A first probe chunk (one gate per thread) sizes the sample so the whole leg takes ~budget_s.
+    """
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     from iyokan_amd import client
 
-    cores = os.cpu_count() or 1
-    if sample < 0:
-        sample = 16 * cores
-    rng = np.random.default_rng(data_seed)
-    bits = rng.integers(0, 2, size=2 * sample).astype(np.uint8)
-    arena = np.zeros((3 * sample, params.n + 1), dtype=np.uint32)
-    arena[: 2 * sample] = client.encrypt_bits(keys, bits, seed=data_seed)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64))
     orc = oracle_lib.Oracle(keys)
-    idx = np.arange(sample, dtype=np.int32)
-    t0 = time.perf_counter()
-    orc.gate_batch(np.full(sample, op_code, dtype=np.int32), idx, idx + sample, np.full(sample, -1, dtype=np.int32),
-                   idx + 2 * sample, arena, nthreads=cores)
-    dt = time.perf_counter() - t0
-    dec = client.decrypt_bits(keys, arena[2 * sample:])
-    assert np.array_equal(dec, 1 - (bits[:sample] & bits[sample:])), "oracle decrypt mismatch"
+
+    def run(count, seed):
+        rng = np.random.default_rng(seed)
+        bits = rng.integers(0, 2, size=2 * count).astype(np.uint8)
+        arena = np.zeros((3 * count, params.n + 1), dtype=np.uint32)
+        arena[: 2 * count] = client.encrypt_bits(keys, bits, seed=seed)
+        idx = np.arange(count, dtype=np.int32)
+        t0 = time.perf_counter()
+        orc.gate_batch(np.full(count, op_code, dtype=np.int32), idx, idx + count, np.full(count, -1, dtype=np.int32),
+                       idx + 2 * count, arena, nthreads=threads)
+        dt = time.perf_counter() - t0
+        dec = client.decrypt_bits(keys, arena[2 * count:])
+        assert np.array_equal(dec, 1 - (bits[:count] & bits[count:])), "oracle decrypt mismatch"
+        return dt
+
+    probe_dt = run(threads, data_seed)
+    if sample < 0:
+        sample = int(max(threads, min(64 * threads, threads * (budget_s - probe_dt) / max(probe_dt, 1e-3))))
+        sample -= sample % threads
+        sample = max(sample, threads)
+    dt = run(sample, data_seed + 1)
     orc.close()
-    return {"value": sample / dt, "unit": "gates/s", "cores": cores, "kind": "port",
-            "sample": f"{sample} NAND gates of the same workload (own exact-NTT CPU restatement oracle/tfhe_oracle.c, "
-                      f"OpenMP over gates, {dt:.1f} s); not TFHEpp"}
+    return {"value": sample / dt, "unit": "gates/s", "cores": threads, "kind": "port",
+            "sample": f"{sample} NAND gates of the same workload in {dt:.1f} s (own exact-NTT CPU restatement "
+                      f"oracle/tfhe_oracle.c, OpenMP over gates, {threads} threads of {cores} visible cores); not TFHEpp"}
 
 
 def main():

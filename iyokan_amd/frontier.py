@@ -1,0 +1,233 @@
+"""Level-synchronous, frontier-sharded evaluation of a netlist over one or more GPUs.
+
+MI355X-first replacement for the reference's scheduling layer around the hot path
+(ReadyQueue + 800 one-gate workers + host bounce per gate: /root/reference/src/iyokan.hpp:775-883,
+/root/reference/src/iyokan_cufhe.hpp:666-753; multi-GPU there = keys replicated, streams
+round-robined over GPUs, every ciphertext through host memory — SURVEY.md §2.4):
+
+  * the per-clock DAG is levelised once (netlist.levelise);
+  * every rank holds the SAME device-resident ciphertext arena (slot per node);
+  * level by level, the bootstrapped gates of the level are dealt round-robin to the ranks
+    (MUX first, so 2-rotation gates spread evenly), each rank evaluates its share with ONE
+    iyk_hip_gate_batch, and one all_gather (RCCL over xGMI) of that level's freshly written
+    slots makes every arena identical again — the only data-path collective, at level
+    boundaries (BASELINE.json north_star);
+  * NOT / CONST are not bootstrapped: every rank computes them locally, no exchange;
+  * the clock edge (DFF / RAM cell latch) is a local two-phase copy on every rank.
+
+The arithmetic is behind `backend.gate_batch`; `HipBackend` is the product path, and
+`PlainBitBackend` (bits instead of ciphertexts, CPU tensors) exists so the sharding /
+collective / clocking logic is covered by gloo world_size-2 tests without a GPU.
+"""
+import numpy as np
+
+from .netlist import BINARY
+from .params import OPS
+
+
+class FrontierPlan:
+    """Slot assignment + per-level, per-rank gate descriptor arrays."""
+
+    def __init__(self, nl, world=1):
+        self.nl, self.world = nl, world
+        levels = nl.levelise()
+        n = nl.num_nodes
+        slot = [-1] * n
+        nslots = 0
+        for i, k in enumerate(nl.kinds):                       # sources first
+            if k in ("INPUT", "DFF"):
+                slot[i] = nslots
+                nslots += 1
+        self.levels = []
+        for lv in levels:
+            boot = [i for i in lv if nl.kinds[i] == "MUX"] + [i for i in lv if nl.kinds[i] in BINARY]
+            ew = [i for i in lv if nl.kinds[i] in ("NOT", "CONSTONE", "CONSTZERO")]
+            B = -(-len(boot) // world) if boot else 0
+            base = nslots
+            for j, i in enumerate(boot):                       # gate j -> rank j % world, position j // world
+                slot[i] = base + (j % world) * B + (j // world)
+            nslots += world * B
+            for i in ew:
+                slot[i] = nslots
+                nslots += 1
+            self.levels.append({"boot": boot, "ew": ew, "base": base, "B": B})
+        for i, k in enumerate(nl.kinds):                       # OUTPUT wires alias their driver
+            if k == "OUTPUT":
+                slot[i] = slot[nl.ins[i][0]]
+        self.dffs = [i for i, k in enumerate(nl.kinds) if k == "DFF"]
+        self.shadow_base = nslots
+        nslots += len(self.dffs)
+        self.slot, self.num_slots = slot, nslots
+
+        def desc(nodes):
+            ops = np.array([OPS[nl.kinds[i]] for i in nodes], dtype=np.int32)
+            cols = []
+            for c in range(3):
+                cols.append(np.array([slot[nl.ins[i][c]] if len(nl.ins[i]) > c else -1 for i in nodes], dtype=np.int32))
+            out = np.array([slot[i] for i in nodes], dtype=np.int32)
+            return ops, cols[0], cols[1], cols[2], out
+
+        for L in self.levels:
+            L["ew_desc"] = desc(L["ew"])
+            L["rank_desc"] = [desc(L["boot"][r::world]) for r in range(world)]
+        d_in = np.array([slot[nl.ins[i][0]] for i in self.dffs], dtype=np.int32)
+        d_sh = np.arange(self.shadow_base, self.shadow_base + len(self.dffs), dtype=np.int32)
+        d_out = np.array([slot[i] for i in self.dffs], dtype=np.int32)
+        cp = np.full(len(self.dffs), OPS["COPY"], dtype=np.int32)
+        neg = np.full(len(self.dffs), -1, dtype=np.int32)
+        self.latch_desc = (cp, d_in, neg, neg, d_sh)
+        self.commit_desc = (cp, d_sh, neg, neg, d_out)
+
+    def stats(self):
+        return {"levels": len(self.levels), "slots": self.num_slots,
+                "rotations": self.nl.rotations(),
+                "max_rank_gates_per_level": [L["B"] for L in self.levels]}
+
+
+class PlainBitBackend:
+    """Bits instead of ciphertexts: arena = torch.uint8 [slots, 1] on CPU.  Test support."""
+
+    def __init__(self, num_slots):
+        import torch
+
+        self.arena = torch.zeros((num_slots, 1), dtype=torch.uint8)
+
+    def gate_batch(self, ops, in0, in1, in2, out):
+        a = self.arena.numpy()[:, 0]
+        v0 = a[np.maximum(in0, 0)]
+        v1 = a[np.maximum(in1, 0)]
+        v2 = a[np.maximum(in2, 0)]
+        res = np.zeros(len(ops), dtype=np.uint8)
+        table = {
+            "AND": v0 & v1, "NAND": 1 ^ (v0 & v1), "ANDNOT": v0 & (1 ^ v1), "OR": v0 | v1, "NOR": 1 ^ (v0 | v1),
+            "ORNOT": v0 | (1 ^ v1), "XOR": v0 ^ v1, "XNOR": 1 ^ v0 ^ v1, "MUX": np.where(v2 == 1, v1, v0),
+            "NOT": 1 ^ v0, "CONSTONE": np.ones_like(v0), "CONSTZERO": np.zeros_like(v0), "COPY": v0,
+        }
+        for name, code in OPS.items():
+            m = ops == code
+            if m.any():
+                res[m] = table[name][m]
+        a[out] = res
+
+    def write(self, slot, value):
+        self.arena[slot, 0] = int(value)
+
+    def write_many(self, slots, values):
+        for s_, v in zip(slots, values):
+            self.write(s_, v)
+
+    def read(self, slot):
+        return int(self.arena[slot, 0])
+
+    def read_many(self, slots):
+        return [self.read(s_) for s_ in slots]
+
+    def sync(self):
+        pass
+
+
+class HipBackend:
+    """Ciphertexts in HBM: arena = torch.int32 [slots, n+1] on the rank's GPU, kernels through the
+    C ABI on torch's current stream (so RCCL collectives issued by torch.distributed order with them)."""
+
+    def __init__(self, num_slots, params, device):
+        import torch
+
+        from . import hip
+
+        self.torch, self.hip = torch, hip
+        self.arena = torch.zeros((num_slots, params.n + 1), dtype=torch.int32, device=device)
+        self._tstream = torch.cuda.Stream(device=device)
+        torch.cuda.synchronize(device)
+        self.stream = hip.Stream(0, hip_stream=self._tstream.cuda_stream)
+        self._arena = hip.Arena.from_torch(self.arena)
+        self.torch_stream = self._tstream
+
+    def gate_batch(self, ops, in0, in1, in2, out):
+        if len(ops):
+            self.stream.gate_batch(self._arena, ops, in0, in1, in2, out)
+
+    def write(self, slot, tlwe):
+        t = self.torch.from_numpy(np.ascontiguousarray(tlwe, dtype=np.uint32).view(np.int32))
+        with self.torch.cuda.stream(self._tstream):
+            self.arena[slot].copy_(t)
+        self._tstream.synchronize()
+
+    def write_many(self, slots, tlwe_rows):
+        rows = np.ascontiguousarray(tlwe_rows, dtype=np.uint32).reshape(len(slots), -1).view(np.int32)
+        idx = self.torch.as_tensor(np.asarray(slots, dtype=np.int64), device=self.arena.device)
+        with self.torch.cuda.stream(self._tstream):
+            self.arena[idx] = self.torch.from_numpy(rows).to(self.arena.device)
+        self._tstream.synchronize()
+
+    def read(self, slot):
+        self._tstream.synchronize()
+        return self.arena[slot].cpu().numpy().view(np.uint32)
+
+    def read_many(self, slots):
+        self._tstream.synchronize()
+        idx = self.torch.as_tensor(np.asarray(slots, dtype=np.int64), device=self.arena.device)
+        return self.arena[idx].cpu().numpy().view(np.uint32)
+
+    def sync(self):
+        self._tstream.synchronize()
+
+    def close(self):
+        self.stream.destroy()
+
+
+class FrontierExecutor:
+    def __init__(self, plan, backend, rank=0, world=1, dist=None):
+        assert plan.world == world
+        self.plan, self.be, self.rank, self.world, self.dist = plan, backend, rank, world, dist
+        self.collectives = 0
+
+    # ---- host-visible ports (TaskMem::set/get) -------------------------------------------
+    def set_input(self, port, bit, value):
+        self.be.write(self.plan.slot[self.plan.nl.inputs[(port, bit)]], value)
+
+    def get_output(self, port, bit):
+        return self.be.read(self.plan.slot[self.plan.nl.outputs[(port, bit)]])
+
+    def set_node(self, node, value):
+        self.be.write(self.plan.slot[node], value)
+
+    def get_node(self, node):
+        return self.be.read(self.plan.slot[node])
+
+    # ---- one combinational evaluation -------------------------------------------------------
+    def run(self):
+        be, w = self.be, self.world
+        ctx = be.torch.cuda.stream(be.torch_stream) if hasattr(be, "torch_stream") else _null()
+        with ctx:
+            for L in self.plan.levels:
+                be.gate_batch(*L["ew_desc"])
+                if L["B"] == 0:
+                    continue
+                be.gate_batch(*L["rank_desc"][self.rank])
+                if w > 1:
+                    lo, B = L["base"], L["B"]
+                    whole = be.arena[lo: lo + w * B]
+                    mine = be.arena[lo + self.rank * B: lo + (self.rank + 1) * B].clone()
+                    self.dist.all_gather_into_tensor(whole, mine)
+                    self.collectives += 1
+
+    # ---- clock edge: two-phase latch so DFF -> DFF chains sample the old value ---------------
+    def tick(self):
+        be = self.be
+        ctx = be.torch.cuda.stream(be.torch_stream) if hasattr(be, "torch_stream") else _null()
+        with ctx:
+            if len(self.plan.dffs):
+                be.gate_batch(*self.plan.latch_desc)
+                be.gate_batch(*self.plan.commit_desc)
+
+    def sync(self):
+        self.be.sync()
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

@@ -45,8 +45,17 @@ enum { /* must match iyk_gate_op in include/iyokan_hip.h */
 };
 
 /* ------------------------------------------------------------ field + NTT (own, radix-2) */
-static inline u64 fadd(u64 a, u64 b) { u128 s = (u128)a + b; return (u64)(s >= GP ? s - GP : s); }
-static inline u64 fsub(u64 a, u64 b) { return a >= b ? a - b : a + (GP - b); }
+static inline u64 fadd(u64 a, u64 b)
+{
+    u64 s;
+    int c = __builtin_add_overflow(a, b, &s);
+    return (c | (s >= GP)) ? s - GP : s; /* wrapped: s - P == s + 2^64 - P (mod 2^64) */
+}
+static inline u64 fsub(u64 a, u64 b)
+{
+    u64 d;
+    return __builtin_sub_overflow(a, b, &d) ? d + GP : d;
+}
 /* 128-bit product reduced with 2^64 = 2^32 - 1, 2^96 = -1 (mod P); checked against the
  * plain `% P` form in orc_selfcheck_field() */
 static inline u64 fmul(u64 a, u64 b)

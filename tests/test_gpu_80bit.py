@@ -1,0 +1,44 @@
+"""GPU parity at the 80-bit parameter set (BASELINE config #5 shape: l = 2, Bgbit = 10, n = 500, t = 8)."""
+import os
+
+import numpy as np
+import pytest
+
+from iyokan_amd import client
+from iyokan_amd.params import OPS, PLAIN
+
+pytestmark = pytest.mark.gpu
+
+
+def test_80bit_gates_bit_exact(keys80, oracle80):
+    from iyokan_amd import hip
+
+    hip.initialize(keys80, device_ids=(0,))
+    try:
+        st = hip.Stream(0)
+        p = keys80.params
+        rng = np.random.default_rng(5)
+        bits = rng.integers(0, 2, size=16).astype(np.uint8)
+        kinds = ["AND", "NAND", "ANDNOT", "OR", "NOR", "ORNOT", "XOR", "XNOR", "MUX", "MUX", "NOT"]
+        ops, in0, in1, in2, out, want = [], [], [], [], [], []
+        for g, k in enumerate(kinds):
+            a, b, s = g % 16, (3 * g + 5) % 16, (7 * g + 2) % 16
+            ops.append(OPS[k]); out.append(16 + g); in0.append(a)
+            in1.append(b if k != "NOT" else -1); in2.append(s if k == "MUX" else -1)
+            want.append(PLAIN[k](int(bits[a])) if k == "NOT" else PLAIN[k](int(bits[a]), int(bits[b]), int(bits[s]))
+                        if k == "MUX" else PLAIN[k](int(bits[a]), int(bits[b])))
+        host = np.zeros((16 + len(kinds), p.n + 1), dtype=np.uint32)
+        host[:16] = client.encrypt_bits(keys80, bits, seed=3)
+        arena = hip.Arena(host.shape[0])
+        st.upload(arena, 0, host)
+        st.gate_batch(arena, ops, in0, in1, in2, out)
+        st.sync()
+        got = st.download(arena, 0, host.shape[0])
+        arena.free()
+        st.destroy()
+    finally:
+        hip.cleanup()
+    ref = host.copy()
+    oracle80.gate_batch(ops, in0, in1, in2, out, ref, nthreads=os.cpu_count() or 1)
+    assert np.array_equal(got, ref)
+    assert list(client.decrypt_bits(keys80, got[16:])) == want

@@ -1,0 +1,89 @@
+"""GPU: netlists through the frontier executor (device-resident arena, level-synchronous batches)
+and the C++ host runtime self-test; decrypted results must equal the plaintext simulator."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from iyokan_amd import client
+from iyokan_amd import netlist as N
+from iyokan_amd.frontier import FrontierExecutor, FrontierPlan, HipBackend
+from netlist_util import GOLD, drive_cycle, input_streams, load_packet
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gpu(keys128):
+    from iyokan_amd import hip
+
+    hip.initialize(keys128, device_ids=(0,))
+    yield hip
+    hip.cleanup()
+
+
+def _make(nl, keys, seed=100):
+    import torch
+
+    plan = FrontierPlan(nl, 1)
+    be = HipBackend(plan.num_slots, keys.params, torch.device("cuda", 0))
+    ex = FrontierExecutor(plan, be)
+    zero = client.trivial(keys.params, 0)
+    be.write_many([plan.slot[i] for i in plan.dffs], np.tile(zero, (len(plan.dffs), 1)))   # DFF/RAM reset value
+    state = {"seed": seed}
+
+    def set_enc(port, bit, v):
+        state["seed"] += 1
+        ex.set_input(port, bit, client.encrypt_bits(keys, [v], seed=state["seed"])[0])
+
+    return plan, be, ex, set_enc
+
+
+def test_counter_4bit_on_gpu(gpu, keys128):
+    nl = N.load_iyokanl1_json(os.path.join(GOLD, "counter-4bit-iyokanl1.json"))
+    plan, be, ex, set_enc = _make(nl, keys128)
+    set_enc("reset", 0, 1)
+    ex.run()
+    set_enc("reset", 0, 0)
+    for clk in range(6):
+        ex.tick()
+        ex.run()
+        got = client.decrypt_bits(keys128, np.stack([ex.get_output("io_out", b) for b in range(4)]))
+        assert sum(int(v) << b for b, v in enumerate(got)) == clk
+    be.close()
+
+
+def test_mux_ram_config3_two_clocks(gpu, keys128):
+    """BASELINE config #3: mux-ram-8-16-16, inputs of test08 (fresh encryptions), RAM zero-initialised;
+    clock 0 (18 985 blind rotations in 14 level batches) then a clock edge and clock 1."""
+    nl = N.load_iyokanl1_json(os.path.join(GOLD, "mux-ram-8-16-16.min.json"))
+    streams = input_streams(load_packet(os.path.join(GOLD, "test08.in")))
+    plan, be, ex, set_enc = _make(nl, keys128)
+    sim = N.PlainSimulator(nl)
+    for c in range(2):
+        ex.tick(); sim.tick()
+        drive_cycle(set_enc, nl, streams, c)
+        drive_cycle(sim.set_input, nl, streams, c)
+        ex.run(); sim.evaluate()
+        outs = sorted(nl.outputs)
+        got = client.decrypt_bits(keys128, be.read_many([plan.slot[nl.outputs[k]] for k in outs]))
+        want = [sim.get_output(*k) for k in outs]
+        assert list(got) == want, f"clock {c}"
+    ex.tick(); sim.tick()
+    ram = client.decrypt_bits(keys128, be.read_many([plan.slot[nl.ram[i]] for i in range(4096)]))
+    assert list(ram) == sim.ram_image(4096)
+    be.close()
+
+
+def test_cpp_host_runtime_on_gpu(gpu, keys128):
+    """test0-shaped self-check of engine.hpp + iyokan_hip.hpp (batching HIPWorker, device arena)."""
+    gpu.cleanup()   # the C++ binary initialises the library in its own process
+    try:
+        exe = os.path.join(ROOT, "iyokan_amd", "host", "test0_hip")
+        out = subprocess.run([exe, "--hip"], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "ALL OK" in out.stdout
+    finally:
+        gpu.initialize(keys128, device_ids=(0,))   # module fixture teardown expects an initialised library

@@ -1,0 +1,130 @@
+"""Netlist ingestion + plaintext evaluation against the reference's own request/result fixtures,
+and the frontier executor's sharding logic on a bit backend (single rank and gloo world_size 2)."""
+import os
+
+import numpy as np
+import pytest
+
+from iyokan_amd import netlist as N
+from iyokan_amd.frontier import FrontierExecutor, FrontierPlan, PlainBitBackend
+from netlist_util import GOLD, drive_cycle, input_streams, load_packet, run_plain
+
+
+def test_counter_yosys_matches_test13():
+    nl = N.load_yosys_json(os.path.join(GOLD, "counter-4bit-yosys.json"))
+    want = load_packet(os.path.join(GOLD, "test13.out"))
+    sim = run_plain(nl, {}, want["cycles"], use_reset=True)
+    assert N.bytes_from_bits([sim.get_output("io_out", b) for b in range(4)]) == want["bits"][0]["bytes"]
+
+
+def test_counter_l1_sequence_like_test0():
+    """/root/reference/src/test0.cpp:403-431: 16 clocks count 0..15."""
+    nl = N.load_iyokanl1_json(os.path.join(GOLD, "counter-4bit-iyokanl1.json"))
+    sim = N.PlainSimulator(nl)
+    sim.set_input("reset", 0, 1)
+    sim.evaluate()
+    sim.set_input("reset", 0, 0)
+    for clk in range(16):
+        sim.tick()
+        sim.evaluate()
+        assert sim.get_port("io_out") == clk
+
+
+@pytest.mark.parametrize("loader,name", [(N.load_yosys_json, "addr-4bit-yosys.json"),
+                                         (N.load_iyokanl1_json, "addr-4bit-iyokanl1.json")])
+def test_adder_matches_test04(loader, name):
+    nl = loader(os.path.join(GOLD, name))
+    req, want = load_packet(os.path.join(GOLD, "test04.in")), load_packet(os.path.join(GOLD, "test04.out"))
+    streams = input_streams(req)
+    port_a = "io_inA" if ("io_inA", 0) in nl.inputs else "A"
+    port_b = "io_inB" if ("io_inB", 0) in nl.inputs else "B"
+    streams = {port_a: streams["A"], port_b: streams["B"]}
+    sim = run_plain(nl, streams, want["cycles"], use_reset=False)
+    out_port = next(p for (p, b) in nl.outputs)
+    width = nl.port_width(nl.outputs, out_port)
+    assert N.bytes_from_bits([sim.get_output(out_port, b) for b in range(width)])[0] & 0xF == want["bits"][0]["bytes"][0]
+
+
+def test_mux_ram_8_16_16_matches_test08():
+    """BASELINE config #3 netlist, full 8-clock run of test.rb's `mux-ram-8-16-16` case."""
+    nl = N.load_iyokanl1_json(os.path.join(GOLD, "mux-ram-8-16-16.min.json"))
+    c = nl.counts()
+    assert c["MUX"] == 5872 and c["DFF"] == 4096 and nl.rotations() == 18985
+    assert len(nl.levelise()) == 14
+    req, want = load_packet(os.path.join(GOLD, "test08.in")), load_packet(os.path.join(GOLD, "test08.out"))
+    sim = run_plain(nl, input_streams(req), want["cycles"], use_reset=False)
+    rdata = N.bytes_from_bits([sim.get_output("rdata", b) for b in range(16)])
+    assert rdata == want["bits"][0]["bytes"]
+    assert N.bytes_from_bits(sim.ram_image(4096)) == want["ram"][0]["bytes"]
+
+
+def test_cahp_ruby_statistics():
+    nl = N.load_yosys_json(os.path.join(GOLD, "cahp-ruby-core-yosys.json"))
+    assert nl.rotations() == 4281 and len(nl.levelise()) == 41 and nl.counts()["DFF"] == 483
+
+
+def _frontier_vs_sim(nl, streams, cycles, world, rank, dist):
+    plan = FrontierPlan(nl, world)
+    ex = FrontierExecutor(plan, PlainBitBackend(plan.num_slots), rank, world, dist)
+    sim = N.PlainSimulator(nl)
+    for c in range(cycles):
+        ex.tick(); sim.tick()
+        drive_cycle(ex.set_input, nl, streams, c)
+        drive_cycle(sim.set_input, nl, streams, c)
+        ex.run(); sim.evaluate()
+        for (port, bit) in nl.outputs:
+            assert ex.get_output(port, bit) == sim.get_output(port, bit), (c, port, bit)
+    for i in plan.dffs:
+        assert ex.get_node(i) == int(sim.val[i])
+    return ex
+
+
+def test_frontier_single_rank_matches_simulator():
+    nl = N.load_iyokanl1_json(os.path.join(GOLD, "mux-ram-8-16-16.min.json"))
+    req = load_packet(os.path.join(GOLD, "test08.in"))
+    _frontier_vs_sim(nl, input_streams(req), 3, 1, 0, None)
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        nl = N.load_iyokanl1_json(os.path.join(GOLD, "mux-ram-8-16-16.min.json"))
+        req = load_packet(os.path.join(GOLD, "test08.in"))
+        ex = _frontier_vs_sim(nl, input_streams(req), 2, world, rank, dist)
+        q.put((rank, ex.collectives))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frontier_two_ranks_gloo():
+    """world_size 2 on CPU: every rank evaluates only its share of each level, the per-level
+    all_gather makes both arenas identical, and both match the plaintext simulator."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=10) for _ in range(2))
+    assert got[0][1] == got[1][1] == 2 * 14      # one collective per level per clock
+
+
+def test_plan_shards_are_balanced():
+    nl = N.load_iyokanl1_json(os.path.join(GOLD, "mux-ram-8-16-16.min.json"))
+    plan = FrontierPlan(nl, 8)
+    for L in plan.levels:
+        sizes = [len(d[0]) for d in L["rank_desc"]]
+        assert max(sizes) - min(sizes) <= 1
+        mux = [int((d[0] == 8).sum()) for d in L["rank_desc"]]
+        assert max(mux) - min(mux) <= 1
+    # every gate appears exactly once across ranks
+    seen = sorted(int(o) for L in plan.levels for d in L["rank_desc"] for o in d[4])
+    assert len(seen) == len(set(seen)) == sum(len(L["boot"]) for L in plan.levels)
