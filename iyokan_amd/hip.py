@@ -41,6 +41,13 @@ def lib():
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise IykHipError(f"{LIB_PATH} is missing — build it with __graft_entry__.build(); there is no CPU fallback")
+        # Load order matters: PyTorch ships its own libamdhip64; if our library pulled in the system
+        # HIP runtime first, torch.cuda would later find "No HIP GPUs".  Importing torch first makes
+        # both share one runtime (torch is only plumbing here: device tensors, streams, RCCL).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         L.iyk_hip_last_error.restype = ctypes.c_char_p
         L.iyk_hip_init.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(IykParams), _u32p, _u32p]

@@ -31,7 +31,12 @@ def _make(nl, keys, seed=100):
     be = HipBackend(plan.num_slots, keys.params, torch.device("cuda", 0))
     ex = FrontierExecutor(plan, be)
     zero = client.trivial(keys.params, 0)
-    be.write_many([plan.slot[i] for i in plan.dffs], np.tile(zero, (len(plan.dffs), 1)))   # DFF/RAM reset value
+
+    def init_state():   # DFF / RAM cells = trivial 0 (TaskCUFHEGateDFF ctor, setInitialRAM)
+        be.write_many([plan.slot[i] for i in plan.dffs], np.tile(zero, (len(plan.dffs), 1)))
+
+    init_state()
+    ex.init_state = init_state
     state = {"seed": seed}
 
     def set_enc(port, bit, v):
@@ -64,6 +69,8 @@ def test_mux_ram_config3_two_clocks(gpu, keys128):
     sim = N.PlainSimulator(nl)
     for c in range(2):
         ex.tick(); sim.tick()
+        if c == 0:
+            ex.init_state()   # the reference sets the initial RAM AFTER the first tick (iyokan_plain.cpp:509-511)
         drive_cycle(set_enc, nl, streams, c)
         drive_cycle(sim.set_input, nl, streams, c)
         ex.run(); sim.evaluate()
