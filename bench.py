@@ -41,6 +41,22 @@ def parse_args():
     return ap.parse_args()
 
 
+def traffic_bytes(args, gates):
+    """HBM bytes per blind_rotate launch measured by a separate rocprofv3 --pmc pass (committed under
+    profiles/), or None when no measurement matches this workload."""
+    if args.traffic_bytes is not None:
+        return args.traffic_bytes
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        t = json.load(open(path))
+        w = t["workload"]
+        if w["gates_per_launch"] == gates and w["params"] == args.params and w["op"] == args.op:
+            return t["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(keys, params, op_code, sample, data_seed, budget_s=15.0):
     """Oracle (kind 'port') timed on this host's cores on a bounded sample of the same workload.
 
@@ -206,7 +222,7 @@ def main():
                 "peak": HBM_PEAK_BYTES_PER_S / 1e9,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_BYTES_PER_S,
-                "traffic": args.traffic_bytes,
+                "traffic": traffic_bytes(args, G),
                 "algorithmic_bytes_per_launch": br_bytes_per_gate * G,
                 "avg_launch_ms": br_avg_s * 1e3,
                 "keyswitch_avg_launch_ms": ks_ms / max(nb, 1),
