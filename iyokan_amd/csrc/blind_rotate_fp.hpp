@@ -1,0 +1,105 @@
+// blind_rotate_fp.hpp — per-lane phases of one CMUX step on the FP64 path (fp50.hpp).
+//
+// Identical lane layout, LDS layout and pass structure to blind_rotate_core.hpp (v3); only the
+// field changes: residues mod p = 2^50 - 16383 held as lazily-reduced integers in doubles, exact
+// FMA arithmetic, general twiddles.  BK is stored in the same device layout (bk_dev_index) as
+// balanced doubles, 8 bytes per coefficient — the algorithmic byte count is unchanged.
+// Instruction budget per CMUX step and lane: ~9.5 k VALU vs ~31 k on the integer path.
+#pragma once
+#include "blind_rotate_core.hpp"
+#include "fpntt32.hpp"
+
+namespace iyk {
+namespace fp {
+
+IYK_HD u64 d2u(double d)
+{
+    u64 u;
+    __builtin_memcpy(&u, &d, 8);
+    return u;
+}
+IYK_HD double u2d(u64 u)
+{
+    double d;
+    __builtin_memcpy(&d, &u, 8);
+    return d;
+}
+
+// forward pass 1, pre: signed gadget digit `lvl` of ((X^abar - 1) acc_h)[t + 32 j2], times zeta^j2
+template <int L, int BGBIT>
+IYK_HD void fwd1_pre(int t, int lvl, u32 abar, const u32* acc_h, double (&x)[32], const double* zf)
+{
+    typedef BrConsts<L, BGBIT> C;
+    const u32 sh = 32u - (u32)(lvl + 1) * BGBIT;
+#pragma unroll
+    for (int j2 = 0; j2 < 32; ++j2) {
+        const u32 idx = (((u32)t - abar) + 32u * (u32)j2) & (2 * NTT_N - 1);
+        u32 v = acc_h[idx & (NTT_N - 1)];
+        v = (idx & NTT_N) ? 0u - v : v;
+        const u32 td = v - acc_h[t + 32 * j2];
+        const i32 d = (i32)(((td + C::offset_plus_round()) >> sh) & C::mask) - (i32)C::half_bg;
+        x[j2] = (j2 == 0) ? (double)d : mulmod((double)d, zf[j2]);
+    }
+}
+
+IYK_HD void fwd1_twiddle(int t, double (&x)[32], const double* twf_t)
+{
+#pragma unroll
+    for (int p = 0; p < 32; ++p) x[p] = mulmod(x[p], twf_t[brv5(p) * 32 + t]);
+}
+
+// 32 x 32 transpose of 64-bit values through the u32 [32][33] LDS matrix, (lo, hi) rounds
+template <bool INV>
+IYK_HD void xpose_write(int t, const double (&x)[32], u32* xb, bool hi)
+{
+#pragma unroll
+    for (int p = 0; p < 32; ++p) {
+        const u64 b = d2u(x[p]);
+        xb[xpose_row<INV>(p) * XB_STRIDE + t] = hi ? (u32)(b >> 32) : (u32)b;
+    }
+}
+IYK_HD void xpose_read_hi(int t, double (&x)[32], const u32 (&lo)[32], const u32* xb)
+{
+#pragma unroll
+    for (int j = 0; j < 32; ++j) x[j] = u2d(((u64)xb[t * XB_STRIDE + j] << 32) | lo[j]);
+}
+
+IYK_HD void share_write(int t, int chunk, const double (&x)[32], double* xb64_own)
+{
+#pragma unroll
+    for (int q = 0; q < 16; ++q) xb64_own[q * 32 + t] = chunk ? x[brv5(16 + q)] : x[brv5(q)];
+}
+
+// accum_h[k1] += D_own[k] BK[r_own][h][k] + D_other[k] BK[r_other][h][k] for k1 = 2m, 2m+1
+// (six such terms per k1 over the three gadget levels: |accum| <= 6.6 p < 2^53)
+IYK_HD void mac_pair(int t, int m, const double (&x)[32], const double* xb64_oth, const double (&bo)[2],
+                     const double (&bt)[2], double (&accum)[32])
+{
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int k1 = 2 * m + e;
+        const double xo = xb64_oth[(k1 & 15) * 32 + t];
+        accum[k1] = (accum[k1] + mulmod(x[brv5(k1)], bo[e])) + mulmod(xo, bt[e]);
+    }
+}
+
+IYK_HD void inv1_twiddle(int t, double (&x)[32], const double* twi_t)
+{
+#pragma unroll
+    for (int p = 0; p < 32; ++p) x[p] = mulmod(x[p], twi_t[inv_index(p) * 32 + t]);
+}
+
+// inverse pass 2', post: zeta^(-j2), reduce to the centred representative (= the integer
+// convolution, see fp50.hpp), low 32 bits, acc_h[t + 32 j2] += result
+IYK_HD void inv2_post(int t, const double (&x)[32], u32* acc_h, const double* zi)
+{
+#pragma unroll
+    for (int p = 0; p < 32; ++p) {
+        const int j2 = inv_index(p);
+        const double v = norm(j2 == 0 ? x[p] : mulmod(x[p], zi[j2]));
+        acc_h[t + 32 * j2] += to_torus32(v);
+    }
+}
+
+}  // namespace fp
+}  // namespace iyk

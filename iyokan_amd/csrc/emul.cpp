@@ -8,6 +8,7 @@
 
 #include "../../include/iyokan_hip_params.h"
 #include "blind_rotate_core.hpp"
+#include "blind_rotate_fp.hpp"
 
 using namespace iyk;
 
@@ -136,9 +137,169 @@ void blind_rotate(const iyk_params* p, const u32* lin, const u64* bk_ntt, u32* t
     tlwe1[NTT_N] = acc_lds[NTT_N];
 #undef ALL_LANES
 }
+// ---------------------------------------------------------------------------------------------
+// FP64 path (fp50.hpp): same lane-by-lane emulation of kernels.hpp::blind_rotate_fp_kernel
+struct FpTables {
+    fp::HostTables t;
+    std::vector<double> twf_t, twi_t;
+    FpTables() : twf_t(NTT_N), twi_t(NTT_N)
+    {
+        fp::make_tables(t);
+        for (int e = 0; e < NTT_N; ++e) {
+            const int a = e >> 5, b = e & 31;
+            twf_t[b * 32 + a] = t.tw_fwd[e];
+            twi_t[b * 32 + a] = t.tw_inv[e];
+        }
+    }
+};
+const FpTables& fptables()
+{
+    static FpTables t;
+    return t;
+}
+
+double g_fp_maxabs = 0.0;  // largest |value| / p seen (magnitude discipline check)
+inline void track(const double (&x)[32])
+{
+    for (double v : x) {
+        const double a = (v < 0 ? -v : v) / fp::P;
+        if (a > g_fp_maxabs) g_fp_maxabs = a;
+    }
+}
+
+void forward_1024_fp_dev(const double* in, double* out)
+{
+    const FpTables& T = fptables();
+    static thread_local double xbuf[32 * XB_STRIDE];
+    double x[32];
+    for (int t = 0; t < 32; ++t) {
+        for (int j2 = 0; j2 < 32; ++j2) x[j2] = j2 ? fp::mulmod(in[t + 32 * j2], T.t.c.zf[j2]) : in[t];
+        fp::ntt32_dif(x, T.t.c.w);
+        for (int p = 0; p < 32; ++p) xbuf[brv5(p) * XB_STRIDE + t] = fp::mulmod(x[p], T.t.tw_fwd[t * 32 + brv5(p)]);
+    }
+    for (int t = 0; t < 32; ++t) {
+        for (int j1 = 0; j1 < 32; ++j1) x[j1] = xbuf[t * XB_STRIDE + j1];
+        fp::ntt32_dif(x, T.t.c.w);
+        for (int p = 0; p < 32; ++p) {
+            const int k1 = brv5(p);
+            out[(size_t)(k1 >> 1) * 64 + t * 2 + (k1 & 1)] = fp::norm(x[p]);
+        }
+    }
+}
+
+template <int L, int BGBIT>
+void blind_rotate_fp(const iyk_params* p, const u32* lin, const double* bk_ntt, u32* tlwe1)
+{
+    const FpTables& T = fptables();
+    const fp::NttConsts& C = T.t.c;
+    std::vector<u32> wave_lds(BR_WAVE_LDS_WORDS + 2);
+    u32* acc_lds = wave_lds.data() + ((reinterpret_cast<uintptr_t>(wave_lds.data()) & 7) ? 1 : 0);
+    struct Lane {
+        u32 lo[32];
+        double x[32], accum[32];
+    };
+    std::vector<Lane> R(64);
+    auto acc_h = [&](int lane) { return acc_lds + (lane >> 5) * NTT_N; };
+    auto xb = [&](int lane) { return acc_lds + 2 * NTT_N + (lane >> 5) * XB_WORDS32; };
+    auto xb64_own = [&](int lane) { return reinterpret_cast<double*>(xb(lane)); };
+    auto xb64_oth = [&](int lane) {
+        return reinterpret_cast<const double*>(acc_lds + 2 * NTT_N + (1 - (lane >> 5)) * XB_WORDS32);
+    };
+#define ALL_LANES for (int lane = 0; lane < 64; ++lane)
+    const u32 bbar = br_modswitch_b(lin[p->n]);
+    ALL_LANES br_init_acc(lane >> 5, lane & 31, bbar, p->mu, acc_h(lane));
+    for (u32 i = 0; i < p->n; ++i) {
+        const u32 abar = br_modswitch_a(lin[i]);
+        const double* bk_step = bk_ntt + (size_t)i * (2 * L) * 2 * NTT_N;
+        ALL_LANES for (int q = 0; q < 32; ++q) R[lane].accum[q] = 0.0;
+        for (int pass = 0; pass < 2 * L + 2; ++pass) {
+            const int lvl = pass >> 1;
+            const bool fwd = pass < 2 * L, first = (pass & 1) == 0;
+            ALL_LANES
+            {
+                Lane& r = R[lane];
+                if (first) {
+                    if (fwd) fp::fwd1_pre<L, BGBIT>(lane & 31, lvl, abar, acc_h(lane), r.x, C.zf);
+                    else
+                        for (int q = 0; q < 32; ++q) r.x[q] = fp::norm(r.accum[q]);
+                }
+                track(r.x);
+                fp::ntt32_dif(r.x, C.w);
+                track(r.x);
+            }
+            if (first) {
+                ALL_LANES
+                {
+                    if (fwd) {
+                        fp::fwd1_twiddle(lane & 31, R[lane].x, T.twf_t.data());
+                        fp::xpose_write<false>(lane & 31, R[lane].x, xb(lane), false);
+                    }
+                    else {
+                        fp::inv1_twiddle(lane & 31, R[lane].x, T.twi_t.data());
+                        fp::xpose_write<true>(lane & 31, R[lane].x, xb(lane), false);
+                    }
+                }
+                ALL_LANES br_xpose_read_lo(lane & 31, R[lane].lo, xb(lane));
+                ALL_LANES
+                {
+                    if (fwd) fp::xpose_write<false>(lane & 31, R[lane].x, xb(lane), true);
+                    else fp::xpose_write<true>(lane & 31, R[lane].x, xb(lane), true);
+                }
+                ALL_LANES fp::xpose_read_hi(lane & 31, R[lane].x, R[lane].lo, xb(lane));
+            }
+            else if (fwd) {
+                for (int chunk = 0; chunk < 2; ++chunk) {
+                    ALL_LANES fp::share_write(lane & 31, chunk, R[lane].x, xb64_own(lane));
+                    ALL_LANES
+                    {
+                        const int h = lane >> 5, t = lane & 31;
+                        const double* bko = bk_step + (size_t)((h * L + lvl) * 2 + h) * NTT_N + (size_t)t * 2;
+                        const double* bkt = bk_step + (size_t)(((1 - h) * L + lvl) * 2 + h) * NTT_N + (size_t)t * 2;
+                        for (int m = chunk * 8; m < chunk * 8 + 8; ++m) {
+                            const double bo[2] = {bko[m * 64], bko[m * 64 + 1]};
+                            const double bt[2] = {bkt[m * 64], bkt[m * 64 + 1]};
+                            fp::mac_pair(t, m, R[lane].x, xb64_oth(lane), bo, bt, R[lane].accum);
+                        }
+                        track(R[lane].accum);
+                    }
+                }
+            }
+            else {
+                ALL_LANES fp::inv2_post(lane & 31, R[lane].x, acc_h(lane), C.zi);
+            }
+        }
+    }
+    tlwe1[0] = acc_lds[0];
+    for (u32 j = 1; j < (u32)NTT_N; ++j) tlwe1[j] = 0u - acc_lds[NTT_N - j];
+    tlwe1[NTT_N] = acc_lds[NTT_N];
+#undef ALL_LANES
+}
 }  // namespace
 
 extern "C" {
+
+// FP64 path: NTT of every BK polynomial (signed 32-bit lift), device layout, balanced doubles
+int iyk_emul_bk_ntt_fp(const iyk_params* p, const uint32_t* bk, double* bk_ntt)
+{
+    const size_t polys = (size_t)iyk_bk_words(p) / p->N;
+    std::vector<double> in(NTT_N);
+    for (size_t q = 0; q < polys; ++q) {
+        for (int x = 0; x < NTT_N; ++x) in[x] = (double)(int32_t)bk[q * NTT_N + x];
+        forward_1024_fp_dev(in.data(), bk_ntt + q * NTT_N);
+    }
+    return 0;
+}
+
+int iyk_emul_blind_rotate_fp(const iyk_params* p, const uint32_t* lin, const double* bk_ntt, uint32_t* tlwe1)
+{
+    if (p->N != 1024 || p->k != 1) return -1;
+    if (p->l == 3 && p->Bgbit == 6) blind_rotate_fp<3, 6>(p, lin, bk_ntt, tlwe1);
+    else return -1;  // (2, 10): |sum| would exceed p/2, Goldilocks path only
+    return 0;
+}
+
+double iyk_emul_fp_max_magnitude(void) { return g_fp_maxabs; }
+
 
 // NTT of every polynomial q of the torus-domain BK, stored in the device layout (bk_dev_index)
 int iyk_emul_bk_ntt(const iyk_params* p, const uint32_t* bk, uint64_t* bk_ntt)

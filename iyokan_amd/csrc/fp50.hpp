@@ -1,0 +1,79 @@
+// fp50.hpp — exact arithmetic in Z_p, p = 2^50 - 16383, on the FP64 FMA pipe.
+//
+// Why: the Goldilocks path (goldilocks.hpp) costs ~30 integer VALU instructions per radix-2
+// butterfly on gfx950 and sits at the integer-issue ceiling.  IEEE-754 double
+// FMA gives EXACT modular products of 50-bit residues in 6 instructions (TwoProduct + Barrett
+// quotient by rint), and v_fma_f64 / v_mul_f64 / v_add_f64 / v_rndne_f64 issue at the same rate
+// as 64-bit integer ops (profiles/r01_ubench_valu_occupancy.txt).  Residues are integers held in
+// doubles in a LAZY BALANCED range |x| <= K p with K p < 2^53, so additions need no correction.
+//
+// Exactness of the external product needs p > 2 |sum|.  With the gadget digits |d| <= Bg/2 and
+// the bootstrapping key lifted as SIGNED 32-bit (same result mod 2^32):
+//     |sum| <= (k+1) l N (Bg/2) 2^31 = 6 * 1024 * 32 * 2^31 = 2^48.58  (128-bit set)  <  p / 2.67
+// so the centred representative of the NTT result IS the integer convolution.  (The 80-bit set,
+// Bg/2 = 512, would need p > 2^53: it stays on the Goldilocks path.)
+//
+// Every operation below is a single correctly-rounded IEEE operation (compile with
+// -ffp-contract=off so nothing is fused behind our back); the same code runs on host and device
+// and is unit-tested bit for bit in host_selftest.cpp.
+#pragma once
+#include <stdint.h>
+
+#include "goldilocks.hpp"  // IYK_HD, u32/u64 typedefs
+
+namespace iyk {
+namespace fp {
+
+static constexpr uint64_t P_INT = 1125899906826241ull;  // 2^50 - 16383, prime, = 1 (mod 16384)
+static constexpr double P = 1125899906826241.0;
+static constexpr double U = 1.0 / 1125899906826241.0;   // correctly rounded 1/p
+static constexpr uint64_t GENERATOR = 22;
+
+IYK_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+IYK_HD double rint_(double x) { return __builtin_rint(x); }  // round to nearest even (v_rndne_f64)
+
+// a*b mod p for integers |a| <= 5p, |b| <= p/2 held in doubles; result r = a*b (mod p), an
+// integer with |r| <= (0.5 + 3A/16) p where |a| <= A p (see DESIGN.md §4.1 "FP64 path").
+//   h + l = a*b exactly (TwoProduct); q = rint(h/p); r = (h - q p) + l, each step exact.
+IYK_HD double mulmod(double a, double b)
+{
+    const double h = a * b;
+    const double l = fma_(a, b, -h);
+    const double q = rint_(h * U);
+    const double r = fma_(-q, P, h);
+    return r + l;
+}
+
+// x mod p into [-p/2 - 1, p/2 + 1] for |x| < 2^53
+IYK_HD double norm(double x)
+{
+    const double q = rint_(x * U);
+    return fma_(-q, P, x);
+}
+
+// integer (as double, |x| < 2^53) -> low 32 bits of its two's-complement value
+IYK_HD u32 to_torus32(double x)
+{
+    const double hi = __builtin_floor(x * (1.0 / 4294967296.0));
+    const double lo = fma_(-hi, 4294967296.0, x);  // in [0, 2^32)
+    return (u32)lo;
+}
+
+// ---- host-side exact helpers (table generation) -------------------------------------------
+inline uint64_t ipowmod(uint64_t b, uint64_t e)
+{
+    unsigned __int128 r = 1, x = b % P_INT;
+    while (e) {
+        if (e & 1) r = r * x % P_INT;
+        x = x * x % P_INT;
+        e >>= 1;
+    }
+    return (uint64_t)r;
+}
+inline uint64_t imulmod(uint64_t a, uint64_t b) { return (uint64_t)((unsigned __int128)a * b % P_INT); }
+inline uint64_t iinv(uint64_t a) { return ipowmod(a, P_INT - 2); }
+// canonical [0,p) -> balanced double in (-p/2, p/2]
+inline double balanced(uint64_t a) { return a > P_INT / 2 ? -(double)(P_INT - a) : (double)a; }
+
+}  // namespace fp
+}  // namespace iyk

@@ -9,6 +9,7 @@
 
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -38,9 +39,9 @@ int fail(int code, const std::string& msg)
 
 struct Device {
     int ordinal = -1;
-    u64* bk_ntt = nullptr;
+    u64* bk_ntt = nullptr;   // NTT-domain BK: u64 residues mod 2^64-2^32+1, or doubles mod 2^50-16383 (fp path)
     u32* ksk = nullptr;
-    u64* tw_fwd = nullptr;
+    u64* tw_fwd = nullptr;   // u64 or double tables, same size
     u64* tw_inv = nullptr;
 };
 
@@ -49,6 +50,8 @@ struct Global {
     bool init = false;
     iyk_params p{};
     u32 ksk_stride = 0;
+    bool use_fp = false;          // FP64 path (fp50.hpp) instead of Goldilocks integers
+    fp::NttConsts fpc{};
     std::vector<Device> devs;
     std::atomic<int> nstreams{0};
     uint64_t key_bytes = 0;
@@ -139,6 +142,25 @@ int launch_br(iyk_hip_stream* st, int njobs, u32* d_tlwe1)
     return IYK_OK;
 }
 
+template <int L, int BGBIT>
+int launch_br_fp(iyk_hip_stream* st, int njobs, u32* d_tlwe1)
+{
+    static bool attr_set[64] = {};
+    const Device& D = G.devs[st->gpu];
+    auto kern = blind_rotate_fp_kernel<L, BGBIT>;
+    if (!attr_set[st->gpu]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)BR_LDS_BYTES));
+        attr_set[st->gpu] = true;
+    }
+    dim3 grid((njobs + BR_WAVES - 1) / BR_WAVES), block(64 * BR_WAVES);
+    hipLaunchKernelGGL(kern, grid, block, BR_LDS_BYTES, st->s, (const u32*)st->d_abar, njobs,
+                       (const double*)D.bk_ntt, (const double*)D.tw_fwd, (const double*)D.tw_inv, G.fpc, d_tlwe1,
+                       G.p.n, G.p.mu, ABAR_STRIDE);
+    HIP_TRY(hipGetLastError());
+    return IYK_OK;
+}
+
 // mod-switch every job into st->d_abar, then one wavefront per job
 int launch_blind_rotate(iyk_hip_stream* st, const u32* d_arena, const RotJob* d_jobs, int njobs,
                         u32* d_tlwe1)
@@ -149,6 +171,7 @@ int launch_blind_rotate(iyk_hip_stream* st, const u32* d_arena, const RotJob* d_
     hipLaunchKernelGGL(modswitch_kernel, dim3(njobs), dim3(256), 0, st->s, d_arena, d_jobs, st->d_abar, p.n,
                        ABAR_STRIDE);
     HIP_TRY(hipGetLastError());
+    if (G.use_fp) return launch_br_fp<3, 6>(st, njobs, d_tlwe1);
     if (p.l == 3 && p.Bgbit == 6) return launch_br<3, 6>(st, njobs, d_tlwe1);
     if (p.l == 2 && p.Bgbit == 10) return launch_br<2, 10>(st, njobs, d_tlwe1);
     return fail(IYK_ERR_INVALID, "unsupported (l, Bgbit)");
@@ -188,6 +211,9 @@ int iyk_hip_get_params(iyk_params* out)
     return IYK_OK;
 }
 
+/* 1 = FP64 field path (p = 2^50 - 16383), 0 = Goldilocks integer path */
+int iyk_hip_ntt_path(void) { return G.init ? (G.use_fp ? 1 : 0) : IYK_ERR_STATE; }
+
 int iyk_hip_resident_key_bytes(uint64_t* out)
 {
     if (!G.init) return fail(IYK_ERR_STATE, "not initialised");
@@ -212,8 +238,22 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
     HIP_TRY(hipGetDeviceCount(&avail));
     if (avail < 1) return fail(IYK_ERR_HIP, "no HIP device visible");
 
+    // Path choice: the FP64 field (p = 2^50 - 16383) is exact iff 2 * (k+1) l N (Bg/2) 2^31 < p
+    // (fp50.hpp); true for the 128-bit set, false for the 80-bit one.  IYK_HIP_NTT=goldilocks forces
+    // the 64-bit integer path (kept as the cross-check and for A/B measurements).
+    const double worst = 2.0 * (p.k + 1) * p.l * p.N * (double)(1u << (p.Bgbit - 1)) * 2147483648.0;
+    const char* force = std::getenv("IYK_HIP_NTT");
+    const bool use_fp = (p.l == 3 && p.Bgbit == 6) && worst < fp::P && !(force && std::string(force) == "goldilocks");
     std::vector<u64> twf(NTT_N), twi(NTT_N);
-    ntt_make_tables(twf.data(), twi.data());
+    fp::HostTables fpt;
+    if (use_fp) {
+        fp::make_tables(fpt);
+        std::memcpy(twf.data(), fpt.tw_fwd, sizeof(double) * NTT_N);
+        std::memcpy(twi.data(), fpt.tw_inv, sizeof(double) * NTT_N);
+    }
+    else {
+        ntt_make_tables(twf.data(), twi.data());
+    }
 
     const size_t bk_words = (size_t)iyk_bk_words(&p);
     const size_t polys = bk_words / NTT_N;
@@ -240,13 +280,19 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
         HIP_TRY(hipMemcpy(D.ksk, ksk_pad.data(), ksk_pad.size() * sizeof(u32), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(D.tw_fwd, twf.data(), NTT_N * sizeof(u64), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(D.tw_inv, twi.data(), NTT_N * sizeof(u64), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(bk_ntt_kernel, dim3((unsigned)((polys + 1) / 2)), dim3(64), 0, 0, d_bk, D.bk_ntt,
-                           D.tw_fwd, polys);
+        if (use_fp)
+            hipLaunchKernelGGL(bk_ntt_fp_kernel, dim3((unsigned)((polys + 1) / 2)), dim3(64), 0, 0, d_bk,
+                               (double*)D.bk_ntt, (const double*)D.tw_fwd, fpt.c, polys);
+        else
+            hipLaunchKernelGGL(bk_ntt_kernel, dim3((unsigned)((polys + 1) / 2)), dim3(64), 0, 0, d_bk, D.bk_ntt,
+                               D.tw_fwd, polys);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipFree(d_bk));
     }
     G.p = p;
+    G.use_fp = use_fp;
+    G.fpc = fpt.c;
     G.ksk_stride = stride;
     G.devs = devs;
     G.key_bytes = bk_words * sizeof(u64) + ksk_pad.size() * sizeof(u32) + 2 * NTT_N * sizeof(u64);

@@ -4,6 +4,7 @@
 //   modswitch_kernel     linear step + mod-switch of every rotation job -> abar[job][n+1]
 //   blind_rotate_kernel  one wavefront per rotation job: n CMUX steps
 //                        (blind_rotate_core.hpp), sample-extract -> TLWE lvl1
+//   bk_ntt_fp_kernel / blind_rotate_fp_kernel   the same two on the FP64 path (fp50.hpp), default for the 128-bit set
 //   keyswitch_kernel     one workgroup per gate: lvl1 -> lvl0 identity key switch
 //   elementwise_kernel   NOT / COPY / CONSTONE / CONSTZERO on arena slots
 //
@@ -13,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include "blind_rotate_core.hpp"
+#include "blind_rotate_fp.hpp"
 
 namespace iyk {
 
@@ -243,6 +245,163 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_kernel(
 }
 
 static constexpr size_t BR_LDS_BYTES = 2 * NTT_N * sizeof(u64) + (size_t)BR_WAVES * BR_WAVE_LDS_WORDS * sizeof(u32);
+
+// ------------------------------------------------------------------------------------------
+// FP64 path (fp50.hpp / blind_rotate_fp.hpp): same launch geometry, LDS layout and pass
+// structure as blind_rotate_kernel, arithmetic mod p = 2^50 - 16383 on the FMA pipe.
+__global__ __launch_bounds__(64) void bk_ntt_fp_kernel(const u32* __restrict__ bk, double* __restrict__ bk_ntt,
+                                                       const double* __restrict__ tw_fwd, fp::NttConsts C,
+                                                       size_t polys)
+{
+    __shared__ double xb[2 * 32 * XB_STRIDE];
+    const int lane = threadIdx.x, h = lane >> 5, t = lane & 31;
+    size_t q = (size_t)blockIdx.x * 2 + h;
+    const bool live = q < polys;
+    if (!live) q = polys - 1;
+    double* xbo = xb + h * 32 * XB_STRIDE;
+    double x[32];
+#pragma unroll
+    for (int j2 = 0; j2 < 32; ++j2) {
+        const double v = (double)(int32_t)bk[q * NTT_N + t + 32 * j2];  // signed lift: |sum| < p/2 (fp50.hpp)
+        x[j2] = j2 ? fp::mulmod(v, C.zf[j2]) : v;
+    }
+    fp::ntt32_dif(x, C.w);
+#pragma unroll
+    for (int p = 0; p < 32; ++p) xbo[brv5(p) * XB_STRIDE + t] = fp::mulmod(x[p], tw_fwd[t * 32 + brv5(p)]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 32; ++j) x[j] = xbo[t * XB_STRIDE + j];
+    fp::ntt32_dif(x, C.w);
+    if (live) {
+#pragma unroll
+        for (int p = 0; p < 32; ++p) {
+            const int k1 = brv5(p);
+            bk_ntt[q * NTT_N + (size_t)(k1 >> 1) * 64 + t * 2 + (k1 & 1)] = fp::norm(x[p]);
+        }
+    }
+}
+
+template <int L, int BGBIT>
+__global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
+    const u32* __restrict__ abar_all, int njobs, const double* __restrict__ bk_ntt,
+    const double* __restrict__ tw_fwd, const double* __restrict__ tw_inv, fp::NttConsts C,
+    u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* s_twf = reinterpret_cast<double*>(smem);         // [k2][j1]
+    double* s_twi = s_twf + NTT_N;                           // [j1][k2]
+    u32* s_wave = reinterpret_cast<u32*>(s_twi + NTT_N);     // [BR_WAVES][BR_WAVE_LDS_WORDS]
+
+    for (int e = threadIdx.x; e < NTT_N; e += 64 * BR_WAVES) {
+        const int a = e >> 5, b = e & 31;
+        s_twf[b * 32 + a] = tw_fwd[e];
+        s_twi[b * 32 + a] = tw_inv[e];
+    }
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int h0 = lane >> 5, t0 = lane & 31;
+    int job = blockIdx.x * BR_WAVES + wave;
+    const bool live = job < njobs;
+    if (!live) job = njobs - 1;
+
+    u32* acc_lds = s_wave + wave * BR_WAVE_LDS_WORDS;
+    const u32* abar = abar_all + (size_t)job * abar_stride;
+
+    u32 lo[32];
+    double x[32], accum[32];
+    br_init_acc(h0, t0, abar[n], mu, acc_lds + h0 * NTT_N);
+    lds_sync();
+
+    for (u32 i = 0; i < n; ++i) {
+        const u32 ab = abar[i];
+        const double* bk_step = bk_ntt + (size_t)i * (2 * L) * 2 * NTT_N;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) accum[q] = 0.0;
+
+#pragma unroll 1
+        for (int pass = 0; pass < 2 * L + 2; ++pass) {
+            const int lvl = pass >> 1;
+            const bool fwd = pass < 2 * L;
+            const bool first = (pass & 1) == 0;
+            int t = t0, h = h0;
+            asm volatile("" : "+v"(t), "+v"(h));  // keep address math inside the pass (see blind_rotate_kernel)
+            u32* acc_h = acc_lds + h * NTT_N;
+            u32* xb = acc_lds + 2 * NTT_N + h * XB_WORDS32;
+            double* xb64_own = reinterpret_cast<double*>(xb);
+            const double* xb64_oth = reinterpret_cast<const double*>(acc_lds + 2 * NTT_N + (1 - h) * XB_WORDS32);
+            const double* bko = bk_step + (size_t)((h * L + lvl) * 2 + h) * NTT_N + (size_t)t * 2;
+            const double* bkt = bk_step + (size_t)(((1 - h) * L + lvl) * 2 + h) * NTT_N + (size_t)t * 2;
+            double b0o[2], b0t[2], b1o[2], b1t[2];
+
+            if (first) {
+                if (fwd) fp::fwd1_pre<L, BGBIT>(t, lvl, ab, acc_h, x, C.zf);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 32; ++q) x[q] = fp::norm(accum[q]);
+                }
+            }
+            else if (fwd) {
+                b0o[0] = bko[0]; b0o[1] = bko[1]; b0t[0] = bkt[0]; b0t[1] = bkt[1];
+            }
+
+            fp::ntt32_dif(x, C.w);
+
+            if (first) {
+                if (fwd) {
+                    fp::fwd1_twiddle(t, x, s_twf);
+                    fp::xpose_write<false>(t, x, xb, false);
+                    lds_sync();
+                    br_xpose_read_lo(t, lo, xb);
+                    lds_sync();
+                    fp::xpose_write<false>(t, x, xb, true);
+                }
+                else {
+                    fp::inv1_twiddle(t, x, s_twi);
+                    fp::xpose_write<true>(t, x, xb, false);
+                    lds_sync();
+                    br_xpose_read_lo(t, lo, xb);
+                    lds_sync();
+                    fp::xpose_write<true>(t, x, xb, true);
+                }
+                lds_sync();
+                fp::xpose_read_hi(t, x, lo, xb);
+                lds_sync();
+            }
+            else if (fwd) {
+#pragma unroll
+                for (int chunk = 0; chunk < 2; ++chunk) {
+                    fp::share_write(t, chunk, x, xb64_own);
+                    lds_sync();
+#pragma unroll
+                    for (int mm = 0; mm < 8; mm += 2) {
+                        const int m = chunk * 8 + mm;
+                        b1o[0] = bko[(m + 1) * 64]; b1o[1] = bko[(m + 1) * 64 + 1];
+                        b1t[0] = bkt[(m + 1) * 64]; b1t[1] = bkt[(m + 1) * 64 + 1];
+                        fp::mac_pair(t, m, x, xb64_oth, b0o, b0t, accum);
+                        if (m + 2 < 16) {
+                            b0o[0] = bko[(m + 2) * 64]; b0o[1] = bko[(m + 2) * 64 + 1];
+                            b0t[0] = bkt[(m + 2) * 64]; b0t[1] = bkt[(m + 2) * 64 + 1];
+                        }
+                        fp::mac_pair(t, m + 1, x, xb64_oth, b1o, b1t, accum);
+                    }
+                    lds_sync();
+                }
+            }
+            else {
+                fp::inv2_post(t, x, acc_h, C.zi);
+                lds_sync();
+            }
+        }
+    }
+
+    if (live) {
+        u32* out = tlwe1_out + (size_t)job * (NTT_N + 1);
+        for (int j = lane; j < NTT_N; j += 64) out[j] = (j == 0) ? acc_lds[0] : 0u - acc_lds[NTT_N - j];
+        if (lane == 0) out[NTT_N] = acc_lds[NTT_N];
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // Identity key switch lvl1 -> lvl0 (TFHEpp IdentityKeySwitch<lvl10param>).

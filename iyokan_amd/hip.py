@@ -28,7 +28,7 @@ EXPORTS = [
     "iyk_hip_stream_query", "iyk_hip_stream_sync", "iyk_hip_arena_alloc", "iyk_hip_arena_free",
     "iyk_hip_arena_upload", "iyk_hip_arena_download", "iyk_hip_gate_batch", "iyk_hip_gate_host",
     "iyk_hip_blind_rotate_batch", "iyk_hip_last_batch_timing", "iyk_hip_resident_key_bytes",
-    "iyk_hip_timing_log_begin", "iyk_hip_timing_log_end",
+    "iyk_hip_timing_log_begin", "iyk_hip_timing_log_end", "iyk_hip_ntt_path",
 ]
 
 
@@ -103,6 +103,11 @@ def resident_key_bytes():
     v = ctypes.c_uint64()
     _check(lib().iyk_hip_resident_key_bytes(ctypes.byref(v)), "iyk_hip_resident_key_bytes")
     return v.value
+
+
+def ntt_path():
+    """'fp50' (FP64 FMA field, default for the 128-bit set) or 'goldilocks' (64-bit integer field)."""
+    return "fp50" if _check(lib().iyk_hip_ntt_path(), "iyk_hip_ntt_path") == 1 else "goldilocks"
 
 
 def current_params():

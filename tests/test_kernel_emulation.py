@@ -29,9 +29,31 @@ def test_emulated_blind_rotate_bit_exact(which, request):
         ca = client.encrypt_bits(keys, [a], seed=50 + seed)[0]
         cb = client.encrypt_bits(keys, [b], seed=60 + seed)[0]
         lin = (np.uint32(0) - ca - cb).astype(np.uint32)
-        lin[-1] += np.uint32(p.mu)
+        lin[-1] = np.uint32((int(lin[-1]) + p.mu) & 0xFFFFFFFF)
         ref = orc.bootstrap_lvl1(lin)
         got = np.zeros(p.N + 1, dtype=np.uint32)
         assert em.iyk_emul_blind_rotate(ctypes.byref(p), lin.ctypes.data_as(u32p),
                                         bkntt.ctypes.data_as(u64p), got.ctypes.data_as(u32p)) == 0
         assert np.array_equal(ref, got)
+
+
+def test_emulated_fp64_path_bit_exact(keys128, oracle128):
+    """FP64-field kernel (fp50.hpp, p = 2^50 - 16383): lane-by-lane emulation == oracle, and the
+    lazily-reduced magnitudes stay well inside the exact-integer range of a double (< 8 p = 2^53)."""
+    p = keys128.params
+    em = _emul()
+    em.iyk_emul_fp_max_magnitude.restype = ctypes.c_double
+    dp = ctypes.POINTER(ctypes.c_double)
+    bk = np.zeros(p.bk_words, dtype=np.float64)
+    assert em.iyk_emul_bk_ntt_fp(ctypes.byref(p), keys128.bk.ctypes.data_as(u32p), bk.ctypes.data_as(dp)) == 0
+    assert np.abs(bk).max() <= 1125899906826241 / 2 + 1
+    for seed, (a, b) in enumerate([(1, 1), (0, 1), (1, 0)]):
+        ca = client.encrypt_bits(keys128, [a], seed=70 + seed)[0]
+        cb = client.encrypt_bits(keys128, [b], seed=80 + seed)[0]
+        lin = (np.uint32(0) - ca - cb).astype(np.uint32)
+        lin[-1] = np.uint32((int(lin[-1]) + p.mu) & 0xFFFFFFFF)
+        got = np.zeros(p.N + 1, dtype=np.uint32)
+        assert em.iyk_emul_blind_rotate_fp(ctypes.byref(p), lin.ctypes.data_as(u32p), bk.ctypes.data_as(dp),
+                                           got.ctypes.data_as(u32p)) == 0
+        assert np.array_equal(oracle128.bootstrap_lvl1(lin), got)
+    assert em.iyk_emul_fp_max_magnitude() < 6.0

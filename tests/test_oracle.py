@@ -68,7 +68,7 @@ def test_ntt_path_equals_schoolbook_path(keys128, oracle128):
     ca = client.encrypt_bits(keys128, [1], seed=11)[0]
     cb = client.encrypt_bits(keys128, [0], seed=12)[0]
     lin = (np.uint32(0) - ca - cb).astype(np.uint32)
-    lin[-1] += np.uint32(keys128.params.mu)
+    lin[-1] = np.uint32((int(lin[-1]) + keys128.params.mu) & 0xFFFFFFFF)
     a = oracle128.bootstrap_lvl1(lin, schoolbook=False)
     b = oracle128.bootstrap_lvl1(lin, schoolbook=True)
     assert np.array_equal(a, b)

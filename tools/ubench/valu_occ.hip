@@ -23,6 +23,12 @@ template <int OP> __global__ __launch_bounds__(256) void k(u32* out, u64* cyc, u
             else if (OP == 5) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b[i]));
             else if (OP == 6) asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(a[i]) : "v"(b[i]) : "vcc");
             else if (OP == 7) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(w[i]) : "v"(z[i]));
+            else if (OP == 8) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(w[i]) : "v"(z[i]));
+            else if (OP == 9) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(w[i]) : "v"(z[i]));
+            else if (OP == 10) asm volatile("v_add_f64 %0, %0, %1" : "+v"(w[i]) : "v"(z[i]));
+            else if (OP == 11) asm volatile("v_rndne_f64 %0, %0" : "+v"(w[i]));
+            else if (OP == 12) asm volatile("v_cmp_lt_f64 vcc, %1, %2\n v_cndmask_b32 %0, %0, %3, vcc" : "+v"(a[i]) : "v"(w[i]), "v"(z[i]), "v"(b[i]) : "vcc");
+            else if (OP == 13) asm volatile("v_fma_f64 %0, %0, s[20:21], %1" : "+v"(w[i]) : "v"(z[i]));
         }
     }
     u64 t1 = __builtin_readcyclecounter();
@@ -31,7 +37,7 @@ template <int OP> __global__ __launch_bounds__(256) void k(u32* out, u64* cyc, u
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 template <int OP> void run(const char* name, u32* d, u64* dc) {
-    for (int bpc = 1; bpc <= 8; bpc *= 2) {  // blocks of 4 waves per CU = waves per SIMD
+    for (int bpc = 2; bpc <= 4; bpc *= 2) {  // blocks of 4 waves per CU = waves per SIMD
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipLaunchKernelGGL(k<OP>, dim3(256 * bpc), dim3(256), 0, 0, d, dc, 1u);
         hipEventRecord(e0); hipLaunchKernelGGL(k<OP>, dim3(256 * bpc), dim3(256), 0, 0, d, dc, 2u); hipEventRecord(e1);
@@ -46,5 +52,7 @@ int main() {
     u32* d; u64* dc; hipMalloc(&d, 256 * 8 * 256 * 4); hipMalloc(&dc, 8);
     run<0>("v_add_u32", d, dc); run<1>("v_fma_f32", d, dc); run<7>("v_pk_fma_f32", d, dc); run<2>("v_mad_u64_u32", d, dc); run<3>("v_lshl_add_u64", d, dc);
     run<4>("v_mul_lo_u32", d, dc); run<6>("v_add_co_u32", d, dc);
+    run<8>("v_fma_f64", d, dc); run<9>("v_mul_f64", d, dc); run<10>("v_add_f64", d, dc); run<11>("v_rndne_f64", d, dc);
+    run<12>("v_cmp_lt_f64+cndmask", d, dc); run<13>("v_fma_f64 sgpr", d, dc);
     return 0;
 }
