@@ -177,6 +177,32 @@ int launch_blind_rotate(iyk_hip_stream* st, const u32* d_arena, const RotJob* d_
     return fail(IYK_ERR_INVALID, "unsupported (l, Bgbit)");
 }
 
+// Key switch: init outputs to (0,..,0,b'), then KS_G gates per workgroup, i range sliced so that at
+// least ~2 workgroups per CU exist even for small frontiers (slices combine by integer atomics).
+int launch_keyswitch(iyk_hip_stream* st, u32* d_arena, const KsJob* d_jobs, int njobs)
+{
+    const Device& D = G.devs[st->gpu];
+    const iyk_params& p = G.p;
+    static bool attr_set[64] = {};
+    if (!attr_set[st->gpu]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(keyswitch_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, KS_G * NTT_N * 2));
+        attr_set[st->gpu] = true;
+    }
+    hipLaunchKernelGGL(keyswitch_init_kernel, dim3((unsigned)njobs), dim3(KS_THREADS), 0, st->s,
+                       (const u32*)st->d_rot, d_jobs, d_arena, p.n);
+    HIP_TRY(hipGetLastError());
+    const int groups = (njobs + KS_G - 1) / KS_G;
+    int slices = 1;
+    while (slices < 64 && groups * slices < 512) slices *= 2;
+    const u32 i_per_slice = (u32)NTT_N / (u32)slices;
+    hipLaunchKernelGGL(keyswitch_kernel, dim3((unsigned)groups, (unsigned)slices), dim3(KS_THREADS),
+                       (size_t)KS_G * i_per_slice * 2, st->s, (const u32*)st->d_rot, d_jobs, njobs,
+                       (const u32*)D.ksk, d_arena, p.n, p.t, G.ksk_stride, i_per_slice);
+    HIP_TRY(hipGetLastError());
+    return IYK_OK;
+}
+
 // linear-step coefficients of TFHEpp HomGate (SURVEY.md §8 a-ext)
 bool gate_coeffs(int op, u32 mu, int32_t& sa, int32_t& sb, u32& off)
 {
@@ -231,9 +257,10 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
     if (p.N != (u32)NTT_N || p.k != 1) return fail(IYK_ERR_INVALID, "kernels require N == 1024, k == 1");
     if (!((p.l == 3 && p.Bgbit == 6) || (p.l == 2 && p.Bgbit == 10)))
         return fail(IYK_ERR_INVALID, "supported (l, Bgbit): (3, 6) [128-bit], (2, 10) [80-bit]");
-    if (p.n < 256 || p.n + 1 > 3 * KS_THREADS)
-        return fail(IYK_ERR_INVALID, "n out of supported range [256, 767]");
-    if (p.basebit * p.t > 31 || p.basebit == 0 || p.t == 0) return fail(IYK_ERR_INVALID, "bad key-switch params");
+
+    if (p.basebit != 2 || p.t == 0 || p.t > 8) return fail(IYK_ERR_INVALID, "key-switch kernel requires basebit == 2, t <= 8");
+    if (((p.n + 1 + 3u) & ~3u) > 3 * KS_THREADS || p.n + 1 <= KS_THREADS)
+        return fail(IYK_ERR_INVALID, "key-switch kernel requires 256 < n + 1 <= 768");
     int avail = 0;
     HIP_TRY(hipGetDeviceCount(&avail));
     if (avail < 1) return fail(IYK_ERR_HIP, "no HIP device visible");
@@ -520,10 +547,7 @@ int iyk_hip_gate_batch(iyk_hip_stream* st, uint32_t* d_arena, uint64_t count, co
         if ((rc = launch_blind_rotate(st, d_arena, (const RotJob*)st->d_stage, (int)rot.size(), st->d_rot)))
             return rc;
         HIP_TRY(hipEventRecord(st->ev_br1, st->s));
-        hipLaunchKernelGGL(keyswitch_kernel, dim3((unsigned)ks.size()), dim3(KS_THREADS), 0, st->s, st->d_rot,
-                           (const KsJob*)(st->d_stage + ks_off), D.ksk, d_arena, p.n, p.t, p.basebit,
-                           G.ksk_stride);
-        HIP_TRY(hipGetLastError());
+        if ((rc = launch_keyswitch(st, d_arena, (const KsJob*)(st->d_stage + ks_off), (int)ks.size()))) return rc;
         HIP_TRY(hipEventRecord(st->ev_ks1, st->s));
         st->timing_valid = true;
         st->timing_has_ks = true;

@@ -404,48 +404,87 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Identity key switch lvl1 -> lvl0 (TFHEpp IdentityKeySwitch<lvl10param>).
-// ksk rows are padded to `row_stride` words (multiple of 4).  One workgroup per gate; the
-// digit v of (i, j) is workgroup-uniform, so there is no divergence and every row read is a
-// contiguous, coalesced stream.
+// Identity key switch lvl1 -> lvl0 (TFHEpp IdentityKeySwitch<lvl10param>):
+//   out = (0,..,0,b') - sum_{i<N} sum_{j<t} KSK[i][j][v_ij - 1],  v_ij = digit j of (a'_i + prec)
+// KSK rows are padded to `row_stride` words.  The kernel is a pure stream over KSK (algorithmic
+// 18 MB per gate), so the design goal is to fetch each row once for many gates:
+//   * a workgroup owns KS_G gates and a slice of the i range; for every (i, j) it loads the three
+//     candidate rows ONCE (coalesced, thread = word) and each gate subtracts the row its own digit
+//     selects — the digit is workgroup-uniform per gate, so the select is a scalar branch;
+//   * gridDim.y slices the i range so small frontiers still fill the chip; partial sums are
+//     combined with integer atomicAdd (commutative mod 2^32 -> bit-exact, order-independent) into
+//     outputs that keyswitch_init_kernel pre-set to (0,..,0,b').
 static constexpr int KS_THREADS = 256;
+static constexpr int KS_G = 16;
+
+__global__ __launch_bounds__(KS_THREADS) void keyswitch_init_kernel(const u32* __restrict__ rot,
+                                                                    const KsJob* __restrict__ jobs,
+                                                                    u32* __restrict__ arena, u32 n)
+{
+    const KsJob jb = jobs[blockIdx.x];
+    u32* out = arena + (size_t)jb.out * ((size_t)n + 1);
+    const u32 bval = rot[(size_t)jb.ra * (NTT_N + 1) + NTT_N] +
+                     (jb.rb >= 0 ? rot[(size_t)jb.rb * (NTT_N + 1) + NTT_N] : 0u) + jb.off;
+    for (u32 w = threadIdx.x; w <= n; w += KS_THREADS) out[w] = (w == n) ? bval : 0u;
+}
 
 __global__ __launch_bounds__(KS_THREADS) void keyswitch_kernel(
-    const u32* __restrict__ rot, const KsJob* __restrict__ jobs, const u32* __restrict__ ksk,
-    u32* __restrict__ arena, u32 n, u32 t_digits, u32 basebit, u32 row_stride)
+    const u32* __restrict__ rot, const KsJob* __restrict__ jobs, int njobs, const u32* __restrict__ ksk,
+    u32* __restrict__ arena, u32 n, u32 t_digits, u32 row_stride, u32 i_per_slice)
 {
-    __shared__ u32 s_a[NTT_N];
-    const KsJob jb = jobs[blockIdx.x];
-    const u32* ra = rot + (size_t)jb.ra * (NTT_N + 1);
-    const u32* rb = jb.rb >= 0 ? rot + (size_t)jb.rb * (NTT_N + 1) : nullptr;
-    const u32 prec = 1u << (32 - (1 + basebit * t_digits));
-    for (int j = threadIdx.x; j < NTT_N; j += KS_THREADS) s_a[j] = ra[j] + (rb ? rb[j] : 0u) + prec;
-    __syncthreads();
-
-    const u32 nb = (1u << basebit) - 1;
-    const u32 w0 = threadIdx.x, w1 = threadIdx.x + KS_THREADS, w2 = threadIdx.x + 2 * KS_THREADS;
-    u32 r0 = 0, r1 = 0, r2 = 0;
-    const u32 bval = ra[NTT_N] + (rb ? rb[NTT_N] : 0u) + jb.off;
-    if (w0 == n) r0 = bval;
-    if (w1 == n) r1 = bval;
-    if (w2 == n) r2 = bval;
-    const bool a1 = w1 <= n, a2 = w2 <= n;
-
-    for (u32 i = 0; i < (u32)NTT_N; ++i) {
-        const u32 ai = s_a[i];
-        for (u32 j = 0; j < t_digits; ++j) {
-            const u32 v = (ai >> (32 - (j + 1) * basebit)) & nb;
-            if (v == 0) continue;
-            const u32* row = ksk + (((size_t)i * t_digits + j) * nb + (v - 1)) * row_stride;
-            r0 -= row[w0];
-            if (a1) r1 -= row[w1];
-            if (a2) r2 -= row[w2];
+    extern __shared__ unsigned short s_dig[];  // [KS_G][i_per_slice]: the t 2-bit digits of a'_i, MSB first
+    const int g0 = blockIdx.x * KS_G;
+    const u32 i0 = blockIdx.y * i_per_slice;
+    const u32 dbits = 2u * t_digits;  // basebit == 2 (checked at init)
+    const u32 prec = 1u << (32 - (1 + dbits));
+    for (int g = 0; g < KS_G; ++g) {
+        const bool valid = g0 + g < njobs;
+        const KsJob jb = jobs[valid ? g0 + g : njobs - 1];
+        const u32* ra = rot + (size_t)jb.ra * (NTT_N + 1);
+        const u32* rb = jb.rb >= 0 ? rot + (size_t)jb.rb * (NTT_N + 1) : nullptr;
+        for (u32 ii = threadIdx.x; ii < i_per_slice; ii += KS_THREADS) {
+            const u32 a = ra[i0 + ii] + (rb ? rb[i0 + ii] : 0u) + prec;
+            s_dig[g * i_per_slice + ii] = valid ? (unsigned short)(a >> (32 - dbits)) : (unsigned short)0;
         }
     }
-    u32* out = arena + (size_t)jb.out * ((size_t)n + 1);
-    if (w0 <= n) out[w0] = r0;
-    if (a1) out[w1] = r1;
-    if (a2) out[w2] = r2;
+    __syncthreads();
+
+    const u32 w0 = threadIdx.x, w1 = threadIdx.x + KS_THREADS, w2 = threadIdx.x + 2 * KS_THREADS;
+    const bool a1 = w1 < row_stride, a2 = w2 < row_stride;  // w0 < 256 <= row_stride always
+    u32 acc[KS_G][3];
+#pragma unroll
+    for (int g = 0; g < KS_G; ++g) acc[g][0] = acc[g][1] = acc[g][2] = 0u;
+
+    for (u32 ii = 0; ii < i_per_slice; ++ii) {
+        u32 dg[KS_G];
+#pragma unroll
+        for (int g = 0; g < KS_G; ++g) dg[g] = __builtin_amdgcn_readfirstlane((u32)s_dig[g * i_per_slice + ii]);
+        const u32* rows = ksk + (size_t)(i0 + ii) * t_digits * 3 * row_stride;
+#pragma unroll 1
+        for (u32 j = 0; j < t_digits; ++j, rows += 3 * (size_t)row_stride) {
+            const u32 r10 = rows[w0], r11 = a1 ? rows[w1] : 0u, r12 = a2 ? rows[w2] : 0u;
+            const u32 r20 = rows[row_stride + w0], r21 = a1 ? rows[row_stride + w1] : 0u,
+                      r22 = a2 ? rows[row_stride + w2] : 0u;
+            const u32 r30 = rows[2 * row_stride + w0], r31 = a1 ? rows[2 * row_stride + w1] : 0u,
+                      r32 = a2 ? rows[2 * row_stride + w2] : 0u;
+            const u32 sh = 2u * (t_digits - 1 - j);
+#pragma unroll
+            for (int g = 0; g < KS_G; ++g) {
+                const u32 v = (dg[g] >> sh) & 3u;  // scalar: uniform branch
+                if (v == 1) { acc[g][0] += r10; acc[g][1] += r11; acc[g][2] += r12; }
+                else if (v == 2) { acc[g][0] += r20; acc[g][1] += r21; acc[g][2] += r22; }
+                else if (v == 3) { acc[g][0] += r30; acc[g][1] += r31; acc[g][2] += r32; }
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < KS_G; ++g) {
+        if (g0 + g >= njobs) break;
+        u32* out = arena + (size_t)jobs[g0 + g].out * ((size_t)n + 1);
+        atomicSub(out + w0, acc[g][0]);
+        if (w1 <= n) atomicSub(out + w1, acc[g][1]);
+        if (w2 <= n) atomicSub(out + w2, acc[g][2]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
