@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Clock-latency benchmark of a whole netlist through the frontier-sharded executor
+(BASELINE configs #3 / #4 shape).  Single GPU: `python tools/bench_netlist.py --net mux-ram`;
+N GPUs: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+tools/bench_netlist.py --net mux-ram`.  Inputs are fresh encryptions; every output bit is checked
+against the plaintext simulator after the timed clocks.  Prints one JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+NETS = {
+    "mux-ram": ("mux-ram-8-16-16.min.json", "l1", "test08.in"),      # config #3
+    "cahp-ruby": ("cahp-ruby-core-yosys.json", "yosys", None),        # the core of config #4 (no ROM/RAM wiring)
+    "counter": ("counter-4bit-iyokanl1.json", "l1", None),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--net", default="mux-ram", choices=sorted(NETS))
+    ap.add_argument("--clocks", type=int, default=2)
+    args = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+
+    from iyokan_amd import client, hip
+    from iyokan_amd import netlist as N
+    from iyokan_amd.frontier import FrontierExecutor, FrontierPlan, HipBackend
+    from iyokan_amd.params import params_128bit
+    from netlist_util import GOLD, drive_cycle, input_streams, load_packet
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    fname, kind, pkt = NETS[args.net]
+    nl = (N.load_iyokanl1_json if kind == "l1" else N.load_yosys_json)(os.path.join(GOLD, fname))
+    streams = input_streams(load_packet(os.path.join(GOLD, pkt))) if pkt else {}
+    p = params_128bit()
+    keys = client.keygen(p, seed=1)   # deterministic: every rank derives identical keys (bench.py shows the RCCL broadcast)
+    hip.initialize(keys, device_ids=(local,))
+    plan = FrontierPlan(nl, world)
+    be = HipBackend(plan.num_slots, p, dev)
+    ex = FrontierExecutor(plan, be, rank, world, dist if world > 1 else None)
+    sim = N.PlainSimulator(nl)
+    zero = client.trivial(p, 0)
+    rng = np.random.default_rng(5)
+    seed = [1000]
+
+    def set_enc(port, bit, v):
+        seed[0] += 1
+        ex.set_input(port, bit, client.encrypt_bits(keys, [v], seed=seed[0])[0])   # same seed on every rank
+
+    def drive(c):
+        if streams:
+            drive_cycle(set_enc, nl, streams, c)
+            drive_cycle(sim.set_input, nl, streams, c)
+        else:
+            for (port, bit) in sorted(nl.inputs):
+                v = int(rng.integers(0, 2)) if port != "reset" else int(c == 0)
+                set_enc(port, bit, v)
+                sim.set_input(port, bit, v)
+
+    times = []
+    for c in range(args.clocks + 1):          # clock 0 is the warm-up
+        ex.tick(); sim.tick()
+        if c == 0:
+            be.write_many([plan.slot[i] for i in plan.dffs], np.tile(zero, (len(plan.dffs), 1)))
+        drive(c)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ex.run()
+        ex.sync()
+        if world > 1:
+            dist.barrier()
+        times.append(time.perf_counter() - t0)
+        sim.evaluate()
+    outs = sorted(nl.outputs)
+    got = client.decrypt_bits(keys, be.read_many([plan.slot[nl.outputs[k]] for k in outs]))
+    ok = list(got) == [sim.get_output(*k) for k in outs]
+    if rank == 0:
+        rot = nl.rotations()
+        best = min(times[1:])
+        print(json.dumps({"net": args.net, "n_gpus": world, "levels": len(plan.levels), "rotations_per_clock": rot,
+                          "s_per_clock": best, "rotations_per_s": rot / best, "collectives_per_clock": len(plan.levels) if world > 1 else 0,
+                          "outputs_match_plaintext": ok, "ntt_path": hip.ntt_path()}))
+    be.close()
+    hip.cleanup()
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("output mismatch")
+
+
+if __name__ == "__main__":
+    main()
