@@ -51,10 +51,12 @@ class FrontierPlan:
                 slot[i] = nslots
                 nslots += 1
             self.levels.append({"boot": boot, "ew": ew, "base": base, "B": B})
-        for i, k in enumerate(nl.kinds):                       # OUTPUT wires alias their driver
+        root = nl.roots()
+        for i, k in enumerate(nl.kinds):                       # OUTPUT-kind wires alias their (ultimate) driver
             if k == "OUTPUT":
-                slot[i] = slot[nl.ins[i][0]]
+                slot[i] = slot[root[i]]
         self.dffs = [i for i, k in enumerate(nl.kinds) if k == "DFF"]
+        self.sources = [i for i, k in enumerate(nl.kinds) if k == "INPUT"]
         self.shadow_base = nslots
         nslots += len(self.dffs)
         self.slot, self.num_slots = slot, nslots

@@ -54,6 +54,24 @@ class Netlist:
             if len(self.ins[i]) != want:
                 raise ValueError(f"node {i} ({k}) has {len(self.ins[i])} inputs, needs {want}")
 
+    def roots(self):
+        """root[i] = the non-alias node whose value node i carries (OUTPUT-kind nodes are pure aliases of
+        their single driver; chains arise when blueprints wire one net's output into another's input)."""
+        root = list(range(self.num_nodes))
+
+        def find(i):
+            path = []
+            while self.kinds[i] == "OUTPUT":
+                path.append(i)
+                i = self.ins[i][0]
+            for j in path:
+                root[j] = i
+            return i
+
+        for i in range(self.num_nodes):
+            find(i)
+        return root
+
     def counts(self):
         c = defaultdict(int)
         for k in self.kinds:
@@ -228,6 +246,8 @@ class PlainSimulator:
         self.nl = nl
         self.val = np.zeros(nl.num_nodes, dtype=np.uint8)
         self.levels = nl.levelise()
+        self.root = nl.roots()
+        self.rins = [[self.root[j] for j in ins] for ins in nl.ins]
         self.dffs = [i for i, k in enumerate(nl.kinds) if k == "DFF"]
         for i, v in nl.dff_init.items():
             self.val[i] = v
@@ -241,7 +261,10 @@ class PlainSimulator:
                 self.val[nid] = (value >> b) & 1
 
     def get_output(self, port, bit):
-        return int(self.val[self.nl.outputs[(port, bit)]])
+        return int(self.val[self.root[self.nl.outputs[(port, bit)]]])
+
+    def node_value(self, nid):
+        return int(self.val[self.root[nid]])
 
     def get_port(self, port):
         return sum(self.get_output(p, b) << b for (p, b) in self.nl.outputs if p == port)
@@ -250,7 +273,7 @@ class PlainSimulator:
         nl, v = self.nl, self.val
         for lv in self.levels:
             for i in lv:
-                k, ins = nl.kinds[i], nl.ins[i]
+                k, ins = nl.kinds[i], self.rins[i]
                 if k in _PLAIN:
                     v[i] = _PLAIN[k](int(v[ins[0]]), int(v[ins[1]]))
                 elif k == "MUX":
@@ -261,11 +284,9 @@ class PlainSimulator:
                     v[i] = 1
                 elif k == "CONSTZERO":
                     v[i] = 0
-        for nid in nl.outputs.values():
-            v[nid] = v[nl.ins[nid][0]]
 
     def tick(self):
-        nxt = [self.val[self.nl.ins[i][0]] for i in self.dffs]   # two-phase: sample, then commit
+        nxt = [self.val[self.rins[i][0]] for i in self.dffs]   # two-phase: sample, then commit
         for i, x in zip(self.dffs, nxt):
             self.val[i] = x
 

@@ -84,6 +84,45 @@ def test_mux_ram_config3_two_clocks(gpu, keys128):
     be.close()
 
 
+def test_cahp_system_config4_on_gpu(gpu, keys128):
+    """BASELINE config #4: CAHP-ruby core + MUX ROM + MUX RAM from the reference blueprint, program and
+    RAM image of test09.in encrypted, 7 clocks on the GPU -> @reg_x0 = 42, @finflag = 1 (test09-ruby.out)."""
+    import torch
+
+    from test_system import load_cahp, packet_memories
+
+    sysm = load_cahp()
+    nl = sysm.nl
+    req = load_packet(os.path.join(GOLD, "test09.in"))
+    want = load_packet(os.path.join(GOLD, "test09-ruby.out"))
+    mem = packet_memories(sysm, req)
+    rom_nodes = {nid for cells in sysm.rom.values() for nid in cells.values()}
+    plan = FrontierPlan(nl, 1)
+    be = HipBackend(plan.num_slots, keys128.params, torch.device("cuda", 0))
+    ex = FrontierExecutor(plan, be)
+
+    def write_bits(nodes, bits, seed):
+        be.write_many([plan.slot[i] for i in nodes], client.encrypt_bits(keys128, bits, seed=seed))
+
+    srcs = plan.sources
+    write_bits(srcs, [mem.get(i, 0) for i in srcs], seed=500)           # ROM image + every other input = enc(0)
+    write_bits(plan.dffs, [0] * len(plan.dffs), seed=501)
+    ex.set_input("reset", 0, client.encrypt_bits(keys128, [1], seed=502)[0])
+    ex.run()
+    for c in range(want["cycles"]):
+        ex.tick()
+        if c == 0:
+            ex.set_input("reset", 0, client.encrypt_bits(keys128, [0], seed=503)[0])
+            ram_nodes = [i for i in mem if i not in rom_nodes]
+            write_bits(ram_nodes, [mem[i] for i in ram_nodes], seed=504)  # setInitialRAM after the first tick
+        ex.run()
+    for entry in want["bits"]:
+        keys_ = [(entry["name"], b) for b in range(entry["size"])]
+        got = client.decrypt_bits(keys128, be.read_many([plan.slot[nl.outputs[k]] for k in keys_]))
+        assert N.bytes_from_bits(list(got)) == entry["bytes"], entry["name"]
+    be.close()
+
+
 def test_cpp_host_runtime_on_gpu(gpu, keys128):
     """test0-shaped self-check of engine.hpp + iyokan_hip.hpp (batching HIPWorker, device arena)."""
     gpu.cleanup()   # the C++ binary initialises the library in its own process

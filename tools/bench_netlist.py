@@ -20,6 +20,7 @@ NETS = {
     "mux-ram": ("mux-ram-8-16-16.min.json", "l1", "test08.in"),      # config #3
     "cahp-ruby": ("cahp-ruby-core-yosys.json", "yosys", None),        # the core of config #4 (no ROM/RAM wiring)
     "counter": ("counter-4bit-iyokanl1.json", "l1", None),
+    "cahp-system": ("cahp-ruby-mux.toml", "blueprint", None),        # config #4: core + MUX ROM + MUX RAM
 }
 
 
@@ -45,7 +46,12 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     fname, kind, pkt = NETS[args.net]
-    nl = (N.load_iyokanl1_json if kind == "l1" else N.load_yosys_json)(os.path.join(GOLD, fname))
+    if kind == "blueprint":
+        from iyokan_amd.system import load_blueprint
+
+        nl = load_blueprint(os.path.join(GOLD, fname)).nl
+    else:
+        nl = (N.load_iyokanl1_json if kind == "l1" else N.load_yosys_json)(os.path.join(GOLD, fname))
     streams = input_streams(load_packet(os.path.join(GOLD, pkt))) if pkt else {}
     p = params_128bit()
     keys = client.keygen(p, seed=1)   # deterministic: every rank derives identical keys (bench.py shows the RCCL broadcast)
@@ -77,6 +83,7 @@ def main():
         ex.tick(); sim.tick()
         if c == 0:
             be.write_many([plan.slot[i] for i in plan.dffs], np.tile(zero, (len(plan.dffs), 1)))
+            be.write_many([plan.slot[i] for i in plan.sources], np.tile(zero, (len(plan.sources), 1)))
         drive(c)
         if world > 1:
             dist.barrier()
