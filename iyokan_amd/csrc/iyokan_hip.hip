@@ -51,6 +51,7 @@ struct Global {
     iyk_params p{};
     u32 ksk_stride = 0;
     bool use_fp = false;          // FP64 path (fp50.hpp) instead of Goldilocks integers
+    int lat_threshold = 640;      // rotations per batch at or below which the low-latency kernel is used
     fp::NttConsts fpc{};
     std::vector<Device> devs;
     std::atomic<int> nstreams{0};
@@ -161,6 +162,26 @@ int launch_br_fp(iyk_hip_stream* st, int njobs, u32* d_tlwe1)
     return IYK_OK;
 }
 
+// narrow frontiers: one rotation per workgroup of L waves (kernels.hpp, blind_rotate_fp_lat_kernel)
+template <int L, int BGBIT>
+int launch_br_fp_lat(iyk_hip_stream* st, int njobs, u32* d_tlwe1)
+{
+    static bool attr_set[64] = {};
+    const Device& D = G.devs[st->gpu];
+    auto kern = blind_rotate_fp_lat_kernel<L, BGBIT>;
+    constexpr size_t lds = br_lat_lds_bytes<L>();
+    if (!attr_set[st->gpu]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        attr_set[st->gpu] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3(64 * L), lds, st->s, (const u32*)st->d_abar, njobs,
+                       (const double*)D.bk_ntt, (const double*)D.tw_fwd, (const double*)D.tw_inv, G.fpc, d_tlwe1,
+                       G.p.n, G.p.mu, ABAR_STRIDE);
+    HIP_TRY(hipGetLastError());
+    return IYK_OK;
+}
+
 // mod-switch every job into st->d_abar, then one wavefront per job
 int launch_blind_rotate(iyk_hip_stream* st, const u32* d_arena, const RotJob* d_jobs, int njobs,
                         u32* d_tlwe1)
@@ -171,7 +192,13 @@ int launch_blind_rotate(iyk_hip_stream* st, const u32* d_arena, const RotJob* d_
     hipLaunchKernelGGL(modswitch_kernel, dim3(njobs), dim3(256), 0, st->s, d_arena, d_jobs, st->d_abar, p.n,
                        ABAR_STRIDE);
     HIP_TRY(hipGetLastError());
-    if (G.use_fp) return launch_br_fp<3, 6>(st, njobs, d_tlwe1);
+    if (G.use_fp) {
+        // up to ~3 resident workgroups per CU: below that the 3-wave-per-rotation kernel halves the latency
+        const char* lat = std::getenv("IYK_HIP_LATENCY_KERNEL");  // "0" disables, "1" forces (A/B, tests)
+        const bool force_on = lat && lat[0] == '1', force_off = lat && lat[0] == '0';
+        if (!force_off && (force_on || njobs <= G.lat_threshold)) return launch_br_fp_lat<3, 6>(st, njobs, d_tlwe1);
+        return launch_br_fp<3, 6>(st, njobs, d_tlwe1);
+    }
     if (p.l == 3 && p.Bgbit == 6) return launch_br<3, 6>(st, njobs, d_tlwe1);
     if (p.l == 2 && p.Bgbit == 10) return launch_br<2, 10>(st, njobs, d_tlwe1);
     return fail(IYK_ERR_INVALID, "unsupported (l, Bgbit)");

@@ -404,6 +404,140 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Low-latency variant for narrow frontiers (netlist levels with a few hundred gates): ONE ROTATION
+// PER WORKGROUP of L wavefronts, wave w owns gadget level w (its two forward transforms + MAC run
+// concurrently with the other levels'), the L partial NTT-domain sums are reduced into wave 0
+// through LDS, wave 0 runs the inverse transform and updates the shared accumulator.
+// Per CMUX step the critical path drops from 3 forward levels + inverse to 1 level + reduce +
+// inverse (~2x).  Same phase functions, same arithmetic, bit-identical results.
+static constexpr size_t BR_LAT_WAVE_WORDS = 2 * XB_WORDS32;  // u32 words of transpose/share buffer per wave
+template <int L>
+constexpr size_t br_lat_lds_bytes()
+{
+    return 2 * NTT_N * sizeof(double) + (2 * NTT_N + L * BR_LAT_WAVE_WORDS) * sizeof(u32);
+}
+
+template <int L, int BGBIT>
+__global__ __launch_bounds__(64 * L) void blind_rotate_fp_lat_kernel(
+    const u32* __restrict__ abar_all, int njobs, const double* __restrict__ bk_ntt,
+    const double* __restrict__ tw_fwd, const double* __restrict__ tw_inv, fp::NttConsts C,
+    u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* s_twf = reinterpret_cast<double*>(smem);
+    double* s_twi = s_twf + NTT_N;
+    u32* acc_lds = reinterpret_cast<u32*>(s_twi + NTT_N);   // [2][1024], shared by all waves
+    u32* s_xb = acc_lds + 2 * NTT_N;                         // [L][2][XB_WORDS32]
+
+    for (int e = threadIdx.x; e < NTT_N; e += 64 * L) {
+        const int a = e >> 5, b = e & 31;
+        s_twf[b * 32 + a] = tw_fwd[e];
+        s_twi[b * 32 + a] = tw_inv[e];
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // = gadget level of this wave
+    const int lane = threadIdx.x & 63;
+    const int h0 = lane >> 5, t0 = lane & 31;
+    const int job = blockIdx.x;
+    const u32* abar = abar_all + (size_t)job * abar_stride;
+    if (wave == 0) br_init_acc(h0, t0, abar[n], mu, acc_lds + h0 * NTT_N);
+    __syncthreads();
+
+    u32 lo[32];
+    double x[32], accum[32];
+    u32* wave_xb = s_xb + wave * BR_LAT_WAVE_WORDS;
+
+    for (u32 i = 0; i < n; ++i) {
+        const u32 ab = abar[i];
+        const double* bk_step = bk_ntt + (size_t)i * (2 * L) * 2 * NTT_N;
+        {
+            int t = t0, h = h0;
+            asm volatile("" : "+v"(t), "+v"(h));
+            const u32* acc_h = acc_lds + h * NTT_N;
+            u32* xb = wave_xb + h * XB_WORDS32;
+            double* xb64_own = reinterpret_cast<double*>(xb);
+            const double* xb64_oth = reinterpret_cast<const double*>(wave_xb + (1 - h) * XB_WORDS32);
+            const double* bko = bk_step + (size_t)((h * L + wave) * 2 + h) * NTT_N + (size_t)t * 2;
+            const double* bkt = bk_step + (size_t)(((1 - h) * L + wave) * 2 + h) * NTT_N + (size_t)t * 2;
+            // forward pass 1 of level `wave`
+            fp::fwd1_pre<L, BGBIT>(t, wave, ab, acc_h, x, C.zf);
+            fp::ntt32_dif(x, C.w);
+            fp::fwd1_twiddle(t, x, s_twf);
+            fp::xpose_write<false>(t, x, xb, false);
+            lds_sync();
+            br_xpose_read_lo(t, lo, xb);
+            lds_sync();
+            fp::xpose_write<false>(t, x, xb, true);
+            lds_sync();
+            fp::xpose_read_hi(t, x, lo, xb);
+            lds_sync();
+            // forward pass 2 + MAC
+            fp::ntt32_dif(x, C.w);
+#pragma unroll
+            for (int q = 0; q < 32; ++q) accum[q] = 0.0;
+#pragma unroll
+            for (int chunk = 0; chunk < 2; ++chunk) {
+                fp::share_write(t, chunk, x, xb64_own);
+                lds_sync();
+#pragma unroll
+                for (int mm = 0; mm < 8; ++mm) {
+                    const int m = chunk * 8 + mm;
+                    const double bo[2] = {bko[m * 64], bko[m * 64 + 1]};
+                    const double bt[2] = {bkt[m * 64], bkt[m * 64 + 1]};
+                    fp::mac_pair(t, m, x, xb64_oth, bo, bt, accum);
+                }
+                lds_sync();
+            }
+        }
+        // reduce the L partial sums into wave 0 (two rounds of 16 values through each wave's buffer)
+#pragma unroll
+        for (int chunk = 0; chunk < 2; ++chunk) {
+            double* mine = reinterpret_cast<double*>(wave_xb);
+            if (wave != 0) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) mine[q * 64 + lane] = accum[16 * chunk + q];
+            }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int w = 1; w < L; ++w) {
+                    const double* other = reinterpret_cast<const double*>(s_xb + w * BR_LAT_WAVE_WORDS);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) accum[16 * chunk + q] += other[q * 64 + lane];
+                }
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {
+            int t = t0, h = h0;
+            asm volatile("" : "+v"(t), "+v"(h));
+            u32* acc_h = acc_lds + h * NTT_N;
+            u32* xb = wave_xb + h * XB_WORDS32;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) x[q] = fp::norm(accum[q]);
+            fp::ntt32_dif(x, C.w);
+            fp::inv1_twiddle(t, x, s_twi);
+            fp::xpose_write<true>(t, x, xb, false);
+            lds_sync();
+            br_xpose_read_lo(t, lo, xb);
+            lds_sync();
+            fp::xpose_write<true>(t, x, xb, true);
+            lds_sync();
+            fp::xpose_read_hi(t, x, lo, xb);
+            lds_sync();
+            fp::ntt32_dif(x, C.w);
+            fp::inv2_post(t, x, acc_h, C.zi);
+        }
+        __syncthreads();  // accumulator of step i is complete before anyone derives step i+1's digits
+    }
+
+    if (wave == 0) {
+        u32* out = tlwe1_out + (size_t)job * (NTT_N + 1);
+        for (int j = lane; j < NTT_N; j += 64) out[j] = (j == 0) ? acc_lds[0] : 0u - acc_lds[NTT_N - j];
+        if (lane == 0) out[NTT_N] = acc_lds[NTT_N];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Identity key switch lvl1 -> lvl0 (TFHEpp IdentityKeySwitch<lvl10param>):
 //   out = (0,..,0,b') - sum_{i<N} sum_{j<t} KSK[i][j][v_ij - 1],  v_ij = digit j of (a'_i + prec)
 // KSK rows are padded to `row_stride` words.  The kernel is a pure stream over KSK (algorithmic
