@@ -29,7 +29,7 @@ HBM_PEAK_BYTES_PER_S = 8.0e12  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gates", type=int, default=65536, help="gates per step per GPU")
     ap.add_argument("--params", default="128bit", choices=["128bit", "80bit"])

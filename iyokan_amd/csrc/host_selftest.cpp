@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "ntt32.hpp"
+#include "fpntt32.hpp"
 
 using namespace iyk;
 
@@ -158,10 +159,128 @@ static void test_ntt()
     std::printf("negacyclic product ok\n");
 }
 
+// ---------------------------------------------------------------- FP64 field (fp50.hpp)
+static double g_maxabs = 0;
+static void trk(const double (&x)[32])
+{
+    for (double v : x) {
+        double a = (v < 0 ? -v : v) / fp::P;
+        if (a > g_maxabs) g_maxabs = a;
+    }
+}
+static void fp_forward(const double* in, double* out, const fp::HostTables& T)
+{
+    static double xbuf[32 * 33];
+    double x[32];
+    for (int t = 0; t < 32; ++t) {
+        for (int j2 = 0; j2 < 32; ++j2) x[j2] = j2 ? fp::mulmod(in[t + 32 * j2], T.c.zf[j2]) : in[t];
+        trk(x);
+        fp::ntt32_dif(x, T.c.w);
+        trk(x);
+        for (int p = 0; p < 32; ++p) xbuf[brv5(p) * 33 + t] = fp::mulmod(x[p], T.tw_fwd[t * 32 + brv5(p)]);
+    }
+    for (int t = 0; t < 32; ++t) {
+        for (int j1 = 0; j1 < 32; ++j1) x[j1] = xbuf[t * 33 + j1];
+        trk(x);
+        fp::ntt32_dif(x, T.c.w);
+        trk(x);
+        for (int p = 0; p < 32; ++p) out[t + 32 * brv5(p)] = x[p];
+    }
+}
+static int inv_idx(int p) { return (32 - brv5(p)) & 31; }
+static void fp_inverse(const double* in, double* out, const fp::HostTables& T)
+{
+    static double xbuf[32 * 33];
+    double x[32];
+    for (int t = 0; t < 32; ++t) {  // lane = k2, natural k1 input
+        for (int k1 = 0; k1 < 32; ++k1) x[k1] = fp::norm(in[t + 32 * k1]);
+        fp::ntt32_dif(x, T.c.w);
+        trk(x);
+        for (int p = 0; p < 32; ++p) xbuf[inv_idx(p) * 33 + t] = fp::mulmod(x[p], T.tw_inv[t * 32 + inv_idx(p)]);
+    }
+    for (int t = 0; t < 32; ++t) {  // lane = j1
+        for (int k2 = 0; k2 < 32; ++k2) x[k2] = xbuf[t * 33 + k2];
+        fp::ntt32_dif(x, T.c.w);
+        trk(x);
+        for (int p = 0; p < 32; ++p) {
+            const int j2 = inv_idx(p);
+            out[t + 32 * j2] = fp::norm(j2 ? fp::mulmod(x[p], T.c.zi[j2]) : x[p]);
+        }
+    }
+}
+
+static void test_fp50()
+{
+    // mulmod / norm exactness against 128-bit integer arithmetic, including the largest lazy magnitudes
+    for (int it = 0; it < 2000000; ++it) {
+        const int64_t amax = (int64_t)(5.9 * (double)fp::P_INT);
+        int64_t a = (int64_t)(rnd() % (2 * (uint64_t)amax)) - amax;
+        int64_t b = (int64_t)(rnd() % fp::P_INT) - (int64_t)(fp::P_INT / 2);
+        if (it % 5 == 0) a = (it % 2 ? amax : -amax) - (int64_t)(rnd() % 7);
+        if (it % 7 == 0) b = (it % 2 ? 1 : -1) * (int64_t)(fp::P_INT / 2 - rnd() % 5);
+        const double r = fp::mulmod((double)a, (double)b);
+        CHECK(r == __builtin_rint(r) && (r < 0 ? -r : r) < 2.2 * fp::P);
+        __int128 want = ((__int128)a * b) % (__int128)fp::P_INT;
+        __int128 got = (__int128)(int64_t)r % (__int128)fp::P_INT;
+        if (want < 0) want += fp::P_INT;
+        if (got < 0) got += fp::P_INT;
+        CHECK(want == got);
+        const double nr = fp::norm((double)a);
+        CHECK((nr < 0 ? -nr : nr) <= fp::P / 2 + 1);
+        __int128 wn = (__int128)a % (__int128)fp::P_INT, gn = (__int128)(int64_t)nr % (__int128)fp::P_INT;
+        if (wn < 0) wn += fp::P_INT;
+        if (gn < 0) gn += fp::P_INT;
+        CHECK(wn == gn);
+    }
+    CHECK(fp::to_torus32(-5.0) == (u32)-5 && fp::to_torus32(4294967301.0) == 5u && fp::to_torus32(-4294967301.0) == (u32)-5);
+    std::printf("fp50 field ok\n");
+
+    // worst-case external product: (k+1) l = 6 rows, digits at the extremes, key coefficients +-2^31
+    fp::HostTables T;
+    fp::make_tables(T);
+    for (int rep = 0; rep < 4; ++rep) {
+        std::vector<double> acc(1024, 0.0);
+        std::vector<u32> ref(1024, 0u);
+        for (int row = 0; row < 6; ++row) {
+            std::vector<i32> d(1024);
+            std::vector<u32> b(1024), prod(1024);
+            for (int i = 0; i < 1024; ++i) {
+                if (rep == 0) { d[i] = -32; b[i] = 0x80000000u; }                       // every term +2^36
+                else if (rep == 1) { d[i] = (i & 1) ? 31 : -32; b[i] = (i % 3) ? 0x7FFFFFFFu : 0x80000000u; }
+                else { d[i] = (i32)(rnd() % 64) - 32; b[i] = (u32)rnd(); }
+            }
+            for (int i = 0; i < 1024; ++i) {  // schoolbook reference, mod 2^32
+                u32 a = 0;
+                for (int j = 0; j < 1024; ++j) {
+                    int kidx = i - j;
+                    u32 term = (u32)d[j] * b[(kidx + 1024) % 1024];
+                    a += (kidx >= 0) ? term : (u32)(0u - term);
+                }
+                prod[i] = a;
+            }
+            std::vector<double> fd(1024), fb(1024), Fd(1024), Fb(1024);
+            for (int i = 0; i < 1024; ++i) { fd[i] = (double)d[i]; fb[i] = (double)(int32_t)b[i]; }
+            fp_forward(fd.data(), Fd.data(), T);
+            fp_forward(fb.data(), Fb.data(), T);
+            for (int i = 0; i < 1024; ++i) {
+                acc[i] += fp::mulmod(Fd[i], fp::norm(Fb[i]));  // BK is stored normalised, D is lazy (<= 3.2 p)
+                ref[i] += prod[i];
+            }
+        }
+        for (double v : acc) CHECK((v < 0 ? -v : v) < 7.0 * fp::P);
+        std::vector<double> res(1024);
+        fp_inverse(acc.data(), res.data(), T);
+        for (int i = 0; i < 1024; ++i) CHECK(fp::to_torus32(res[i]) == ref[i]);
+    }
+    CHECK(g_maxabs < 6.0);
+    std::printf("fp50 worst-case external product ok (max |x|/p inside transforms = %.3f)\n", g_maxabs);
+}
+
 int main()
 {
     test_field();
     test_ntt();
+    test_fp50();
     std::printf("ALL OK\n");
     return 0;
 }

@@ -51,7 +51,7 @@ struct Global {
     iyk_params p{};
     u32 ksk_stride = 0;
     bool use_fp = false;          // FP64 path (fp50.hpp) instead of Goldilocks integers
-    int lat_threshold = 640;      // rotations per batch at or below which the low-latency kernel is used
+    int lat_threshold = 1280;      // rotations per batch at or below which the low-latency kernel is used
     fp::NttConsts fpc{};
     std::vector<Device> devs;
     std::atomic<int> nstreams{0};
@@ -144,7 +144,7 @@ int launch_br(iyk_hip_stream* st, int njobs, u32* d_tlwe1)
 }
 
 template <int L, int BGBIT>
-int launch_br_fp(iyk_hip_stream* st, int njobs, u32* d_tlwe1)
+int launch_br_fp(iyk_hip_stream* st, int first, int njobs, u32* d_tlwe1)
 {
     static bool attr_set[64] = {};
     const Device& D = G.devs[st->gpu];
@@ -155,16 +155,16 @@ int launch_br_fp(iyk_hip_stream* st, int njobs, u32* d_tlwe1)
         attr_set[st->gpu] = true;
     }
     dim3 grid((njobs + BR_WAVES - 1) / BR_WAVES), block(64 * BR_WAVES);
-    hipLaunchKernelGGL(kern, grid, block, BR_LDS_BYTES, st->s, (const u32*)st->d_abar, njobs,
-                       (const double*)D.bk_ntt, (const double*)D.tw_fwd, (const double*)D.tw_inv, G.fpc, d_tlwe1,
-                       G.p.n, G.p.mu, ABAR_STRIDE);
+    hipLaunchKernelGGL(kern, grid, block, BR_LDS_BYTES, st->s, (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE,
+                       njobs, (const double*)D.bk_ntt, (const double*)D.tw_fwd, (const double*)D.tw_inv, G.fpc,
+                       d_tlwe1 + (size_t)first * (NTT_N + 1), G.p.n, G.p.mu, ABAR_STRIDE);
     HIP_TRY(hipGetLastError());
     return IYK_OK;
 }
 
 // narrow frontiers: one rotation per workgroup of L waves (kernels.hpp, blind_rotate_fp_lat_kernel)
 template <int L, int BGBIT>
-int launch_br_fp_lat(iyk_hip_stream* st, int njobs, u32* d_tlwe1)
+int launch_br_fp_lat(iyk_hip_stream* st, int first, int njobs, u32* d_tlwe1)
 {
     static bool attr_set[64] = {};
     const Device& D = G.devs[st->gpu];
@@ -175,8 +175,9 @@ int launch_br_fp_lat(iyk_hip_stream* st, int njobs, u32* d_tlwe1)
                                     (int)lds));
         attr_set[st->gpu] = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3(64 * L), lds, st->s, (const u32*)st->d_abar, njobs,
-                       (const double*)D.bk_ntt, (const double*)D.tw_fwd, (const double*)D.tw_inv, G.fpc, d_tlwe1,
+    hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3(64 * L), lds, st->s,
+                       (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE, njobs, (const double*)D.bk_ntt,
+                       (const double*)D.tw_fwd, (const double*)D.tw_inv, G.fpc, d_tlwe1 + (size_t)first * (NTT_N + 1),
                        G.p.n, G.p.mu, ABAR_STRIDE);
     HIP_TRY(hipGetLastError());
     return IYK_OK;
@@ -193,11 +194,19 @@ int launch_blind_rotate(iyk_hip_stream* st, const u32* d_arena, const RotJob* d_
                        ABAR_STRIDE);
     HIP_TRY(hipGetLastError());
     if (G.use_fp) {
-        // up to ~3 resident workgroups per CU: below that the 3-wave-per-rotation kernel halves the latency
+        // Measured (profiles/r01_sweep_kernels.txt): the wave-per-rotation kernel runs 2048 rotations per
+        // 28 ms round; the 3-wave-per-rotation kernel takes 7 ms for <= 256 and ~21 ms per 1024.  So: full
+        // 2048-rounds on the former, a remainder of up to lat_threshold rotations on the latter.
         const char* lat = std::getenv("IYK_HIP_LATENCY_KERNEL");  // "0" disables, "1" forces (A/B, tests)
         const bool force_on = lat && lat[0] == '1', force_off = lat && lat[0] == '0';
-        if (!force_off && (force_on || njobs <= G.lat_threshold)) return launch_br_fp_lat<3, 6>(st, njobs, d_tlwe1);
-        return launch_br_fp<3, 6>(st, njobs, d_tlwe1);
+        if (force_on) return launch_br_fp_lat<3, 6>(st, 0, njobs, d_tlwe1);
+        if (force_off) return launch_br_fp<3, 6>(st, 0, njobs, d_tlwe1);
+        const int round = 2048;
+        const int rem = njobs % round, full = njobs - rem;
+        if (rem > G.lat_threshold) return launch_br_fp<3, 6>(st, 0, njobs, d_tlwe1);
+        if (full && (rc = launch_br_fp<3, 6>(st, 0, full, d_tlwe1))) return rc;
+        if (rem) return launch_br_fp_lat<3, 6>(st, full, rem, d_tlwe1);
+        return IYK_OK;
     }
     if (p.l == 3 && p.Bgbit == 6) return launch_br<3, 6>(st, njobs, d_tlwe1);
     if (p.l == 2 && p.Bgbit == 10) return launch_br<2, 10>(st, njobs, d_tlwe1);
