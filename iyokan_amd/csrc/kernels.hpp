@@ -41,20 +41,14 @@ static constexpr int BR_WAVES = 8;  // rotation jobs (wavefronts) per workgroup;
 
 // Wave-local LDS hand-off.  A wavefront's DS instructions execute in issue order, so data
 // written by one lane is visible to another lane of the SAME wave at the next DS read; the
-// only thing to prevent is compiler reordering.  IYK_WG_SYNC=1 swaps in a workgroup barrier
-// (legal: all waves run identical trip counts) to A/B this assumption on hardware.
-#ifndef IYK_WG_SYNC
-#define IYK_WG_SYNC 0
-#endif
+// only thing to prevent is compiler reordering across the hand-off.  (v1 used __syncthreads()
+// at the same points and produced identical bits; cross-WAVE hand-offs, which only the
+// low-latency kernel has, use real __syncthreads().)
 __device__ __forceinline__ void lds_sync()
 {
-#if IYK_WG_SYNC
-    __syncthreads();
-#else
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#endif
 }
 
 // ------------------------------------------------------------------------------------------

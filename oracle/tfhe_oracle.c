@@ -48,13 +48,14 @@ enum { /* must match iyk_gate_op in include/iyokan_hip.h */
 static inline u64 fadd(u64 a, u64 b)
 {
     u64 s;
-    int c = __builtin_add_overflow(a, b, &s);
-    return (c | (s >= GP)) ? s - GP : s; /* wrapped: s - P == s + 2^64 - P (mod 2^64) */
+    u64 c = __builtin_add_overflow(a, b, &s);
+    return s - ((0 - (c | (u64)(s >= GP))) & GP); /* wrapped: s - P == s + 2^64 - P (mod 2^64) */
 }
 static inline u64 fsub(u64 a, u64 b)
 {
     u64 d;
-    return __builtin_sub_overflow(a, b, &d) ? d + GP : d;
+    u64 bw = __builtin_sub_overflow(a, b, &d);
+    return d + ((0 - bw) & GP);
 }
 /* 128-bit product reduced with 2^64 = 2^32 - 1, 2^96 = -1 (mod P); checked against the
  * plain `% P` form in orc_selfcheck_field() */
@@ -64,9 +65,13 @@ static inline u64 fmul(u64 a, u64 b)
     u64 lo = (u64)pr, hi = (u64)(pr >> 64);
     u64 hh = hi >> 32, hl = hi & 0xFFFFFFFFull;
     u64 t0, r;
-    if (__builtin_sub_overflow(lo, hh, &t0)) t0 -= 0xFFFFFFFFull; /* lo - hh (mod P) */
-    if (__builtin_add_overflow(t0, hl * 0xFFFFFFFFull, &r)) r += 0xFFFFFFFFull;
-    return r >= GP ? r - GP : r;
+    /* branch-free: borrows / carries are data-dependent coin flips, a branch would mispredict */
+    u64 bw = __builtin_sub_overflow(lo, hh, &t0);
+    t0 -= (0 - bw) & 0xFFFFFFFFull;                 /* lo - hh (mod P) */
+    u64 cy = __builtin_add_overflow(t0, hl * 0xFFFFFFFFull, &r);
+    r += (0 - cy) & 0xFFFFFFFFull;
+    r -= (0 - (u64)(r >= GP)) & GP;
+    return r;
 }
 static inline u64 fmul_slow(u64 a, u64 b) { return (u64)(((u128)a * b) % GP); }
 static u64 fpow(u64 b, u64 e)

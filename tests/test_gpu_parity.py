@@ -211,3 +211,52 @@ def test_full_size_flat_nand_property(gpu128, keys128, oracle128):
     oracle128.gate_batch([OPS["NAND"]] * 64, ia[sample], ib[sample], [-1] * 64,
                          list(range(nin, nin + 64)), ref, nthreads=os.cpu_count() or 1)
     assert np.array_equal(got[sample], ref[nin:])
+
+
+def test_both_rotation_kernels_agree(gpu128, keys128, oracle128):
+    """The wave-per-rotation kernel and the 3-wave low-latency kernel (IYK_HIP_LATENCY_KERNEL=0/1 forces
+    one or the other; default picks by batch size) must produce identical ciphertexts, equal to the oracle."""
+    hip, st = gpu128
+    p = keys128.params
+    rng = np.random.default_rng(41)
+    nin, ng = 48, 70
+    bits = rng.integers(0, 2, size=nin).astype(np.uint8)
+    ops = rng.choice([OPS["NAND"], OPS["XNOR"], OPS["MUX"], OPS["ORNOT"]], size=ng).astype(np.int32)
+    in0, in1, in2 = (rng.integers(0, nin, size=ng).astype(np.int32) for _ in range(3))
+    in2 = np.where(ops == OPS["MUX"], in2, -1).astype(np.int32)
+    out = np.arange(nin, nin + ng, dtype=np.int32)
+    host = np.zeros((nin + ng, p.n + 1), dtype=np.uint32)
+    host[:nin] = client.encrypt_bits(keys128, bits, seed=77)
+    results = {}
+    old = os.environ.get("IYK_HIP_LATENCY_KERNEL")
+    try:
+        for mode in ("0", "1"):
+            os.environ["IYK_HIP_LATENCY_KERNEL"] = mode
+            results[mode] = _run(hip, st, host, ops, in0, in1, in2, out)
+    finally:
+        if old is None:
+            os.environ.pop("IYK_HIP_LATENCY_KERNEL", None)
+        else:
+            os.environ["IYK_HIP_LATENCY_KERNEL"] = old
+    assert np.array_equal(results["0"], results["1"])
+    ref = host.copy()
+    oracle128.gate_batch(ops, in0, in1, in2, out, ref, nthreads=os.cpu_count() or 1)
+    assert np.array_equal(results["0"], ref)
+
+
+def test_mid_size_batch_uses_both_kernels(gpu128, keys128):
+    """2048 + 300 rotations: full round on the wave-per-rotation kernel, remainder on the 3-wave kernel;
+    every output must decrypt correctly (size-independent property) and inputs stay untouched."""
+    hip, st = gpu128
+    rng = np.random.default_rng(43)
+    nin, ng = 512, 2348
+    bits = rng.integers(0, 2, size=nin).astype(np.uint8)
+    ia = rng.integers(0, nin, size=ng).astype(np.int32)
+    ib = rng.integers(0, nin, size=ng).astype(np.int32)
+    enc = client.encrypt_bits(keys128, bits, seed=78)
+    host = np.zeros((nin + ng, keys128.params.n + 1), dtype=np.uint32)
+    host[:nin] = enc
+    got = _run(hip, st, host, np.full(ng, OPS["XOR"], dtype=np.int32), ia, ib, np.full(ng, -1, dtype=np.int32),
+               np.arange(nin, nin + ng, dtype=np.int32))
+    assert np.array_equal(got[:nin], enc)
+    assert np.array_equal(client.decrypt_bits(keys128, got[nin:]), bits[ia] ^ bits[ib])
