@@ -25,20 +25,46 @@ IYK_HD double u2d(u64 u)
     return d;
 }
 
-// forward pass 1, pre: signed gadget digit `lvl` of ((X^abar - 1) acc_h)[t + 32 j2], times zeta^j2
-template <int L, int BGBIT>
-IYK_HD void fwd1_pre(int t, int lvl, u32 abar, const u32* acc_h, double (&x)[32], const double* zf)
+// Gadget decomposition policy.  SPLIT = 1: the L digits of Bgbit bits are used as they are
+// (128-bit set: L = 3, Bgbit = 6, |d| <= 32).  SPLIT = 2: every digit d in [-Bg/2, Bg/2) is split
+// exactly as d = 2^HB * hi + lo with lo in [-2^(HB-1), 2^(HB-1)), |hi| <= 2^(HB-1), HB = Bgbit/2,
+// and paired with the keys 2^HB * BK_j (mod 2^32) and BK_j: LV = 2L "virtual levels" with 5-bit
+// digits, so that |sum| <= (k+1) LV N 2^(HB-1) 2^31 stays below p/2 (80-bit set: L = 2, Bgbit = 10
+// -> LV = 4, |sum| <= 2^48).  Virtual level v = 2*lvl + part, part 0 = hi, part 1 = lo.
+template <int L_, int BGBIT_, int SPLIT_>
+struct Decomp {
+    static constexpr int L = L_, BGBIT = BGBIT_, SPLIT = SPLIT_;
+    static constexpr int LV = L_ * SPLIT_;
+    static constexpr int HB = BGBIT_ / 2;
+    static_assert(SPLIT_ == 1 || (SPLIT_ == 2 && BGBIT_ % 2 == 0), "unsupported split");
+    IYK_HD static i32 digit(u32 td, int v)
+    {
+        typedef BrConsts<L_, BGBIT_> C;
+        const int lvl = v / SPLIT_;
+        const u32 sh = 32u - (u32)(lvl + 1) * BGBIT_;
+        const i32 d = (i32)(((td + C::offset_plus_round()) >> sh) & C::mask) - (i32)C::half_bg;
+        if (SPLIT_ == 1) return d;
+        const i32 half = 1 << (HB - 1);
+        const i32 lo = ((d + half) & ((1 << HB) - 1)) - half;
+        return (v % SPLIT_ == 0) ? ((d - lo) >> HB) : lo;
+    }
+    // largest |digit| and the scale applied to the key row of virtual level v
+    static constexpr double max_digit() { return SPLIT_ == 1 ? (double)(1 << (BGBIT_ - 1)) : (double)(1 << (HB - 1)); }
+    IYK_HD static u32 key_scale(int v) { return (SPLIT_ == 2 && (v % SPLIT_ == 0)) ? (1u << HB) : 1u; }
+};
+
+// forward pass 1, pre: signed digit of virtual level v of ((X^abar - 1) acc_h)[t + 32 j2], times zeta^j2
+template <class D>
+IYK_HD void fwd1_pre(int t, int v, u32 abar, const u32* acc_h, double (&x)[32], const double* zf)
 {
-    typedef BrConsts<L, BGBIT> C;
-    const u32 sh = 32u - (u32)(lvl + 1) * BGBIT;
 #pragma unroll
     for (int j2 = 0; j2 < 32; ++j2) {
         const u32 idx = (((u32)t - abar) + 32u * (u32)j2) & (2 * NTT_N - 1);
-        u32 v = acc_h[idx & (NTT_N - 1)];
-        v = (idx & NTT_N) ? 0u - v : v;
-        const u32 td = v - acc_h[t + 32 * j2];
-        const i32 d = (i32)(((td + C::offset_plus_round()) >> sh) & C::mask) - (i32)C::half_bg;
-        x[j2] = (j2 == 0) ? (double)d : mulmod((double)d, zf[j2]);
+        u32 a = acc_h[idx & (NTT_N - 1)];
+        a = (idx & NTT_N) ? 0u - a : a;
+        const u32 td = a - acc_h[t + 32 * j2];
+        const double d = (double)D::digit(td, v);
+        x[j2] = (j2 == 0) ? d : mulmod(d, zf[j2]);
     }
 }
 

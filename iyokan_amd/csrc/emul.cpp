@@ -187,9 +187,10 @@ void forward_1024_fp_dev(const double* in, double* out)
     }
 }
 
-template <int L, int BGBIT>
+template <class D>
 void blind_rotate_fp(const iyk_params* p, const u32* lin, const double* bk_ntt, u32* tlwe1)
 {
+    constexpr int L = D::LV;
     const FpTables& T = fptables();
     const fp::NttConsts& C = T.t.c;
     std::vector<u32> wave_lds(BR_WAVE_LDS_WORDS + 2);
@@ -219,7 +220,7 @@ void blind_rotate_fp(const iyk_params* p, const u32* lin, const double* bk_ntt, 
             {
                 Lane& r = R[lane];
                 if (first) {
-                    if (fwd) fp::fwd1_pre<L, BGBIT>(lane & 31, lvl, abar, acc_h(lane), r.x, C.zf);
+                    if (fwd) fp::fwd1_pre<D>(lane & 31, lvl, abar, acc_h(lane), r.x, C.zf);
                     else
                         for (int q = 0; q < 32; ++q) r.x[q] = fp::norm(r.accum[q]);
                 }
@@ -263,6 +264,7 @@ void blind_rotate_fp(const iyk_params* p, const u32* lin, const double* bk_ntt, 
                         track(R[lane].accum);
                     }
                 }
+                if (L > 3 && lvl == 1) ALL_LANES for (int q = 0; q < 32; ++q) R[lane].accum[q] = fp::norm(R[lane].accum[q]);
             }
             else {
                 ALL_LANES fp::inv2_post(lane & 31, R[lane].x, acc_h(lane), C.zi);
@@ -278,13 +280,20 @@ void blind_rotate_fp(const iyk_params* p, const u32* lin, const double* bk_ntt, 
 
 extern "C" {
 
-// FP64 path: NTT of every BK polynomial (signed 32-bit lift), device layout, balanced doubles
+// FP64 path: NTT of every (virtual) BK row polynomial, device layout, balanced doubles.
+// Output size: n * 2*LV * 2 * N doubles, LV = l (128-bit set) or 2l (80-bit set, split digits).
 int iyk_emul_bk_ntt_fp(const iyk_params* p, const uint32_t* bk, double* bk_ntt)
 {
-    const size_t polys = (size_t)iyk_bk_words(p) / p->N;
+    const int split = (p->l == 2 && p->Bgbit == 10) ? 2 : 1;
+    const int L = (int)p->l, LV = L * split, hb = (int)p->Bgbit / 2;
+    const size_t vpolys = (size_t)p->n * 2 * LV * 2;
     std::vector<double> in(NTT_N);
-    for (size_t q = 0; q < polys; ++q) {
-        for (int x = 0; x < NTT_N; ++x) in[x] = (double)(int32_t)bk[q * NTT_N + x];
+    for (size_t q = 0; q < vpolys; ++q) {
+        const size_t cc = q & 1, rv = (q >> 1) % (size_t)(2 * LV), i = (q >> 1) / (size_t)(2 * LV);
+        const int c = (int)(rv / LV), v = (int)(rv % LV);
+        const size_t src = ((i * (size_t)(2 * L) + (size_t)(c * L + v / split)) * 2 + cc) * NTT_N;
+        const u32 scale = (split == 2 && (v % split) == 0) ? (1u << hb) : 1u;
+        for (int x = 0; x < NTT_N; ++x) in[x] = (double)(int32_t)(bk[src + x] * scale);
         forward_1024_fp_dev(in.data(), bk_ntt + q * NTT_N);
     }
     return 0;
@@ -293,8 +302,9 @@ int iyk_emul_bk_ntt_fp(const iyk_params* p, const uint32_t* bk, double* bk_ntt)
 int iyk_emul_blind_rotate_fp(const iyk_params* p, const uint32_t* lin, const double* bk_ntt, uint32_t* tlwe1)
 {
     if (p->N != 1024 || p->k != 1) return -1;
-    if (p->l == 3 && p->Bgbit == 6) blind_rotate_fp<3, 6>(p, lin, bk_ntt, tlwe1);
-    else return -1;  // (2, 10): |sum| would exceed p/2, Goldilocks path only
+    if (p->l == 3 && p->Bgbit == 6) blind_rotate_fp<fp::Decomp<3, 6, 1>>(p, lin, bk_ntt, tlwe1);
+    else if (p->l == 2 && p->Bgbit == 10) blind_rotate_fp<fp::Decomp<2, 10, 2>>(p, lin, bk_ntt, tlwe1);
+    else return -1;
     return 0;
 }
 

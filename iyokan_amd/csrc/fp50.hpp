@@ -21,6 +21,13 @@
 
 #include "goldilocks.hpp"  // IYK_HD, u32/u64 typedefs
 
+// Belt and braces: exactness relies on every a*b, a+b below being ONE rounded IEEE operation.
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#elif defined(__GNUC__)
+#pragma GCC optimize("fp-contract=off")
+#endif
+
 namespace iyk {
 namespace fp {
 

@@ -64,11 +64,14 @@ struct iyk_hip_stream {
     int gpu = 0;
     hipStream_t s = nullptr;
     bool owned = false;
-    // descriptor staging (pinned host + device), reused batch after batch
+    // descriptor staging (pinned host + device), two halves used alternately so that enqueueing
+    // batch k+1 only has to wait for the H2D copy of batch k-1 (long finished), never for batch k
     char* h_stage = nullptr;
     char* d_stage = nullptr;
-    size_t stage_cap = 0;
-    hipEvent_t stage_free = nullptr;  // last H2D descriptor copy done -> pinned buffer reusable
+    size_t stage_cap = 0;             // bytes per half
+    int stage_sel = 0;
+    hipEvent_t stage_free = nullptr;  // H2D descriptor copy out of half 0 done
+    hipEvent_t stage_free1 = nullptr; // ... half 1
     // blind-rotation outputs (TLWE lvl1), one row per rotation job
     u32* d_rot = nullptr;
     u32* d_abar = nullptr;  // mod-switched rotation inputs, one row of ABAR_STRIDE words per job
@@ -102,10 +105,26 @@ int ensure_stage(iyk_hip_stream* st, size_t bytes)
     if (st->d_stage) HIP_TRY(hipFree(st->d_stage));
     st->h_stage = nullptr;
     st->d_stage = nullptr;
-    size_t cap = bytes + bytes / 2 + 4096;
-    HIP_TRY(hipHostMalloc((void**)&st->h_stage, cap, hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void**)&st->d_stage, cap));
+    size_t cap = (bytes + bytes / 2 + 4096 + 255) & ~(size_t)255;
+    HIP_TRY(hipHostMalloc((void**)&st->h_stage, 2 * cap, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&st->d_stage, 2 * cap));
     st->stage_cap = cap;
+    return IYK_OK;
+}
+
+// pick the staging half not used by the previous batch; returns its offset
+int acquire_stage(iyk_hip_stream* st, size_t bytes, size_t* off)
+{
+    int rc = ensure_stage(st, bytes);
+    if (rc) return rc;
+    st->stage_sel ^= 1;
+    HIP_TRY(hipEventSynchronize(st->stage_sel ? st->stage_free1 : st->stage_free));
+    *off = st->stage_sel ? st->stage_cap : 0;
+    return IYK_OK;
+}
+int release_stage(iyk_hip_stream* st)
+{
+    HIP_TRY(hipEventRecord(st->stage_sel ? st->stage_free1 : st->stage_free, st->s));
     return IYK_OK;
 }
 
@@ -143,12 +162,12 @@ int launch_br(iyk_hip_stream* st, int njobs, u32* d_tlwe1)
     return IYK_OK;
 }
 
-template <int L, int BGBIT>
+template <class DC>
 int launch_br_fp(iyk_hip_stream* st, int first, int njobs, u32* d_tlwe1)
 {
     static bool attr_set[64] = {};
     const Device& D = G.devs[st->gpu];
-    auto kern = blind_rotate_fp_kernel<L, BGBIT>;
+    auto kern = blind_rotate_fp_kernel<DC>;
     if (!attr_set[st->gpu]) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)BR_LDS_BYTES));
@@ -163,12 +182,13 @@ int launch_br_fp(iyk_hip_stream* st, int first, int njobs, u32* d_tlwe1)
 }
 
 // narrow frontiers: one rotation per workgroup of L waves (kernels.hpp, blind_rotate_fp_lat_kernel)
-template <int L, int BGBIT>
+template <class DC>
 int launch_br_fp_lat(iyk_hip_stream* st, int first, int njobs, u32* d_tlwe1)
 {
     static bool attr_set[64] = {};
     const Device& D = G.devs[st->gpu];
-    auto kern = blind_rotate_fp_lat_kernel<L, BGBIT>;
+    auto kern = blind_rotate_fp_lat_kernel<DC>;
+    constexpr int L = DC::LV;
     constexpr size_t lds = br_lat_lds_bytes<L>();
     if (!attr_set[st->gpu]) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -183,6 +203,25 @@ int launch_br_fp_lat(iyk_hip_stream* st, int first, int njobs, u32* d_tlwe1)
     return IYK_OK;
 }
 
+// Measured (profiles/r01_sweep_kernels.txt): the wave-per-rotation kernel runs 2048 rotations per 28 ms
+// round; the one-wave-per-level kernel takes 7 ms for <= 256 and ~21 ms per 1024.  So: full 2048-rounds
+// on the former, a remainder of up to lat_threshold rotations on the latter.
+template <class DC>
+int dispatch_fp(iyk_hip_stream* st, int njobs, u32* d_tlwe1)
+{
+    int rc;
+    const char* lat = std::getenv("IYK_HIP_LATENCY_KERNEL");  // "0" disables, "1" forces (A/B, tests)
+    const bool force_on = lat && lat[0] == '1', force_off = lat && lat[0] == '0';
+    if (force_on) return launch_br_fp_lat<DC>(st, 0, njobs, d_tlwe1);
+    if (force_off) return launch_br_fp<DC>(st, 0, njobs, d_tlwe1);
+    const int round = 2048;
+    const int rem = njobs % round, full = njobs - rem;
+    if (rem > G.lat_threshold) return launch_br_fp<DC>(st, 0, njobs, d_tlwe1);
+    if (full && (rc = launch_br_fp<DC>(st, 0, full, d_tlwe1))) return rc;
+    if (rem) return launch_br_fp_lat<DC>(st, full, rem, d_tlwe1);
+    return IYK_OK;
+}
+
 // mod-switch every job into st->d_abar, then one wavefront per job
 int launch_blind_rotate(iyk_hip_stream* st, const u32* d_arena, const RotJob* d_jobs, int njobs,
                         u32* d_tlwe1)
@@ -194,19 +233,8 @@ int launch_blind_rotate(iyk_hip_stream* st, const u32* d_arena, const RotJob* d_
                        ABAR_STRIDE);
     HIP_TRY(hipGetLastError());
     if (G.use_fp) {
-        // Measured (profiles/r01_sweep_kernels.txt): the wave-per-rotation kernel runs 2048 rotations per
-        // 28 ms round; the 3-wave-per-rotation kernel takes 7 ms for <= 256 and ~21 ms per 1024.  So: full
-        // 2048-rounds on the former, a remainder of up to lat_threshold rotations on the latter.
-        const char* lat = std::getenv("IYK_HIP_LATENCY_KERNEL");  // "0" disables, "1" forces (A/B, tests)
-        const bool force_on = lat && lat[0] == '1', force_off = lat && lat[0] == '0';
-        if (force_on) return launch_br_fp_lat<3, 6>(st, 0, njobs, d_tlwe1);
-        if (force_off) return launch_br_fp<3, 6>(st, 0, njobs, d_tlwe1);
-        const int round = 2048;
-        const int rem = njobs % round, full = njobs - rem;
-        if (rem > G.lat_threshold) return launch_br_fp<3, 6>(st, 0, njobs, d_tlwe1);
-        if (full && (rc = launch_br_fp<3, 6>(st, 0, full, d_tlwe1))) return rc;
-        if (rem) return launch_br_fp_lat<3, 6>(st, full, rem, d_tlwe1);
-        return IYK_OK;
+        if (p.l == 3) return dispatch_fp<fp::Decomp<3, 6, 1>>(st, njobs, d_tlwe1);
+        return dispatch_fp<fp::Decomp<2, 10, 2>>(st, njobs, d_tlwe1);
     }
     if (p.l == 3 && p.Bgbit == 6) return launch_br<3, 6>(st, njobs, d_tlwe1);
     if (p.l == 2 && p.Bgbit == 10) return launch_br<2, 10>(st, njobs, d_tlwe1);
@@ -304,9 +332,14 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
     // Path choice: the FP64 field (p = 2^50 - 16383) is exact iff 2 * (k+1) l N (Bg/2) 2^31 < p
     // (fp50.hpp); true for the 128-bit set, false for the 80-bit one.  IYK_HIP_NTT=goldilocks forces
     // the 64-bit integer path (kept as the cross-check and for A/B measurements).
-    const double worst = 2.0 * (p.k + 1) * p.l * p.N * (double)(1u << (p.Bgbit - 1)) * 2147483648.0;
+    // (128-bit set: 3 levels of 6-bit digits; 80-bit set: each 10-bit digit split into two 5-bit halves,
+    // 4 virtual levels — blind_rotate_fp.hpp Decomp.)
+    const int split = (p.l == 2 && p.Bgbit == 10) ? 2 : 1;
+    const int LV = (int)p.l * split;
+    const double dmax = split == 1 ? (double)(1u << (p.Bgbit - 1)) : (double)(1u << (p.Bgbit / 2 - 1));
+    const double worst = 2.0 * (p.k + 1) * LV * p.N * dmax * 2147483648.0;
     const char* force = std::getenv("IYK_HIP_NTT");
-    const bool use_fp = (p.l == 3 && p.Bgbit == 6) && worst < fp::P && !(force && std::string(force) == "goldilocks");
+    const bool use_fp = worst < fp::P && !(force && std::string(force) == "goldilocks");
     std::vector<u64> twf(NTT_N), twi(NTT_N);
     fp::HostTables fpt;
     if (use_fp) {
@@ -335,7 +368,7 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
         HIP_TRY(hipSetDevice(D.ordinal));
         u32* d_bk = nullptr;
         HIP_TRY(hipMalloc((void**)&d_bk, bk_words * sizeof(u32)));
-        HIP_TRY(hipMalloc((void**)&D.bk_ntt, bk_words * sizeof(u64)));
+        HIP_TRY(hipMalloc((void**)&D.bk_ntt, bk_words * sizeof(u64) * (use_fp ? split : 1)));
         HIP_TRY(hipMalloc((void**)&D.ksk, ksk_pad.size() * sizeof(u32)));
         HIP_TRY(hipMalloc((void**)&D.tw_fwd, NTT_N * sizeof(u64)));
         HIP_TRY(hipMalloc((void**)&D.tw_inv, NTT_N * sizeof(u64)));
@@ -344,8 +377,9 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
         HIP_TRY(hipMemcpy(D.tw_fwd, twf.data(), NTT_N * sizeof(u64), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(D.tw_inv, twi.data(), NTT_N * sizeof(u64), hipMemcpyHostToDevice));
         if (use_fp)
-            hipLaunchKernelGGL(bk_ntt_fp_kernel, dim3((unsigned)((polys + 1) / 2)), dim3(64), 0, 0, d_bk,
-                               (double*)D.bk_ntt, (const double*)D.tw_fwd, fpt.c, polys);
+            hipLaunchKernelGGL(bk_ntt_fp_kernel, dim3((unsigned)((polys * split + 1) / 2)), dim3(64), 0, 0, d_bk,
+                               (double*)D.bk_ntt, (const double*)D.tw_fwd, fpt.c, polys * split, (int)p.l, split,
+                               (int)p.Bgbit / 2);
         else
             hipLaunchKernelGGL(bk_ntt_kernel, dim3((unsigned)((polys + 1) / 2)), dim3(64), 0, 0, d_bk, D.bk_ntt,
                                D.tw_fwd, polys);
@@ -358,7 +392,7 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
     G.fpc = fpt.c;
     G.ksk_stride = stride;
     G.devs = devs;
-    G.key_bytes = bk_words * sizeof(u64) + ksk_pad.size() * sizeof(u32) + 2 * NTT_N * sizeof(u64);
+    G.key_bytes = bk_words * sizeof(u64) * (use_fp ? split : 1) + ksk_pad.size() * sizeof(u32) + 2 * NTT_N * sizeof(u64);
     G.init = true;
     return IYK_OK;
 }
@@ -402,6 +436,7 @@ static int stream_new(int gpu_index, void* wrap, bool do_wrap, iyk_hip_stream** 
         st->owned = true;
     }
     (void)hipEventCreateWithFlags(&st->stage_free, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&st->stage_free1, hipEventDisableTiming);
     (void)hipEventCreate(&st->ev_br0);
     (void)hipEventCreate(&st->ev_br1);
     (void)hipEventCreate(&st->ev_ks1);
@@ -429,6 +464,7 @@ int iyk_hip_stream_destroy(iyk_hip_stream* st)
     if (st->d_abar) (void)hipFree(st->d_abar);
     if (st->d_scratch) (void)hipFree(st->d_scratch);
     (void)hipEventDestroy(st->stage_free);
+    (void)hipEventDestroy(st->stage_free1);
     if (st->log_on) {
         for (hipEvent_t e : st->log_events) (void)hipEventDestroy(e);
     }
@@ -554,19 +590,21 @@ int iyk_hip_gate_batch(iyk_hip_stream* st, uint32_t* d_arena, uint64_t count, co
     const size_t ks_off = (rot_bytes + 15) & ~(size_t)15;
     const size_t ew_off = (ks_off + ks_bytes + 15) & ~(size_t)15;
     const size_t total = ew_off + ew_bytes;
-    if ((rc = ensure_stage(st, total))) return rc;
+    size_t soff = 0;
+    if ((rc = acquire_stage(st, total, &soff))) return rc;
     if ((rc = ensure_rot(st, rot.size()))) return rc;
-    HIP_TRY(hipEventSynchronize(st->stage_free));  // previous descriptor copy has left the pinned buffer
-    if (rot_bytes) std::memcpy(st->h_stage, rot.data(), rot_bytes);
-    if (ks_bytes) std::memcpy(st->h_stage + ks_off, ks.data(), ks_bytes);
-    if (ew_bytes) std::memcpy(st->h_stage + ew_off, ew.data(), ew_bytes);
-    HIP_TRY(hipMemcpyAsync(st->d_stage, st->h_stage, total, hipMemcpyHostToDevice, st->s));
-    HIP_TRY(hipEventRecord(st->stage_free, st->s));
+    char* hs = st->h_stage + soff;
+    char* ds = st->d_stage + soff;
+    if (rot_bytes) std::memcpy(hs, rot.data(), rot_bytes);
+    if (ks_bytes) std::memcpy(hs + ks_off, ks.data(), ks_bytes);
+    if (ew_bytes) std::memcpy(hs + ew_off, ew.data(), ew_bytes);
+    HIP_TRY(hipMemcpyAsync(ds, hs, total, hipMemcpyHostToDevice, st->s));
+    if ((rc = release_stage(st))) return rc;
 
     const Device& D = G.devs[st->gpu];
     if (!ew.empty()) {
         hipLaunchKernelGGL(elementwise_kernel, dim3((unsigned)ew.size()), dim3(256), 0, st->s, d_arena,
-                           (const EwJob*)(st->d_stage + ew_off), p.n, p.mu);
+                           (const EwJob*)(ds + ew_off), p.n, p.mu);
         HIP_TRY(hipGetLastError());
     }
     st->timing_valid = false;
@@ -580,10 +618,9 @@ int iyk_hip_gate_batch(iyk_hip_stream* st, uint32_t* d_arena, uint64_t count, co
             st->ev_ks1 = e3[2];
         }
         HIP_TRY(hipEventRecord(st->ev_br0, st->s));
-        if ((rc = launch_blind_rotate(st, d_arena, (const RotJob*)st->d_stage, (int)rot.size(), st->d_rot)))
-            return rc;
+        if ((rc = launch_blind_rotate(st, d_arena, (const RotJob*)ds, (int)rot.size(), st->d_rot))) return rc;
         HIP_TRY(hipEventRecord(st->ev_br1, st->s));
-        if ((rc = launch_keyswitch(st, d_arena, (const KsJob*)(st->d_stage + ks_off), (int)ks.size()))) return rc;
+        if ((rc = launch_keyswitch(st, d_arena, (const KsJob*)(ds + ks_off), (int)ks.size()))) return rc;
         HIP_TRY(hipEventRecord(st->ev_ks1, st->s));
         st->timing_valid = true;
         st->timing_has_ks = true;
@@ -626,13 +663,13 @@ int iyk_hip_blind_rotate_batch(iyk_hip_stream* st, const uint32_t* d_arena, uint
     std::vector<RotJob> rot(count);
     for (uint64_t g = 0; g < count; ++g) rot[g] = RotJob{ia[g], ib[g], sa[g], sb[g], off[g]};
     const size_t bytes = rot.size() * sizeof(RotJob);
-    if ((rc = ensure_stage(st, bytes))) return rc;
-    HIP_TRY(hipEventSynchronize(st->stage_free));
-    std::memcpy(st->h_stage, rot.data(), bytes);
-    HIP_TRY(hipMemcpyAsync(st->d_stage, st->h_stage, bytes, hipMemcpyHostToDevice, st->s));
-    HIP_TRY(hipEventRecord(st->stage_free, st->s));
+    size_t soff = 0;
+    if ((rc = acquire_stage(st, bytes, &soff))) return rc;
+    std::memcpy(st->h_stage + soff, rot.data(), bytes);
+    HIP_TRY(hipMemcpyAsync(st->d_stage + soff, st->h_stage + soff, bytes, hipMemcpyHostToDevice, st->s));
+    if ((rc = release_stage(st))) return rc;
     HIP_TRY(hipEventRecord(st->ev_br0, st->s));
-    if ((rc = launch_blind_rotate(st, d_arena, (const RotJob*)st->d_stage, (int)count, d_tlwe1))) return rc;
+    if ((rc = launch_blind_rotate(st, d_arena, (const RotJob*)(st->d_stage + soff), (int)count, d_tlwe1))) return rc;
     HIP_TRY(hipEventRecord(st->ev_br1, st->s));
     st->timing_valid = true;
     st->timing_has_ks = false;

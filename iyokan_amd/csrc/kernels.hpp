@@ -243,21 +243,28 @@ static constexpr size_t BR_LDS_BYTES = 2 * NTT_N * sizeof(u64) + (size_t)BR_WAVE
 // ------------------------------------------------------------------------------------------
 // FP64 path (fp50.hpp / blind_rotate_fp.hpp): same launch geometry, LDS layout and pass
 // structure as blind_rotate_kernel, arithmetic mod p = 2^50 - 16383 on the FMA pipe.
+// BK rows for the FP path: [n][c][v][cc] with v a VIRTUAL level (Decomp): source row c*L + v/split,
+// coefficients scaled by 2^hb (mod 2^32) for the hi part, lifted as signed 32-bit.
 __global__ __launch_bounds__(64) void bk_ntt_fp_kernel(const u32* __restrict__ bk, double* __restrict__ bk_ntt,
                                                        const double* __restrict__ tw_fwd, fp::NttConsts C,
-                                                       size_t polys)
+                                                       size_t vpolys, int L, int split, int hb)
 {
     __shared__ double xb[2 * 32 * XB_STRIDE];
     const int lane = threadIdx.x, h = lane >> 5, t = lane & 31;
     size_t q = (size_t)blockIdx.x * 2 + h;
-    const bool live = q < polys;
-    if (!live) q = polys - 1;
+    const bool live = q < vpolys;
+    if (!live) q = vpolys - 1;
+    const int LV = L * split;
+    const size_t cc = q & 1, rv = (q >> 1) % (size_t)(2 * LV), i = (q >> 1) / (size_t)(2 * LV);
+    const int c = (int)(rv / LV), v = (int)(rv % LV);
+    const size_t src = ((i * (size_t)(2 * L) + (size_t)(c * L + v / split)) * 2 + cc) * NTT_N;
+    const u32 scale = (split == 2 && (v % split) == 0) ? (1u << hb) : 1u;
     double* xbo = xb + h * 32 * XB_STRIDE;
     double x[32];
 #pragma unroll
     for (int j2 = 0; j2 < 32; ++j2) {
-        const double v = (double)(int32_t)bk[q * NTT_N + t + 32 * j2];  // signed lift: |sum| < p/2 (fp50.hpp)
-        x[j2] = j2 ? fp::mulmod(v, C.zf[j2]) : v;
+        const double val = (double)(int32_t)(bk[src + t + 32 * j2] * scale);  // signed lift: |sum| < p/2 (fp50.hpp)
+        x[j2] = j2 ? fp::mulmod(val, C.zf[j2]) : val;
     }
     fp::ntt32_dif(x, C.w);
 #pragma unroll
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(64) void bk_ntt_fp_kernel(const u32* __restrict__ b
     }
 }
 
-template <int L, int BGBIT>
+template <class D>
 __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
     const u32* __restrict__ abar_all, int njobs, const double* __restrict__ bk_ntt,
     const double* __restrict__ tw_fwd, const double* __restrict__ tw_inv, fp::NttConsts C,
@@ -300,6 +307,7 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
     const bool live = job < njobs;
     if (!live) job = njobs - 1;
 
+    constexpr int L = D::LV;  // (virtual) gadget levels
     u32* acc_lds = s_wave + wave * BR_WAVE_LDS_WORDS;
     const u32* abar = abar_all + (size_t)job * abar_stride;
 
@@ -330,7 +338,7 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
             double b0o[2], b0t[2], b1o[2], b1t[2];
 
             if (first) {
-                if (fwd) fp::fwd1_pre<L, BGBIT>(t, lvl, ab, acc_h, x, C.zf);
+                if (fwd) fp::fwd1_pre<D>(t, lvl, ab, acc_h, x, C.zf);
                 else {
 #pragma unroll
                     for (int q = 0; q < 32; ++q) x[q] = fp::norm(accum[q]);
@@ -382,6 +390,12 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
                     }
                     lds_sync();
                 }
+                // magnitude discipline: each level adds two terms of <= 1.1 p; with 4 virtual levels the
+                // running sum is renormalised half way so it can never reach 2^53 (8 p)
+                if (L > 3 && lvl == 1) {
+#pragma unroll
+                    for (int q = 0; q < 32; ++q) accum[q] = fp::norm(accum[q]);
+                }
             }
             else {
                 fp::inv2_post(t, x, acc_h, C.zi);
@@ -411,12 +425,13 @@ constexpr size_t br_lat_lds_bytes()
     return 2 * NTT_N * sizeof(double) + (2 * NTT_N + L * BR_LAT_WAVE_WORDS) * sizeof(u32);
 }
 
-template <int L, int BGBIT>
-__global__ __launch_bounds__(64 * L) void blind_rotate_fp_lat_kernel(
+template <class D>
+__global__ __launch_bounds__(64 * D::LV) void blind_rotate_fp_lat_kernel(
     const u32* __restrict__ abar_all, int njobs, const double* __restrict__ bk_ntt,
     const double* __restrict__ tw_fwd, const double* __restrict__ tw_inv, fp::NttConsts C,
     u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride)
 {
+    constexpr int L = D::LV;  // one wavefront per (virtual) gadget level
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* s_twf = reinterpret_cast<double*>(smem);
     double* s_twi = s_twf + NTT_N;
@@ -453,7 +468,7 @@ __global__ __launch_bounds__(64 * L) void blind_rotate_fp_lat_kernel(
             const double* bko = bk_step + (size_t)((h * L + wave) * 2 + h) * NTT_N + (size_t)t * 2;
             const double* bkt = bk_step + (size_t)(((1 - h) * L + wave) * 2 + h) * NTT_N + (size_t)t * 2;
             // forward pass 1 of level `wave`
-            fp::fwd1_pre<L, BGBIT>(t, wave, ab, acc_h, x, C.zf);
+            fp::fwd1_pre<D>(t, wave, ab, acc_h, x, C.zf);
             fp::ntt32_dif(x, C.w);
             fp::fwd1_twiddle(t, x, s_twf);
             fp::xpose_write<false>(t, x, xb, false);
@@ -481,6 +496,10 @@ __global__ __launch_bounds__(64 * L) void blind_rotate_fp_lat_kernel(
                 }
                 lds_sync();
             }
+        }
+        if (L > 3) {  // L partial sums of <= 2.2 p each could exceed 2^53: reduce each first
+#pragma unroll
+            for (int q = 0; q < 32; ++q) accum[q] = fp::norm(accum[q]);
         }
         // reduce the L partial sums into wave 0 (two rounds of 16 values through each wave's buffer)
 #pragma unroll

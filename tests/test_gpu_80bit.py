@@ -10,11 +10,24 @@ from iyokan_amd.params import OPS, PLAIN
 pytestmark = pytest.mark.gpu
 
 
-def test_80bit_gates_bit_exact(keys80, oracle80):
+@pytest.mark.parametrize("path", ["fp50", "goldilocks"])
+def test_80bit_gates_bit_exact(path, keys80, oracle80):
+    """Both exact-arithmetic paths at the 80-bit set: FP64 field with split digits (default) and the
+    64-bit integer field (IYK_HIP_NTT=goldilocks)."""
     from iyokan_amd import hip
 
+    old = os.environ.get("IYK_HIP_NTT")
+    if path == "goldilocks":
+        os.environ["IYK_HIP_NTT"] = "goldilocks"
+    else:
+        os.environ.pop("IYK_HIP_NTT", None)
     hip.initialize(keys80, device_ids=(0,))
+    if old is None:
+        os.environ.pop("IYK_HIP_NTT", None)
+    else:
+        os.environ["IYK_HIP_NTT"] = old
     try:
+        assert hip.ntt_path() == path
         st = hip.Stream(0)
         p = keys80.params
         rng = np.random.default_rng(5)

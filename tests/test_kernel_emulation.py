@@ -37,14 +37,18 @@ def test_emulated_blind_rotate_bit_exact(which, request):
         assert np.array_equal(ref, got)
 
 
-def test_emulated_fp64_path_bit_exact(keys128, oracle128):
+@pytest.mark.parametrize("which", ["128", "80"])
+def test_emulated_fp64_path_bit_exact(which, request):
     """FP64-field kernel (fp50.hpp, p = 2^50 - 16383): lane-by-lane emulation == oracle, and the
-    lazily-reduced magnitudes stay well inside the exact-integer range of a double (< 8 p = 2^53)."""
+    lazily-reduced magnitudes stay well inside the exact-integer range of a double (< 8 p = 2^53).
+    80-bit set: every 10-bit gadget digit split into two 5-bit halves (4 virtual levels)."""
+    keys128 = request.getfixturevalue("keys" + which)
+    oracle128 = request.getfixturevalue("oracle" + which)
     p = keys128.params
     em = _emul()
     em.iyk_emul_fp_max_magnitude.restype = ctypes.c_double
     dp = ctypes.POINTER(ctypes.c_double)
-    bk = np.zeros(p.bk_words, dtype=np.float64)
+    bk = np.zeros(p.bk_words * (2 if p.l == 2 else 1), dtype=np.float64)
     assert em.iyk_emul_bk_ntt_fp(ctypes.byref(p), keys128.bk.ctypes.data_as(u32p), bk.ctypes.data_as(dp)) == 0
     assert np.abs(bk).max() <= 1125899906826241 / 2 + 1
     for seed, (a, b) in enumerate([(1, 1), (0, 1), (1, 0)]):
