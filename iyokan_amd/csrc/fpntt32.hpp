@@ -7,9 +7,15 @@
 // with zeta = psi^32 (order 64), w32 = zeta^2.  Inverse = forward DIF with the output index
 // negated, tw_inv[k2][j1] = psi^(-j1(2k2+1)) / N, post-twist zeta^(-j2).
 //
-// Magnitude discipline (units of p; everything must stay < 8 = 2^53 / p): DIF inputs <= 1.25,
-// the add branch is renormalised after stages 1 and 3, worst intermediate 5.76, outputs <= 3.2
-// (derivation in DESIGN.md; host_selftest.cpp tracks the observed maxima).
+// Magnitude discipline (units of p; every value must stay < 8 = 2^53 / p so that all additions are
+// exact integers).  A mulmod whose first operand is bounded by A p returns |r| <= (0.5 + 3A/16) p.
+// Bounds are propagated at COMPILE TIME through the butterfly network (make_norm_sched): with inputs
+// <= 1.25 p, the invariant "stage outputs <= {3.75, 3.75, 2.93, 1.6} p" is enforced by renormalising
+// exactly those sums / twiddle-free differences whose static bound would break it (34 of the 160
+// butterfly outputs).  Consequences: no intermediate exceeds 5.75 p, outputs are <= 2.14 p, and the
+// consumers stay in range: twiddle mulmod -> <= 0.9 p (next pass input), MAC terms <= 0.9 p each
+// (six or eight of them per accumulator).  host_selftest.cpp / the emulation tests track the
+// observed maxima against these bounds.
 #pragma once
 #include "fp50.hpp"
 #include "ntt32.hpp"  // brv5, NTT_N
@@ -24,6 +30,44 @@ struct NttConsts {
     double zi[32];     // zeta^(-j2)
 };
 
+// static renormalisation schedule, see the header comment
+struct NormSched {
+    bool sum[5][32];
+    bool dif[5][32];
+    double out_bound, mid_bound;
+};
+constexpr double mm_bound(double t) { return 0.5 + 3.0 * t / 16.0; }
+constexpr NormSched make_norm_sched(double b0)
+{
+    NormSched S{};
+    double B[32] = {};
+    for (int i = 0; i < 32; ++i) B[i] = b0;
+    const double beta[5] = {3.75, 3.75, 2.93, 1.6, 1e9};
+    double mid = 0;
+    for (int s = 0; s < 5; ++s) {
+        const int len = 16 >> s;
+        for (int blk = 0; blk < 32; blk += 2 * len)
+            for (int j = 0; j < len; ++j) {
+                const int a = blk + j, b = blk + j + len;
+                const double t = B[a] + B[b];
+                if (t > mid) mid = t;
+                S.sum[s][a] = t > beta[s];
+                S.dif[s][b] = (j == 0) && t > beta[s];
+                B[a] = S.sum[s][a] ? 0.51 : t;
+                B[b] = (j == 0) ? (S.dif[s][b] ? 0.51 : t) : mm_bound(t);
+            }
+    }
+    double ob = 0;
+    for (int i = 0; i < 32; ++i)
+        if (B[i] > ob) ob = B[i];
+    S.out_bound = ob;
+    S.mid_bound = mid;
+    return S;
+}
+static constexpr double DIF_INPUT_BOUND = 1.25;
+static constexpr NormSched kSched = make_norm_sched(DIF_INPUT_BOUND);
+static_assert(kSched.mid_bound < 7.5 && kSched.out_bound < 3.2, "magnitude discipline violated");
+
 // cyclic 32-point DIF, natural in, bit-reversed out; twiddle of position j at stage s is w[j << s]
 IYK_HD void ntt32_dif(double (&a)[32], const double* w)
 {
@@ -36,8 +80,8 @@ IYK_HD void ntt32_dif(double (&a)[32], const double* w)
             for (int j = 0; j < len; ++j) {
                 const double u = a[blk + j], v = a[blk + j + len];
                 const double sum = u + v, dif = u - v;
-                a[blk + j] = (s == 1 || s == 3) ? norm(sum) : sum;
-                a[blk + j + len] = (j == 0) ? dif : mulmod(dif, w[j << s]);
+                a[blk + j] = kSched.sum[s][blk + j] ? norm(sum) : sum;
+                a[blk + j + len] = (j == 0) ? (kSched.dif[s][blk + j + len] ? norm(dif) : dif) : mulmod(dif, w[j << s]);
             }
         }
     }

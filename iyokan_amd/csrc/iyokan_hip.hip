@@ -43,6 +43,7 @@ struct Device {
     u32* ksk = nullptr;
     u64* tw_fwd = nullptr;   // u64 or double tables, same size
     u64* tw_inv = nullptr;
+    fp::NttConsts* fpc = nullptr;  // FP path: 32-point twiddles + twists, read by scalar loads
 };
 
 struct Global {
@@ -175,7 +176,7 @@ int launch_br_fp(iyk_hip_stream* st, int first, int njobs, u32* d_tlwe1)
     }
     dim3 grid((njobs + BR_WAVES - 1) / BR_WAVES), block(64 * BR_WAVES);
     hipLaunchKernelGGL(kern, grid, block, BR_LDS_BYTES, st->s, (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE,
-                       njobs, (const double*)D.bk_ntt, (const double*)D.tw_fwd, (const double*)D.tw_inv, G.fpc,
+                       njobs, (const double*)D.bk_ntt, (const double*)D.tw_fwd, (const double*)D.tw_inv, D.fpc,
                        d_tlwe1 + (size_t)first * (NTT_N + 1), G.p.n, G.p.mu, ABAR_STRIDE);
     HIP_TRY(hipGetLastError());
     return IYK_OK;
@@ -197,7 +198,7 @@ int launch_br_fp_lat(iyk_hip_stream* st, int first, int njobs, u32* d_tlwe1)
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3(64 * L), lds, st->s,
                        (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE, njobs, (const double*)D.bk_ntt,
-                       (const double*)D.tw_fwd, (const double*)D.tw_inv, G.fpc, d_tlwe1 + (size_t)first * (NTT_N + 1),
+                       (const double*)D.tw_fwd, (const double*)D.tw_inv, D.fpc, d_tlwe1 + (size_t)first * (NTT_N + 1),
                        G.p.n, G.p.mu, ABAR_STRIDE);
     HIP_TRY(hipGetLastError());
     return IYK_OK;
@@ -372,13 +373,15 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
         HIP_TRY(hipMalloc((void**)&D.ksk, ksk_pad.size() * sizeof(u32)));
         HIP_TRY(hipMalloc((void**)&D.tw_fwd, NTT_N * sizeof(u64)));
         HIP_TRY(hipMalloc((void**)&D.tw_inv, NTT_N * sizeof(u64)));
+        HIP_TRY(hipMalloc((void**)&D.fpc, sizeof(fp::NttConsts)));
+        HIP_TRY(hipMemcpy(D.fpc, &fpt.c, sizeof(fp::NttConsts), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_bk, bk_torus, bk_words * sizeof(u32), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(D.ksk, ksk_pad.data(), ksk_pad.size() * sizeof(u32), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(D.tw_fwd, twf.data(), NTT_N * sizeof(u64), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(D.tw_inv, twi.data(), NTT_N * sizeof(u64), hipMemcpyHostToDevice));
         if (use_fp)
             hipLaunchKernelGGL(bk_ntt_fp_kernel, dim3((unsigned)((polys * split + 1) / 2)), dim3(64), 0, 0, d_bk,
-                               (double*)D.bk_ntt, (const double*)D.tw_fwd, fpt.c, polys * split, (int)p.l, split,
+                               (double*)D.bk_ntt, (const double*)D.tw_fwd, D.fpc, polys * split, (int)p.l, split,
                                (int)p.Bgbit / 2);
         else
             hipLaunchKernelGGL(bk_ntt_kernel, dim3((unsigned)((polys + 1) / 2)), dim3(64), 0, 0, d_bk, D.bk_ntt,
@@ -408,6 +411,7 @@ int iyk_hip_cleanup(void)
         HIP_TRY(hipFree(D.ksk));
         HIP_TRY(hipFree(D.tw_fwd));
         HIP_TRY(hipFree(D.tw_inv));
+        HIP_TRY(hipFree(D.fpc));
     }
     G.devs.clear();
     G.init = false;

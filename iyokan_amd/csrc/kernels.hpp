@@ -246,10 +246,12 @@ static constexpr size_t BR_LDS_BYTES = 2 * NTT_N * sizeof(u64) + (size_t)BR_WAVE
 // BK rows for the FP path: [n][c][v][cc] with v a VIRTUAL level (Decomp): source row c*L + v/split,
 // coefficients scaled by 2^hb (mod 2^32) for the hi part, lifted as signed 32-bit.
 __global__ __launch_bounds__(64) void bk_ntt_fp_kernel(const u32* __restrict__ bk, double* __restrict__ bk_ntt,
-                                                       const double* __restrict__ tw_fwd, fp::NttConsts C,
-                                                       size_t vpolys, int L, int split, int hb)
+                                                       const double* __restrict__ tw_fwd,
+                                                       const fp::NttConsts* __restrict__ Cp, size_t vpolys, int L,
+                                                       int split, int hb)
 {
     __shared__ double xb[2 * 32 * XB_STRIDE];
+    const fp::NttConsts& C = *Cp;
     const int lane = threadIdx.x, h = lane >> 5, t = lane & 31;
     size_t q = (size_t)blockIdx.x * 2 + h;
     const bool live = q < vpolys;
@@ -285,9 +287,12 @@ __global__ __launch_bounds__(64) void bk_ntt_fp_kernel(const u32* __restrict__ b
 template <class D>
 __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
     const u32* __restrict__ abar_all, int njobs, const double* __restrict__ bk_ntt,
-    const double* __restrict__ tw_fwd, const double* __restrict__ tw_inv, fp::NttConsts C,
+    const double* __restrict__ tw_fwd, const double* __restrict__ tw_inv, const fp::NttConsts* __restrict__ Cp,
     u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride)
 {
+    // twist / 32-point twiddle constants are read with scalar loads where they are used: held by value
+    // they overflow the SGPR file and come back through v_readlane (a VALU op per 32 bits)
+    const fp::NttConsts& C = *Cp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* s_twf = reinterpret_cast<double*>(smem);         // [k2][j1]
     double* s_twi = s_twf + NTT_N;                           // [j1][k2]
@@ -428,9 +433,10 @@ constexpr size_t br_lat_lds_bytes()
 template <class D>
 __global__ __launch_bounds__(64 * D::LV) void blind_rotate_fp_lat_kernel(
     const u32* __restrict__ abar_all, int njobs, const double* __restrict__ bk_ntt,
-    const double* __restrict__ tw_fwd, const double* __restrict__ tw_inv, fp::NttConsts C,
+    const double* __restrict__ tw_fwd, const double* __restrict__ tw_inv, const fp::NttConsts* __restrict__ Cp,
     u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride)
 {
+    const fp::NttConsts& C = *Cp;
     constexpr int L = D::LV;  // one wavefront per (virtual) gadget level
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* s_twf = reinterpret_cast<double*>(smem);
