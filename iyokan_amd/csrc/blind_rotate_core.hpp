@@ -128,9 +128,6 @@ IYK_HD size_t bk_dev_index(int r, int c, int k)
     const int t = k & 31, k1 = k >> 5;
     return ((size_t)(r * 2 + c) * 16 + (k1 >> 1)) * 64 + (size_t)t * 2 + (k1 & 1);
 }
-struct BkPair {
-    u64 v[2];
-};
 // base pointers of the two BK rows a lane multiplies against at level `lvl` (already offset by t)
 template <int L>
 IYK_HD const u64* bk_row_own(const u64* bk_step, int h, int t, int lvl)

@@ -1,0 +1,108 @@
+"""GPU: remaining C-ABI entry points and error behaviour (status codes, never a crash or a fallback)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from iyokan_amd import client
+from iyokan_amd.params import OPS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(keys128):
+    from iyokan_amd import hip
+
+    hip.initialize(keys128, device_ids=(0,))
+    yield hip
+    hip.cleanup()
+
+
+def test_arena_roundtrip_and_copy_ops(gpu, keys128):
+    st = gpu.Stream(0)
+    p = keys128.params
+    rng = np.random.default_rng(1)
+    host = rng.integers(0, 2**32, size=(5, p.n + 1), dtype=np.uint64).astype(np.uint32)
+    arena = gpu.Arena(12)
+    st.upload(arena, 2, host)
+    assert np.array_equal(st.download(arena, 2, 5), host)
+    # COPY / NOT / CONST are exact elementwise maps on arbitrary words
+    st.gate_batch(arena, [OPS["COPY"], OPS["NOT"], OPS["CONSTONE"], OPS["CONSTZERO"]], [2, 3, -1, -1],
+                  [-1] * 4, [-1] * 4, [8, 9, 10, 11])
+    st.sync()
+    got = st.download(arena, 8, 4)
+    assert np.array_equal(got[0], host[0])
+    assert np.array_equal(got[1], (np.uint32(0) - host[1]).astype(np.uint32))
+    assert np.array_equal(got[2], client.trivial(p, 1)) and np.array_equal(got[3], client.trivial(p, 0))
+    arena.free()
+    st.destroy()
+
+
+def test_blind_rotate_batch_matches_oracle_lvl1(gpu, keys128, oracle128):
+    """iyk_hip_blind_rotate_batch: rotation + sample-extract only, checked against the oracle's lvl1 TLWE."""
+    import torch
+
+    st = gpu.Stream(0)
+    p = keys128.params
+    cts = client.encrypt_bits(keys128, [1, 0, 1], seed=90)
+    arena = gpu.Arena(3)
+    st.upload(arena, 0, cts)
+    out = torch.zeros((2, p.N + 1), dtype=torch.int32, device="cuda")
+    mu = np.uint32(p.mu)
+    st.blind_rotate_batch(arena, [0, 2], [1, -1], [-1, 1], [-1, 0], [mu, np.uint32(0)], out.data_ptr())
+    st.sync()
+    got = out.cpu().numpy().view(np.uint32)
+    lin0 = (np.uint32(0) - cts[0] - cts[1]).astype(np.uint32)
+    lin0[-1] = np.uint32((int(lin0[-1]) + p.mu) & 0xFFFFFFFF)
+    assert np.array_equal(got[0], oracle128.bootstrap_lvl1(lin0))
+    assert np.array_equal(got[1], oracle128.bootstrap_lvl1(cts[2]))
+    br_ms, ks_ms = st.last_batch_timing()
+    assert br_ms > 0 and ks_ms == 0
+    arena.free()
+    st.destroy()
+
+
+def test_two_streams_and_wrapped_torch_stream(gpu, keys128, oracle128):
+    import torch
+
+    p = keys128.params
+    cts = client.encrypt_bits(keys128, [1, 1, 0, 1], seed=91)
+    s1 = gpu.Stream(0)
+    ts = torch.cuda.Stream()
+    s2 = gpu.Stream(0, hip_stream=ts.cuda_stream)
+    a1, a2 = gpu.Arena(3), gpu.Arena(3)
+    s1.upload(a1, 0, cts[:2])
+    s2.upload(a2, 0, cts[2:])
+    s1.gate_batch(a1, [OPS["XOR"]], [0], [1], [-1], [2])
+    s2.gate_batch(a2, [OPS["ANDNOT"]], [0], [1], [-1], [2])
+    ts.synchronize()
+    s1.sync()
+    assert s1.query() and s2.query()
+    assert np.array_equal(s1.download(a1, 2, 1)[0], oracle128.gate(OPS["XOR"], cts[0], cts[1]))
+    assert np.array_equal(s2.download(a2, 2, 1)[0], oracle128.gate(OPS["ANDNOT"], cts[2], cts[3]))
+    for a in (a1, a2):
+        a.free()
+    s1.destroy()
+    s2.destroy()
+
+
+def test_error_codes(gpu, keys128):
+    L = gpu.lib()
+    st = gpu.Stream(0)
+    arena = gpu.Arena(4)
+    i32 = lambda *v: np.array(v, dtype=np.int32)
+    with pytest.raises(gpu.IykHipError, match="unknown gate op"):
+        st.gate_batch(arena, i32(99), i32(0), i32(1), i32(-1), i32(2))
+    with pytest.raises(gpu.IykHipError, match="MUX needs three inputs"):
+        st.gate_batch(arena, i32(OPS["MUX"]), i32(0), i32(1), i32(-1), i32(2))
+    with pytest.raises(gpu.IykHipError, match="negative output slot"):
+        st.gate_batch(arena, i32(OPS["NAND"]), i32(0), i32(1), i32(-1), i32(-1))
+    assert L.iyk_hip_gate_batch(None, ctypes.c_void_p(arena.ptr), 1, None, None, None, None, None) == -1
+    assert L.iyk_hip_init(1, None, ctypes.byref(keys128.params), None, None) == -2       # already initialised
+    assert L.iyk_hip_cleanup() == -2 and b"streams still alive" in L.iyk_hip_last_error()
+    h = ctypes.c_void_p()
+    assert L.iyk_hip_stream_create(7, ctypes.byref(h)) == -1                               # gpu_index out of range
+    assert gpu.resident_key_bytes() > 100e6 and gpu.ntt_path() in ("fp50", "goldilocks")
+    arena.free()
+    st.destroy()
