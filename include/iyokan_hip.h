@@ -147,6 +147,20 @@ int iyk_hip_blind_rotate_batch(iyk_hip_stream* st, const uint32_t* d_arena, uint
                                const int32_t* ia, const int32_t* ib, const int32_t* sa,
                                const int32_t* sb, const uint32_t* off, uint32_t* d_tlwe1);
 
+/* Blind rotation only, result left as a TRLWE lvl1 (a(X) then b(X), 2N words per job at
+ * d_trlwe + job*2N).  Replaces cufhe::GateBootstrappingTLWE2TRLWElvl01NTT(cuFHETRLWElvl1&, Ctxt&, st)
+ * (/root/reference/src/iyokan_cufhe.hpp:634-635).  Same job description as iyk_hip_blind_rotate_batch. */
+int iyk_hip_bootstrap_trlwe_batch(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t count,
+                                  const int32_t* ia, const int32_t* ib, const int32_t* sa,
+                                  const int32_t* sb, const uint32_t* off, uint32_t* d_trlwe);
+
+/* Sample-extract(index 0) + identity key switch of TRLWEs into arena slots.  Replaces
+ * cufhe::SampleExtractAndKeySwitch(Ctxt&, cuFHETRLWElvl1&, st) (/root/reference/src/iyokan_cufhe.hpp:601).
+ * trlwe_index[g] selects the TRLWE (2N words each) in d_trlwe, out_slot[g] the destination slot. */
+int iyk_hip_sample_extract_keyswitch_batch(iyk_hip_stream* st, const uint32_t* d_trlwe, uint64_t count,
+                                           const int32_t* trlwe_index, const int32_t* out_slot,
+                                           uint32_t* d_arena);
+
 /* Kernel-only time of the most recent iyk_hip_gate_batch on this stream, from HIP events
  * recorded on the stream around the blind-rotate and key-switch launches (milliseconds).
  * Blocks until those events have completed. */

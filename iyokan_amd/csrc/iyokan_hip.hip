@@ -145,7 +145,7 @@ int ensure_rot(iyk_hip_stream* st, size_t jobs)
 }
 
 template <int L, int BGBIT>
-int launch_br(iyk_hip_stream* st, int njobs, u32* d_tlwe1)
+int launch_br(iyk_hip_stream* st, int njobs, u32* d_tlwe1, int trlwe)
 {
     static bool attr_set[64] = {};
     const Device& D = G.devs[st->gpu];
@@ -158,13 +158,13 @@ int launch_br(iyk_hip_stream* st, int njobs, u32* d_tlwe1)
     dim3 grid((njobs + BR_WAVES - 1) / BR_WAVES), block(64 * BR_WAVES);
     hipLaunchKernelGGL(kern, grid, block, BR_LDS_BYTES, st->s, (const u32*)st->d_abar, njobs,
                        (const u64*)D.bk_ntt, (const u64*)D.tw_fwd, (const u64*)D.tw_inv, d_tlwe1, G.p.n, G.p.mu,
-                       ABAR_STRIDE);
+                       ABAR_STRIDE, trlwe);
     HIP_TRY(hipGetLastError());
     return IYK_OK;
 }
 
 template <class DC>
-int launch_br_fp(iyk_hip_stream* st, int first, int njobs, u32* d_tlwe1)
+int launch_br_fp(iyk_hip_stream* st, int first, int njobs, u32* d_tlwe1, int trlwe)
 {
     static bool attr_set[64] = {};
     const Device& D = G.devs[st->gpu];
@@ -177,14 +177,14 @@ int launch_br_fp(iyk_hip_stream* st, int first, int njobs, u32* d_tlwe1)
     dim3 grid((njobs + BR_WAVES - 1) / BR_WAVES), block(64 * BR_WAVES);
     hipLaunchKernelGGL(kern, grid, block, BR_LDS_BYTES, st->s, (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE,
                        njobs, (const double*)D.bk_ntt, (const double*)D.tw_fwd, (const double*)D.tw_inv, D.fpc,
-                       d_tlwe1 + (size_t)first * (NTT_N + 1), G.p.n, G.p.mu, ABAR_STRIDE);
+                       d_tlwe1 + (size_t)first * (trlwe ? 2 * NTT_N : NTT_N + 1), G.p.n, G.p.mu, ABAR_STRIDE, trlwe);
     HIP_TRY(hipGetLastError());
     return IYK_OK;
 }
 
 // narrow frontiers: one rotation per workgroup of L waves (kernels.hpp, blind_rotate_fp_lat_kernel)
 template <class DC>
-int launch_br_fp_lat(iyk_hip_stream* st, int first, int njobs, u32* d_tlwe1)
+int launch_br_fp_lat(iyk_hip_stream* st, int first, int njobs, u32* d_tlwe1, int trlwe)
 {
     static bool attr_set[64] = {};
     const Device& D = G.devs[st->gpu];
@@ -198,8 +198,8 @@ int launch_br_fp_lat(iyk_hip_stream* st, int first, int njobs, u32* d_tlwe1)
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3(64 * L), lds, st->s,
                        (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE, njobs, (const double*)D.bk_ntt,
-                       (const double*)D.tw_fwd, (const double*)D.tw_inv, D.fpc, d_tlwe1 + (size_t)first * (NTT_N + 1),
-                       G.p.n, G.p.mu, ABAR_STRIDE);
+                       (const double*)D.tw_fwd, (const double*)D.tw_inv, D.fpc,
+                       d_tlwe1 + (size_t)first * (trlwe ? 2 * NTT_N : NTT_N + 1), G.p.n, G.p.mu, ABAR_STRIDE, trlwe);
     HIP_TRY(hipGetLastError());
     return IYK_OK;
 }
@@ -208,24 +208,24 @@ int launch_br_fp_lat(iyk_hip_stream* st, int first, int njobs, u32* d_tlwe1)
 // round; the one-wave-per-level kernel takes 7 ms for <= 256 and ~21 ms per 1024.  So: full 2048-rounds
 // on the former, a remainder of up to lat_threshold rotations on the latter.
 template <class DC>
-int dispatch_fp(iyk_hip_stream* st, int njobs, u32* d_tlwe1)
+int dispatch_fp(iyk_hip_stream* st, int njobs, u32* d_tlwe1, int trlwe)
 {
     int rc;
     const char* lat = std::getenv("IYK_HIP_LATENCY_KERNEL");  // "0" disables, "1" forces (A/B, tests)
     const bool force_on = lat && lat[0] == '1', force_off = lat && lat[0] == '0';
-    if (force_on) return launch_br_fp_lat<DC>(st, 0, njobs, d_tlwe1);
-    if (force_off) return launch_br_fp<DC>(st, 0, njobs, d_tlwe1);
+    if (force_on) return launch_br_fp_lat<DC>(st, 0, njobs, d_tlwe1, trlwe);
+    if (force_off) return launch_br_fp<DC>(st, 0, njobs, d_tlwe1, trlwe);
     const int round = 2048;
     const int rem = njobs % round, full = njobs - rem;
-    if (rem > G.lat_threshold) return launch_br_fp<DC>(st, 0, njobs, d_tlwe1);
-    if (full && (rc = launch_br_fp<DC>(st, 0, full, d_tlwe1))) return rc;
-    if (rem) return launch_br_fp_lat<DC>(st, full, rem, d_tlwe1);
+    if (rem > G.lat_threshold) return launch_br_fp<DC>(st, 0, njobs, d_tlwe1, trlwe);
+    if (full && (rc = launch_br_fp<DC>(st, 0, full, d_tlwe1, trlwe))) return rc;
+    if (rem) return launch_br_fp_lat<DC>(st, full, rem, d_tlwe1, trlwe);
     return IYK_OK;
 }
 
 // mod-switch every job into st->d_abar, then one wavefront per job
 int launch_blind_rotate(iyk_hip_stream* st, const u32* d_arena, const RotJob* d_jobs, int njobs,
-                        u32* d_tlwe1)
+                        u32* d_tlwe1, int trlwe = 0)
 {
     const iyk_params& p = G.p;
     int rc = ensure_rot(st, (size_t)njobs);
@@ -234,11 +234,11 @@ int launch_blind_rotate(iyk_hip_stream* st, const u32* d_arena, const RotJob* d_
                        ABAR_STRIDE);
     HIP_TRY(hipGetLastError());
     if (G.use_fp) {
-        if (p.l == 3) return dispatch_fp<fp::Decomp<3, 6, 1>>(st, njobs, d_tlwe1);
-        return dispatch_fp<fp::Decomp<2, 10, 2>>(st, njobs, d_tlwe1);
+        if (p.l == 3) return dispatch_fp<fp::Decomp<3, 6, 1>>(st, njobs, d_tlwe1, trlwe);
+        return dispatch_fp<fp::Decomp<2, 10, 2>>(st, njobs, d_tlwe1, trlwe);
     }
-    if (p.l == 3 && p.Bgbit == 6) return launch_br<3, 6>(st, njobs, d_tlwe1);
-    if (p.l == 2 && p.Bgbit == 10) return launch_br<2, 10>(st, njobs, d_tlwe1);
+    if (p.l == 3 && p.Bgbit == 6) return launch_br<3, 6>(st, njobs, d_tlwe1, trlwe);
+    if (p.l == 2 && p.Bgbit == 10) return launch_br<2, 10>(st, njobs, d_tlwe1, trlwe);
     return fail(IYK_ERR_INVALID, "unsupported (l, Bgbit)");
 }
 
@@ -655,12 +655,13 @@ int iyk_hip_gate_host(iyk_hip_stream* st, int op, const uint32_t* in0, const uin
     return IYK_OK;
 }
 
-int iyk_hip_blind_rotate_batch(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t count, const int32_t* ia,
-                               const int32_t* ib, const int32_t* sa, const int32_t* sb, const uint32_t* off,
-                               uint32_t* d_tlwe1)
+// shared body of the two rotation-only entry points
+static int rotate_only(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t count, const int32_t* ia,
+                       const int32_t* ib, const int32_t* sa, const int32_t* sb, const uint32_t* off, uint32_t* d_out,
+                       int trlwe)
 {
     if (!G.init) return fail(IYK_ERR_STATE, "not initialised");
-    if (!st || !d_arena || !d_tlwe1 || !ia || !ib || !sa || !sb || !off) return fail(IYK_ERR_INVALID, "null argument");
+    if (!st || !d_arena || !d_out || !ia || !ib || !sa || !sb || !off) return fail(IYK_ERR_INVALID, "null argument");
     if (count == 0) return IYK_OK;
     int rc = set_device(st->gpu);
     if (rc) return rc;
@@ -673,11 +674,53 @@ int iyk_hip_blind_rotate_batch(iyk_hip_stream* st, const uint32_t* d_arena, uint
     HIP_TRY(hipMemcpyAsync(st->d_stage + soff, st->h_stage + soff, bytes, hipMemcpyHostToDevice, st->s));
     if ((rc = release_stage(st))) return rc;
     HIP_TRY(hipEventRecord(st->ev_br0, st->s));
-    if ((rc = launch_blind_rotate(st, d_arena, (const RotJob*)(st->d_stage + soff), (int)count, d_tlwe1))) return rc;
+    if ((rc = launch_blind_rotate(st, d_arena, (const RotJob*)(st->d_stage + soff), (int)count, d_out, trlwe))) return rc;
     HIP_TRY(hipEventRecord(st->ev_br1, st->s));
     st->timing_valid = true;
     st->timing_has_ks = false;
     return IYK_OK;
+}
+
+int iyk_hip_blind_rotate_batch(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t count, const int32_t* ia,
+                               const int32_t* ib, const int32_t* sa, const int32_t* sb, const uint32_t* off,
+                               uint32_t* d_tlwe1)
+{
+    return rotate_only(st, d_arena, count, ia, ib, sa, sb, off, d_tlwe1, 0);
+}
+
+int iyk_hip_bootstrap_trlwe_batch(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t count, const int32_t* ia,
+                                  const int32_t* ib, const int32_t* sa, const int32_t* sb, const uint32_t* off,
+                                  uint32_t* d_trlwe)
+{
+    return rotate_only(st, d_arena, count, ia, ib, sa, sb, off, d_trlwe, 1);
+}
+
+int iyk_hip_sample_extract_keyswitch_batch(iyk_hip_stream* st, const uint32_t* d_trlwe, uint64_t count,
+                                           const int32_t* trlwe_index, const int32_t* out_slot, uint32_t* d_arena)
+{
+    if (!G.init) return fail(IYK_ERR_STATE, "not initialised");
+    if (!st || !d_trlwe || !trlwe_index || !out_slot || !d_arena) return fail(IYK_ERR_INVALID, "null argument");
+    if (count == 0) return IYK_OK;
+    int rc = set_device(st->gpu);
+    if (rc) return rc;
+    std::vector<KsJob> ks(count);
+    for (uint64_t g = 0; g < count; ++g) {
+        if (trlwe_index[g] < 0 || out_slot[g] < 0) return fail(IYK_ERR_INVALID, "negative index");
+        ks[g] = KsJob{(int32_t)g, -1, 0u, out_slot[g]};
+    }
+    const size_t ks_bytes = ks.size() * sizeof(KsJob), idx_off = (ks_bytes + 15) & ~(size_t)15;
+    const size_t total = idx_off + count * sizeof(int32_t);
+    size_t soff = 0;
+    if ((rc = acquire_stage(st, total, &soff))) return rc;
+    if ((rc = ensure_rot(st, count))) return rc;
+    std::memcpy(st->h_stage + soff, ks.data(), ks_bytes);
+    std::memcpy(st->h_stage + soff + idx_off, trlwe_index, count * sizeof(int32_t));
+    HIP_TRY(hipMemcpyAsync(st->d_stage + soff, st->h_stage + soff, total, hipMemcpyHostToDevice, st->s));
+    if ((rc = release_stage(st))) return rc;
+    hipLaunchKernelGGL(sample_extract_kernel, dim3((unsigned)count), dim3(256), 0, st->s, d_trlwe,
+                       (const int32_t*)(st->d_stage + soff + idx_off), st->d_rot);
+    HIP_TRY(hipGetLastError());
+    return launch_keyswitch(st, d_arena, (const KsJob*)(st->d_stage + soff), (int)count);
 }
 
 int iyk_hip_last_batch_timing(iyk_hip_stream* st, float* blind_rotate_ms, float* keyswitch_ms)

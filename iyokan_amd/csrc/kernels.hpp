@@ -113,7 +113,7 @@ template <int L, int BGBIT>
 __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_kernel(
     const u32* __restrict__ abar_all, int njobs, const u64* __restrict__ bk_ntt,
     const u64* __restrict__ tw_fwd, const u64* __restrict__ tw_inv, u32* __restrict__ tlwe1_out, u32 n,
-    u32 mu, u32 abar_stride)
+    u32 mu, u32 abar_stride, int trlwe_mode)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* s_twf = reinterpret_cast<u64*>(smem);            // [k2][j1]
@@ -232,9 +232,15 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_kernel(
 
     // sample extract at index 0 -> TLWE lvl1: a'[0] = a[0], a'[j] = -a[N-j], b' = b[0]
     if (live) {
-        u32* out = tlwe1_out + (size_t)job * (NTT_N + 1);
-        for (int j = lane; j < NTT_N; j += 64) out[j] = (j == 0) ? acc_lds[0] : 0u - acc_lds[NTT_N - j];
-        if (lane == 0) out[NTT_N] = acc_lds[NTT_N];
+        if (trlwe_mode) {  // raw accumulator: TRLWE (a(X), b(X)), 2N words per job
+            u32* out = tlwe1_out + (size_t)job * (2 * NTT_N);
+            for (int j = lane; j < 2 * NTT_N; j += 64) out[j] = acc_lds[j];
+        }
+        else {
+            u32* out = tlwe1_out + (size_t)job * (NTT_N + 1);
+            for (int j = lane; j < NTT_N; j += 64) out[j] = (j == 0) ? acc_lds[0] : 0u - acc_lds[NTT_N - j];
+            if (lane == 0) out[NTT_N] = acc_lds[NTT_N];
+        }
     }
 }
 
@@ -288,7 +294,7 @@ template <class D>
 __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
     const u32* __restrict__ abar_all, int njobs, const double* __restrict__ bk_ntt,
     const double* __restrict__ tw_fwd, const double* __restrict__ tw_inv, const fp::NttConsts* __restrict__ Cp,
-    u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride)
+    u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride, int trlwe_mode)
 {
     // twist / 32-point twiddle constants are read with scalar loads where they are used: held by value
     // they overflow the SGPR file and come back through v_readlane (a VALU op per 32 bits)
@@ -410,9 +416,15 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
     }
 
     if (live) {
-        u32* out = tlwe1_out + (size_t)job * (NTT_N + 1);
-        for (int j = lane; j < NTT_N; j += 64) out[j] = (j == 0) ? acc_lds[0] : 0u - acc_lds[NTT_N - j];
-        if (lane == 0) out[NTT_N] = acc_lds[NTT_N];
+        if (trlwe_mode) {  // raw accumulator: TRLWE (a(X), b(X)), 2N words per job
+            u32* out = tlwe1_out + (size_t)job * (2 * NTT_N);
+            for (int j = lane; j < 2 * NTT_N; j += 64) out[j] = acc_lds[j];
+        }
+        else {
+            u32* out = tlwe1_out + (size_t)job * (NTT_N + 1);
+            for (int j = lane; j < NTT_N; j += 64) out[j] = (j == 0) ? acc_lds[0] : 0u - acc_lds[NTT_N - j];
+            if (lane == 0) out[NTT_N] = acc_lds[NTT_N];
+        }
     }
 }
 
@@ -434,7 +446,7 @@ template <class D>
 __global__ __launch_bounds__(64 * D::LV) void blind_rotate_fp_lat_kernel(
     const u32* __restrict__ abar_all, int njobs, const double* __restrict__ bk_ntt,
     const double* __restrict__ tw_fwd, const double* __restrict__ tw_inv, const fp::NttConsts* __restrict__ Cp,
-    u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride)
+    u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride, int trlwe_mode)
 {
     const fp::NttConsts& C = *Cp;
     constexpr int L = D::LV;  // one wavefront per (virtual) gadget level
@@ -550,10 +562,29 @@ __global__ __launch_bounds__(64 * D::LV) void blind_rotate_fp_lat_kernel(
     }
 
     if (wave == 0) {
-        u32* out = tlwe1_out + (size_t)job * (NTT_N + 1);
-        for (int j = lane; j < NTT_N; j += 64) out[j] = (j == 0) ? acc_lds[0] : 0u - acc_lds[NTT_N - j];
-        if (lane == 0) out[NTT_N] = acc_lds[NTT_N];
+        if (trlwe_mode) {  // raw accumulator: TRLWE (a(X), b(X)), 2N words per job
+            u32* out = tlwe1_out + (size_t)job * (2 * NTT_N);
+            for (int j = lane; j < 2 * NTT_N; j += 64) out[j] = acc_lds[j];
+        }
+        else {
+            u32* out = tlwe1_out + (size_t)job * (NTT_N + 1);
+            for (int j = lane; j < NTT_N; j += 64) out[j] = (j == 0) ? acc_lds[0] : 0u - acc_lds[NTT_N - j];
+            if (lane == 0) out[NTT_N] = acc_lds[NTT_N];
+        }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// TRLWE -> TLWE lvl1 at index 0 (TFHEpp SampleExtractIndex(., 0)): a'[0] = a[0], a'[j] = -a[N-j], b' = b[0].
+// src_index[job] selects the TRLWE; rows of N+1 words are written to `rot` for the key switch.
+__global__ __launch_bounds__(256) void sample_extract_kernel(const u32* __restrict__ trlwe,
+                                                             const int32_t* __restrict__ src_index,
+                                                             u32* __restrict__ rot)
+{
+    const u32* in = trlwe + (size_t)src_index[blockIdx.x] * (2 * NTT_N);
+    u32* out = rot + (size_t)blockIdx.x * (NTT_N + 1);
+    for (int j = threadIdx.x; j < NTT_N; j += 256) out[j] = (j == 0) ? in[0] : 0u - in[NTT_N - j];
+    if (threadIdx.x == 0) out[NTT_N] = in[NTT_N];
 }
 
 // ------------------------------------------------------------------------------------------

@@ -29,6 +29,7 @@ EXPORTS = [
     "iyk_hip_arena_upload", "iyk_hip_arena_download", "iyk_hip_gate_batch", "iyk_hip_gate_host",
     "iyk_hip_blind_rotate_batch", "iyk_hip_last_batch_timing", "iyk_hip_resident_key_bytes",
     "iyk_hip_timing_log_begin", "iyk_hip_timing_log_end", "iyk_hip_ntt_path",
+    "iyk_hip_bootstrap_trlwe_batch", "iyk_hip_sample_extract_keyswitch_batch",
 ]
 
 
@@ -63,6 +64,8 @@ def lib():
         L.iyk_hip_gate_batch.argtypes = [_vp, _vp, ctypes.c_uint64, _i32p, _i32p, _i32p, _i32p, _i32p]
         L.iyk_hip_gate_host.argtypes = [_vp, ctypes.c_int, _u32p, _u32p, _u32p, _u32p]
         L.iyk_hip_blind_rotate_batch.argtypes = [_vp, _vp, ctypes.c_uint64, _i32p, _i32p, _i32p, _i32p, _u32p, _vp]
+        L.iyk_hip_bootstrap_trlwe_batch.argtypes = [_vp, _vp, ctypes.c_uint64, _i32p, _i32p, _i32p, _i32p, _u32p, _vp]
+        L.iyk_hip_sample_extract_keyswitch_batch.argtypes = [_vp, _vp, ctypes.c_uint64, _i32p, _i32p, _vp]
         L.iyk_hip_last_batch_timing.argtypes = [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
         L.iyk_hip_resident_key_bytes.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
         L.iyk_hip_timing_log_begin.argtypes = [_vp]
@@ -215,6 +218,22 @@ class Stream:
         _check(lib().iyk_hip_blind_rotate_batch(self.h, arena.ptr, len(ia), p(ia), p(ib), p(sa), p(sb),
                                                 off.ctypes.data_as(_u32p), _vp(int(d_tlwe1_ptr))),
                "iyk_hip_blind_rotate_batch")
+
+    def bootstrap_trlwe_batch(self, arena, ia, ib, sa, sb, off, d_trlwe_ptr):
+        """GateBootstrappingTLWE2TRLWElvl01NTT shape: rotation only, TRLWE (2N words) per job."""
+        ia, ib, sa, sb = map(_i32, (ia, ib, sa, sb))
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        p = lambda a: a.ctypes.data_as(_i32p)
+        _check(lib().iyk_hip_bootstrap_trlwe_batch(self.h, arena.ptr, len(ia), p(ia), p(ib), p(sa), p(sb),
+                                                   off.ctypes.data_as(_u32p), _vp(int(d_trlwe_ptr))),
+               "iyk_hip_bootstrap_trlwe_batch")
+
+    def sample_extract_keyswitch_batch(self, d_trlwe_ptr, trlwe_index, out_slot, arena):
+        """SampleExtractAndKeySwitch shape: TRLWE -> TLWE lvl0 into arena slots."""
+        ti, os_ = _i32(trlwe_index), _i32(out_slot)
+        p = lambda a: a.ctypes.data_as(_i32p)
+        _check(lib().iyk_hip_sample_extract_keyswitch_batch(self.h, _vp(int(d_trlwe_ptr)), len(ti), p(ti), p(os_),
+                                                            arena.ptr), "iyk_hip_sample_extract_keyswitch_batch")
 
     def last_batch_timing(self):
         """(blind_rotate_ms, keyswitch_ms) of the most recent batch, from HIP events on this stream."""

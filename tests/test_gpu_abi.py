@@ -63,6 +63,37 @@ def test_blind_rotate_batch_matches_oracle_lvl1(gpu, keys128, oracle128):
     st.destroy()
 
 
+def test_trlwe_bootstrap_then_extract_keyswitch(gpu, keys128, oracle128):
+    """cufhe::GateBootstrappingTLWE2TRLWElvl01NTT + cufhe::SampleExtractAndKeySwitch shapes: the two halves
+    of a gate, composed, must equal the fused gate and the oracle's intermediate TRLWE."""
+    import ctypes as C
+
+    import oracle_lib
+    import torch
+
+    st = gpu.Stream(0)
+    p = keys128.params
+    cts = client.encrypt_bits(keys128, [1, 1], seed=95)
+    arena = gpu.Arena(4)
+    st.upload(arena, 0, cts)
+    trlwe = torch.zeros((1, 2 * p.N), dtype=torch.int32, device="cuda")
+    st.bootstrap_trlwe_batch(arena, [0], [1], [-1], [-1], [np.uint32(p.mu)], trlwe.data_ptr())
+    st.sample_extract_keyswitch_batch(trlwe.data_ptr(), [0], [2], arena)
+    st.gate_batch(arena, [OPS["NAND"]], [0], [1], [-1], [3])
+    st.sync()
+    got = st.download(arena, 2, 2)
+    assert np.array_equal(got[0], got[1])
+    assert np.array_equal(got[0], oracle128.gate(OPS["NAND"], cts[0], cts[1]))
+    lin = (np.uint32(0) - cts[0] - cts[1]).astype(np.uint32)
+    lin[-1] = np.uint32((int(lin[-1]) + p.mu) & 0xFFFFFFFF)
+    acc = np.zeros(2 * p.N, dtype=np.uint32)
+    u32p = C.POINTER(C.c_uint32)
+    oracle_lib.lib().orc_blind_rotate(oracle128.ctx, lin.ctypes.data_as(u32p), acc.ctypes.data_as(u32p), 0)
+    assert np.array_equal(trlwe.cpu().numpy().view(np.uint32)[0], acc)
+    arena.free()
+    st.destroy()
+
+
 def test_two_streams_and_wrapped_torch_stream(gpu, keys128, oracle128):
     import torch
 
