@@ -1,4 +1,5 @@
-// blind_rotate_core.hpp — per-lane phases of one CMUX step of the blind rotation (v3).
+// blind_rotate_core.hpp — per-lane phases of one CMUX step of the blind rotation, 64-bit integer
+// (Goldilocks) field; also the lane / LDS layout shared with the FP64 path (blind_rotate_fp.hpp).
 //
 // One 64-lane wavefront owns one rotation job.  Lane = (h, t): h = lane >> 5 selects the
 // TRLWE polynomial (h = 0: mask a(X), h = 1: body b(X)), t = lane & 31 is the column of the
@@ -15,10 +16,9 @@
 // CMUXFFTwithPolynomialMulByXaiMinusOne on the CPU path (/root/reference/src/iyokan_tfhepp.hpp:131-141).
 //
 // Per-lane registers: x[32] (u64, the pass being transformed), accum[32] (u64, NTT-domain sum
-// over gadget rows for output polynomial h, natural k1 order).  v2 also kept the TRLWE
-// accumulator and (X^abar - 1) acc in registers and spilled; v3 keeps the accumulator in LDS
-// (paying for the room with 32-bit (lo, hi) transposes) and re-derives the rotated difference
-// per gadget level.
+// over gadget rows for output polynomial h, natural k1 order).  The TRLWE accumulator lives in
+// LDS (the room is paid for with 32-bit (lo, hi) transposes) and the rotated difference is
+// re-derived per gadget level: keeping either in registers spills (measured: DESIGN.md §6).
 // Per-wave LDS (u32 words):  acc[2][1024]  +  xb[2][XB_WORDS32]
 //   xb is used three ways: u32 transpose matrix [32][33]; u64 share chunk [16][32]; nothing else.
 // Per-workgroup LDS: twiddle tables, transposed so lane t reads tw[row][t] conflict-free.

@@ -1,9 +1,11 @@
 // iyokan_hip.hip — implementation of the C ABI in include/iyokan_hip.h (libiyokan_hip.so).
 //
 // Host side of the MI355X backend: owns device-resident keys (NTT-domain BK, padded KSK,
-// twiddle tables) per GPU, streams with their staging buffers, and turns a batch of gate
-// descriptors into three launches: elementwise (NOT/COPY/CONST), blind_rotate (one wave per
-// rotation), keyswitch (one workgroup per gate).  Replaces the cuFHE host API used at
+// twiddle tables) per GPU, streams with their (double-buffered) staging buffers, and turns a batch of
+// gate descriptors into a fixed launch sequence: elementwise (NOT/COPY/CONST), modswitch, blind rotation
+// (wave-per-rotation kernel for full rounds of 2048 + 3-wave kernel for the remainder), keyswitch_init +
+// keyswitch.  Chooses the exact-arithmetic field at init (FP64 p = 2^50-16383 where its bound holds,
+// else / on request the 64-bit Goldilocks integers).  Replaces the cuFHE host API used at
 // /root/reference/src/iyokan_cufhe.cpp:530-536,721 and /root/reference/src/iyokan_cufhe.hpp:8-27,249-261.
 #include <hip/hip_runtime.h>
 

@@ -1,12 +1,13 @@
 // kernels.hpp — HIP kernels of the gate-bootstrapping hot path for gfx950 (MI355X).
 //
-//   bk_ntt_kernel        init: torus-domain BK polynomial -> NTT domain (once per GPU)
-//   modswitch_kernel     linear step + mod-switch of every rotation job -> abar[job][n+1]
-//   blind_rotate_kernel  one wavefront per rotation job: n CMUX steps
-//                        (blind_rotate_core.hpp), sample-extract -> TLWE lvl1
-//   bk_ntt_fp_kernel / blind_rotate_fp_kernel   the same two on the FP64 path (fp50.hpp), default for the 128-bit set
-//   keyswitch_kernel     one workgroup per gate: lvl1 -> lvl0 identity key switch
-//   elementwise_kernel   NOT / COPY / CONSTONE / CONSTZERO on arena slots
+//   init        bk_ntt_fp_kernel / bk_ntt_kernel     torus-domain BK rows -> NTT domain (once per GPU)
+//   per batch   modswitch_kernel                      linear step + mod-switch of every rotation -> abar[job][n+1]
+//               blind_rotate_fp_kernel<Decomp>        one wavefront per rotation, FP64 field (fp50.hpp): default
+//               blind_rotate_fp_lat_kernel<Decomp>    one rotation per workgroup of LV wavefronts: narrow frontiers
+//               blind_rotate_kernel<L,BGBIT>          one wavefront per rotation, Goldilocks integers (IYK_HIP_NTT=goldilocks)
+//               sample_extract_kernel                 TRLWE -> TLWE lvl1 (CMUX-memory helper entry point only)
+//               keyswitch_init_kernel + keyswitch_kernel   lvl1 -> lvl0 identity key switch, 16 gates per workgroup
+//               elementwise_kernel                    NOT / COPY / CONSTONE / CONSTZERO on arena slots
 //
 // Replaces cufhe's device code behind cufhe::Initialize and cufhe::{And..Mux,Not}<lvl0param>
 // (/root/reference/src/iyokan_cufhe.cpp:530-536, /root/reference/src/iyokan_cufhe.hpp:249-261).

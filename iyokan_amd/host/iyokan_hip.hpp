@@ -17,7 +17,7 @@
 //    Mem::set/get (INPUT / OUTPUT / RAM / ROM cells) cross PCIe.  The reference copies both
 //    inputs host->device and the output device->host for every single gate (:217-222,238-241).
 //  * One BATCHING worker replaces hundreds of one-gate workers: HIPWorker::update() drains the
-//    whole ready frontier into ONE iyk_hip_gate_batch (3 kernel launches) and propagates the
+//    whole ready frontier into ONE iyk_hip_gate_batch (a handful of kernel launches) and propagates the
 //    frontier when its stream goes idle.  The reference issues one fused kernel per gate on
 //    800 streams and polls each with StreamQuery.
 //  * Status codes: every C-ABI failure is mapped to die() = the reference's error::die.
