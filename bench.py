@@ -57,6 +57,29 @@ def traffic_bytes(args, gates):
     return None
 
 
+def broadcast_keys(keys, dist, device, rank):
+    """Key material is generated on rank 0 only and broadcast once (RCCL over xGMI on the GPU box; the
+    reference instead replicates keys by a per-device cudaMemcpy loop inside cufhe::Initialize).  Works
+    on any torch device so the same code is exercised by the gloo CPU test (tests/test_bench_dist.py)."""
+    import torch
+
+    for name in ("s0", "s1", "bk", "ksk"):
+        host = getattr(keys, name)
+        t = torch.from_numpy(host.view(np.int32)).to(device)
+        dist.broadcast(t, src=0)
+        if rank != 0:
+            setattr(keys, name, t.cpu().numpy().view(np.uint32).copy())
+        del t
+    return keys
+
+
+def empty_keys(params):
+    from iyokan_amd import client
+
+    return client.KeySet(params, np.zeros(params.n, np.uint32), np.zeros(params.N, np.uint32),
+                         np.zeros(params.bk_words, np.uint32), np.zeros(params.ksk_words, np.uint32))
+
+
 def cpu_baseline(keys, params, op_code, sample, data_seed, budget_s=15.0):
     """Oracle (kind 'port') timed on this host's cores on a bounded sample of the same workload.
 
@@ -126,17 +149,9 @@ def main():
     G = args.gates
 
     # ---- keys: rank 0 generates, RCCL broadcast (north_star: "bootstrapping key broadcast once") ----
-    if rank == 0:
-        keys = client.keygen(params, seed=1)
-    else:
-        keys = client.KeySet(params, np.zeros(params.n, np.uint32), np.zeros(params.N, np.uint32),
-                             np.zeros(params.bk_words, np.uint32), np.zeros(params.ksk_words, np.uint32))
+    keys = client.keygen(params, seed=1) if rank == 0 else empty_keys(params)
     if world > 1:
-        for name in ("s0", "s1", "bk", "ksk"):
-            t = torch.from_numpy(getattr(keys, name).view(np.int32)).to(dev)
-            dist.broadcast(t, src=0)
-            setattr(keys, name, t.cpu().numpy().view(np.uint32))
-            del t
+        keys = broadcast_keys(keys, dist, dev, rank)
     hip.initialize(keys, device_ids=(local_rank,))
 
     # ---- synthetic inputs: 2G fresh encryptions per rank (distinct data seed per rank) ----

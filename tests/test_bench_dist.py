@@ -1,0 +1,49 @@
+"""bench.py's N > 1 plumbing on CPU (gloo, world_size 2): rank 0 generates the key set, every other
+rank receives identical key material through broadcast_keys; the per-rank work split of a flat batch
+needs no collective (each rank owns `--gates` gates), so equality of keys is the whole contract."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    import bench
+    from iyokan_amd import client
+    from iyokan_amd.params import params_80bit
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = params_80bit()
+        keys = client.keygen(p, seed=1) if rank == 0 else bench.empty_keys(p)
+        keys = bench.broadcast_keys(keys, dist, torch.device("cpu"), rank)
+        h = hashlib.sha256()
+        for name in ("s0", "s1", "bk", "ksk"):
+            h.update(np.ascontiguousarray(getattr(keys, name)).tobytes())
+        q.put((rank, h.hexdigest(), int(keys.bk.any())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_key_broadcast_two_ranks_gloo():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=10) for _ in range(2))
+    assert got[0][1] == got[1][1] and got[1][2] == 1
