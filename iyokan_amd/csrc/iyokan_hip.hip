@@ -246,14 +246,16 @@ int launch_blind_rotate(iyk_hip_stream* st, const u32* d_arena, const RotJob* d_
 
 // Key switch: init outputs to (0,..,0,b'), then KS_G gates per workgroup, i range sliced so that at
 // least ~2 workgroups per CU exist even for small frontiers (slices combine by integer atomics).
-int launch_keyswitch(iyk_hip_stream* st, u32* d_arena, const KsJob* d_jobs, int njobs)
+template <int T>
+int launch_keyswitch_t(iyk_hip_stream* st, u32* d_arena, const KsJob* d_jobs, int njobs)
 {
     const Device& D = G.devs[st->gpu];
     const iyk_params& p = G.p;
     static bool attr_set[64] = {};
+    auto kern = keyswitch_kernel<T>;
     if (!attr_set[st->gpu]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(keyswitch_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, KS_G * NTT_N * 2));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    KS_G * NTT_N * 2));
         attr_set[st->gpu] = true;
     }
     hipLaunchKernelGGL(keyswitch_init_kernel, dim3((unsigned)njobs), dim3(KS_THREADS), 0, st->s,
@@ -263,11 +265,20 @@ int launch_keyswitch(iyk_hip_stream* st, u32* d_arena, const KsJob* d_jobs, int 
     int slices = 1;
     while (slices < 64 && groups * slices < 512) slices *= 2;
     const u32 i_per_slice = (u32)NTT_N / (u32)slices;
-    hipLaunchKernelGGL(keyswitch_kernel, dim3((unsigned)groups, (unsigned)slices), dim3(KS_THREADS),
+    hipLaunchKernelGGL(kern, dim3((unsigned)groups, (unsigned)slices), dim3(KS_THREADS),
                        (size_t)KS_G * i_per_slice * 2, st->s, (const u32*)st->d_rot, d_jobs, njobs,
-                       (const u32*)D.ksk, d_arena, p.n, p.t, G.ksk_stride, i_per_slice);
+                       (const u32*)D.ksk, d_arena, p.n, G.ksk_stride, i_per_slice);
     HIP_TRY(hipGetLastError());
     return IYK_OK;
+}
+int launch_keyswitch(iyk_hip_stream* st, u32* d_arena, const KsJob* d_jobs, int njobs)
+{
+    switch (G.p.t) {
+    case 7: return launch_keyswitch_t<7>(st, d_arena, d_jobs, njobs);
+    case 8: return launch_keyswitch_t<8>(st, d_arena, d_jobs, njobs);
+    case 5: return launch_keyswitch_t<5>(st, d_arena, d_jobs, njobs);
+    default: return fail(IYK_ERR_INVALID, "key-switch kernel is instantiated for t in {5, 7, 8}");
+    }
 }
 
 // linear-step coefficients of TFHEpp HomGate (SURVEY.md §8 a-ext)
@@ -325,7 +336,8 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
     if (!((p.l == 3 && p.Bgbit == 6) || (p.l == 2 && p.Bgbit == 10)))
         return fail(IYK_ERR_INVALID, "supported (l, Bgbit): (3, 6) [128-bit], (2, 10) [80-bit]");
 
-    if (p.basebit != 2 || p.t == 0 || p.t > 8) return fail(IYK_ERR_INVALID, "key-switch kernel requires basebit == 2, t <= 8");
+    if (p.basebit != 2 || !(p.t == 5 || p.t == 7 || p.t == 8))
+        return fail(IYK_ERR_INVALID, "key-switch kernel requires basebit == 2 and t in {5, 7, 8}");
     if (((p.n + 1 + 3u) & ~3u) > 3 * KS_THREADS || p.n + 1 <= KS_THREADS)
         return fail(IYK_ERR_INVALID, "key-switch kernel requires 256 < n + 1 <= 768");
     int avail = 0;

@@ -613,10 +613,12 @@ __global__ __launch_bounds__(KS_THREADS) void keyswitch_init_kernel(const u32* _
     for (u32 w = threadIdx.x; w <= n; w += KS_THREADS) out[w] = (w == n) ? bval : 0u;
 }
 
+template <int T>  // T = number of key-switch digits t (compile time: all T row-triples of one i are loaded up front)
 __global__ __launch_bounds__(KS_THREADS) void keyswitch_kernel(
     const u32* __restrict__ rot, const KsJob* __restrict__ jobs, int njobs, const u32* __restrict__ ksk,
-    u32* __restrict__ arena, u32 n, u32 t_digits, u32 row_stride, u32 i_per_slice)
+    u32* __restrict__ arena, u32 n, u32 row_stride, u32 i_per_slice)
 {
+    constexpr u32 t_digits = T;
     extern __shared__ unsigned short s_dig[];  // [KS_G][i_per_slice]: the t 2-bit digits of a'_i, MSB first
     const int g0 = blockIdx.x * KS_G;
     const u32 i0 = blockIdx.y * i_per_slice;
@@ -645,20 +647,27 @@ __global__ __launch_bounds__(KS_THREADS) void keyswitch_kernel(
 #pragma unroll
         for (int g = 0; g < KS_G; ++g) dg[g] = __builtin_amdgcn_readfirstlane((u32)s_dig[g * i_per_slice + ii]);
         const u32* rows = ksk + (size_t)(i0 + ii) * t_digits * 3 * row_stride;
-#pragma unroll 1
-        for (u32 j = 0; j < t_digits; ++j, rows += 3 * (size_t)row_stride) {
-            const u32 r10 = rows[w0], r11 = a1 ? rows[w1] : 0u, r12 = a2 ? rows[w2] : 0u;
-            const u32 r20 = rows[row_stride + w0], r21 = a1 ? rows[row_stride + w1] : 0u,
-                      r22 = a2 ? rows[row_stride + w2] : 0u;
-            const u32 r30 = rows[2 * row_stride + w0], r31 = a1 ? rows[2 * row_stride + w1] : 0u,
-                      r32 = a2 ? rows[2 * row_stride + w2] : 0u;
+        // all T x 3 rows of this i in flight at once (memory-level parallelism: the kernel is latency-bound)
+        u32 r[T][3][3];
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const u32* row = rows + (size_t)(j * 3 + v) * row_stride;
+                r[j][v][0] = row[w0];
+                r[j][v][1] = a1 ? row[w1] : 0u;
+                r[j][v][2] = a2 ? row[w2] : 0u;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
             const u32 sh = 2u * (t_digits - 1 - j);
 #pragma unroll
             for (int g = 0; g < KS_G; ++g) {
                 const u32 v = (dg[g] >> sh) & 3u;  // scalar: uniform branch
-                if (v == 1) { acc[g][0] += r10; acc[g][1] += r11; acc[g][2] += r12; }
-                else if (v == 2) { acc[g][0] += r20; acc[g][1] += r21; acc[g][2] += r22; }
-                else if (v == 3) { acc[g][0] += r30; acc[g][1] += r31; acc[g][2] += r32; }
+                if (v == 1) { acc[g][0] += r[j][0][0]; acc[g][1] += r[j][0][1]; acc[g][2] += r[j][0][2]; }
+                else if (v == 2) { acc[g][0] += r[j][1][0]; acc[g][1] += r[j][1][1]; acc[g][2] += r[j][1][2]; }
+                else if (v == 3) { acc[g][0] += r[j][2][0]; acc[g][1] += r[j][2][1]; acc[g][2] += r[j][2][2]; }
             }
         }
     }
