@@ -52,12 +52,16 @@ def test_rom_generator_shape():
     assert rom.counts()["MUX"] == 4064 and len(rom.rom) == 4096 and len(rom.levelise()) == 7
 
 
-def test_cahp_ruby_system_matches_test09():
-    sysm = load_cahp()
+import pytest
+
+
+@pytest.mark.parametrize("core,rot", [("ruby", 4281), ("pearl", 3662)])
+def test_cahp_system_matches_test09(core, rot):
+    sysm = load_blueprint(os.path.join(GOLD, f"cahp-{core}-mux.toml"))
     nl = sysm.nl
-    assert nl.rotations() == 4281 + 8128 + 18985     # core + ROM + RAM (~31 394)
+    assert nl.rotations() == rot + 8128 + 18985     # core + ROM + RAM
     req = load_packet(os.path.join(GOLD, "test09.in"))
-    want = load_packet(os.path.join(GOLD, "test09-ruby.out"))
+    want = load_packet(os.path.join(GOLD, f"test09-{core}.out"))
     sim = run_system_plain(sysm, req, want["cycles"])
     for entry in want["bits"]:
         name, size = entry["name"], entry["size"]
