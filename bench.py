@@ -200,6 +200,7 @@ def main():
     decrypt_ok = bool(np.array_equal(client.decrypt_bits(keys, got), want))
 
     if rank == 0:
+        fp_path = hip.ntt_path() == "fp50"
         gates_total = G * args.steps * world
         value = gates_total / elapsed
         b_gate = params.gate_algorithmic_bytes(rotations=1, inputs=2)
@@ -220,7 +221,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32 torus; NTT in u64 mod 2^64-2^32+1",
+            "dtype": ("u32 torus; NTT in f64 mod 2^50-16383 (exact FMA arithmetic)" if fp_path
+                      else "u32 torus; NTT in u64 mod 2^64-2^32+1"),
             "data": "synthetic",
             "config": {
                 "workload": f"{G} independent Hom{args.op} gates per GPU per step (flat DAG), {args.params} params, "
@@ -232,7 +234,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "blind_rotate_kernel",
+                "kernel": "blind_rotate_fp_kernel" if fp_path else "blind_rotate_kernel",
                 "achieved": achieved / 1e9,
                 "peak": HBM_PEAK_BYTES_PER_S / 1e9,
                 "unit": "GB/s",

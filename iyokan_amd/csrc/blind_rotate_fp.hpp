@@ -84,10 +84,41 @@ IYK_HD void xpose_write(int t, const double (&x)[32], u32* xb, bool hi)
         xb[xpose_row<INV>(p) * XB_STRIDE + t] = hi ? (u32)(b >> 32) : (u32)b;
     }
 }
+// Row t of the u32 transpose matrix -> 32 registers.  On the device these are 32 single ds_read_b32
+// issued from inline assembly on purpose: left to the compiler, adjacent words are paired into
+// ds_read2_b32, whose two results must land in CONSECUTIVE registers — but word j is one half of
+// double j, so every pair then costs v_mov's to untangle (96 of them per transpose, ~3 % of the
+// kernel's VALU issue).  Single loads let the halves be written straight into place.
+IYK_HD void xpose_read_words(int t, u32 (&r)[32], const u32* xb)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 base = (u32)(size_t)(const __attribute__((address_space(3))) u32*)(xb + t * XB_STRIDE);
+#define IYK_R(j) "ds_read_b32 %" #j ", %32 offset:" #j "*4\n"
+    asm volatile(
+        IYK_R(0) IYK_R(1) IYK_R(2) IYK_R(3) IYK_R(4) IYK_R(5) IYK_R(6) IYK_R(7)
+        IYK_R(8) IYK_R(9) IYK_R(10) IYK_R(11) IYK_R(12) IYK_R(13) IYK_R(14) IYK_R(15)
+        IYK_R(16) IYK_R(17) IYK_R(18) IYK_R(19) IYK_R(20) IYK_R(21) IYK_R(22) IYK_R(23)
+        IYK_R(24) IYK_R(25) IYK_R(26) IYK_R(27) IYK_R(28) IYK_R(29) IYK_R(30) IYK_R(31)
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]),
+          "=&v"(r[8]), "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]), "=&v"(r[14]),
+          "=&v"(r[15]), "=&v"(r[16]), "=&v"(r[17]), "=&v"(r[18]), "=&v"(r[19]), "=&v"(r[20]), "=&v"(r[21]),
+          "=&v"(r[22]), "=&v"(r[23]), "=&v"(r[24]), "=&v"(r[25]), "=&v"(r[26]), "=&v"(r[27]), "=&v"(r[28]),
+          "=&v"(r[29]), "=&v"(r[30]), "=&v"(r[31])
+        : "v"(base)
+        : "memory");
+#undef IYK_R
+#else
+#pragma unroll
+    for (int j = 0; j < 32; ++j) r[j] = xb[t * XB_STRIDE + j];
+#endif
+}
 IYK_HD void xpose_read_hi(int t, double (&x)[32], const u32 (&lo)[32], const u32* xb)
 {
+    u32 hi[32];
+    xpose_read_words(t, hi, xb);
 #pragma unroll
-    for (int j = 0; j < 32; ++j) x[j] = u2d(((u64)xb[t * XB_STRIDE + j] << 32) | lo[j]);
+    for (int j = 0; j < 32; ++j) x[j] = u2d(((u64)hi[j] << 32) | lo[j]);
 }
 
 IYK_HD void share_write(int t, int chunk, const double (&x)[32], double* xb64_own)

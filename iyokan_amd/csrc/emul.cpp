@@ -174,12 +174,12 @@ void forward_1024_fp_dev(const double* in, double* out)
     double x[32];
     for (int t = 0; t < 32; ++t) {
         for (int j2 = 0; j2 < 32; ++j2) x[j2] = j2 ? fp::mulmod(in[t + 32 * j2], T.t.c.zf[j2]) : in[t];
-        fp::ntt32_dif(x, T.t.c.w);
+        fp::ntt32_dif<fp::PASS1>(x, T.t.c.w);
         for (int p = 0; p < 32; ++p) xbuf[brv5(p) * XB_STRIDE + t] = fp::mulmod(x[p], T.t.tw_fwd[t * 32 + brv5(p)]);
     }
     for (int t = 0; t < 32; ++t) {
         for (int j1 = 0; j1 < 32; ++j1) x[j1] = xbuf[t * XB_STRIDE + j1];
-        fp::ntt32_dif(x, T.t.c.w);
+        fp::ntt32_dif<fp::PASS2>(x, T.t.c.w);
         for (int p = 0; p < 32; ++p) {
             const int k1 = brv5(p);
             out[(size_t)(k1 >> 1) * 64 + t * 2 + (k1 & 1)] = fp::norm(x[p]);
@@ -225,7 +225,8 @@ void blind_rotate_fp(const iyk_params* p, const u32* lin, const double* bk_ntt, 
                         for (int q = 0; q < 32; ++q) r.x[q] = fp::norm(r.accum[q]);
                 }
                 track(r.x);
-                fp::ntt32_dif(r.x, C.w);
+                if (first) fp::ntt32_dif<fp::PASS1>(r.x, C.w);
+                else fp::ntt32_dif<fp::PASS2>(r.x, C.w);
                 track(r.x);
             }
             if (first) {

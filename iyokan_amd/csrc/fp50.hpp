@@ -58,12 +58,15 @@ IYK_HD double norm(double x)
     return fma_(-q, P, x);
 }
 
-// integer (as double, |x| < 2^53) -> low 32 bits of its two's-complement value
+// integer (as double, |x| < 2^51) -> low 32 bits of its two's-complement value.  Adding 1.5 * 2^52
+// puts the sum in [2^52, 2^53), where doubles are exactly the integers: the mantissa then holds
+// 2^51 + x, whose low 32 bits are x mod 2^32.  One v_add_f64, and the answer is the register's low half.
 IYK_HD u32 to_torus32(double x)
 {
-    const double hi = __builtin_floor(x * (1.0 / 4294967296.0));
-    const double lo = fma_(-hi, 4294967296.0, x);  // in [0, 2^32)
-    return (u32)lo;
+    const double y = x + 6755399441055744.0;
+    u64 b;
+    __builtin_memcpy(&b, &y, 8);
+    return (u32)b;
 }
 
 // ---- host-side exact helpers (table generation) -------------------------------------------

@@ -9,13 +9,15 @@
 //
 // Magnitude discipline (units of p; every value must stay < 8 = 2^53 / p so that all additions are
 // exact integers).  A mulmod whose first operand is bounded by A p returns |r| <= (0.5 + 3A/16) p.
-// Bounds are propagated at COMPILE TIME through the butterfly network (make_norm_sched): with inputs
-// <= 1.25 p, the invariant "stage outputs <= {3.75, 3.75, 2.93, 1.6} p" is enforced by renormalising
-// exactly those sums / twiddle-free differences whose static bound would break it (34 of the 160
-// butterfly outputs).  Consequences: no intermediate exceeds 5.75 p, outputs are <= 2.14 p, and the
-// consumers stay in range: twiddle mulmod -> <= 0.9 p (next pass input), MAC terms <= 0.9 p each
-// (six or eight of them per accumulator).  host_selftest.cpp / the emulation tests track the
-// observed maxima against these bounds.
+// Bounds are propagated at COMPILE TIME through the butterfly network (make_norm_sched) and a sum /
+// twiddle-free difference is renormalised exactly where its static bound would exceed the per-stage
+// threshold.  Two schedules, one per pass of the four-step transform, chained by static_asserts:
+//   PASS1 (inputs <= 0.51 p: digits times twist, or a renormalised accumulator): 10 norms,
+//         outputs <= 7.03 p -> the inter-pass twiddle mulmod returns <= 1.82 p
+//   PASS2 (inputs <= 1.82 p): 23 norms, outputs <= 4.08 p -> each MAC term is <= 1.27 p, six of them
+//         (three gadget levels x two rows) stay below 7.6 p; no intermediate exceeds 7.46 p
+// (a single schedule good for both passes needs 34 + 34 norms of 3 instructions each).
+// host_selftest.cpp / the emulation tests track the observed maxima against these bounds.
 #pragma once
 #include "fp50.hpp"
 #include "ntt32.hpp"  // brv5, NTT_N
@@ -35,14 +37,18 @@ struct NormSched {
     bool sum[5][32];
     bool dif[5][32];
     double out_bound, mid_bound;
+    int norms;
+};
+struct NormThresholds {
+    double beta[5];
 };
 constexpr double mm_bound(double t) { return 0.5 + 3.0 * t / 16.0; }
-constexpr NormSched make_norm_sched(double b0)
+static constexpr double NORM_BOUND = 0.51;  // |norm(x)| <= p/2 + 1
+constexpr NormSched make_norm_sched(double b0, NormThresholds th)
 {
     NormSched S{};
     double B[32] = {};
     for (int i = 0; i < 32; ++i) B[i] = b0;
-    const double beta[5] = {3.75, 3.75, 2.93, 1.6, 1e9};
     double mid = 0;
     for (int s = 0; s < 5; ++s) {
         const int len = 16 >> s;
@@ -51,10 +57,11 @@ constexpr NormSched make_norm_sched(double b0)
                 const int a = blk + j, b = blk + j + len;
                 const double t = B[a] + B[b];
                 if (t > mid) mid = t;
-                S.sum[s][a] = t > beta[s];
-                S.dif[s][b] = (j == 0) && t > beta[s];
-                B[a] = S.sum[s][a] ? 0.51 : t;
-                B[b] = (j == 0) ? (S.dif[s][b] ? 0.51 : t) : mm_bound(t);
+                S.sum[s][a] = t > th.beta[s];
+                S.dif[s][b] = (j == 0) && t > th.beta[s];
+                S.norms += (S.sum[s][a] ? 1 : 0) + (S.dif[s][b] ? 1 : 0);
+                B[a] = S.sum[s][a] ? NORM_BOUND : t;
+                B[b] = (j == 0) ? (S.dif[s][b] ? NORM_BOUND : t) : mm_bound(t);
             }
     }
     double ob = 0;
@@ -64,13 +71,23 @@ constexpr NormSched make_norm_sched(double b0)
     S.mid_bound = mid;
     return S;
 }
-static constexpr double DIF_INPUT_BOUND = 1.25;
-static constexpr NormSched kSched = make_norm_sched(DIF_INPUT_BOUND);
-static_assert(kSched.mid_bound < 7.5 && kSched.out_bound < 3.2, "magnitude discipline violated");
+enum { PASS1 = 0, PASS2 = 1 };
+static constexpr double PASS1_INPUT_BOUND = NORM_BOUND;
+static constexpr NormSched kSched1 = make_norm_sched(PASS1_INPUT_BOUND, {{1.25, 2.25, 3.0, 4.0, 1e9}});
+static constexpr double PASS2_INPUT_BOUND = mm_bound(kSched1.out_bound);  // after the inter-pass twiddle
+static constexpr NormSched kSched2 = make_norm_sched(PASS2_INPUT_BOUND, {{3.75, 5.0, 3.75, 2.5, 1e9}});
+static constexpr double MAC_TERM_BOUND = mm_bound(kSched2.out_bound);
+static_assert(kSched1.mid_bound < 7.5 && kSched1.out_bound < 7.5, "pass-1 magnitude discipline violated");
+static_assert(kSched2.mid_bound < 7.5 && kSched2.out_bound < 7.5, "pass-2 magnitude discipline violated");
+static_assert(6 * MAC_TERM_BOUND < 7.9, "six MAC terms must stay below 2^53");
+static_assert(NORM_BOUND + 4 * MAC_TERM_BOUND < 7.9, "LV = 4: renormalised half sum + four more terms");
+static_assert(kSched1.norms == 10 && kSched2.norms == 23, "schedule changed: update the comments");
 
 // cyclic 32-point DIF, natural in, bit-reversed out; twiddle of position j at stage s is w[j << s]
+template <int PASS>
 IYK_HD void ntt32_dif(double (&a)[32], const double* w)
 {
+    constexpr const NormSched& S = PASS == PASS1 ? kSched1 : kSched2;
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
         const int len = 16 >> s;
@@ -80,8 +97,8 @@ IYK_HD void ntt32_dif(double (&a)[32], const double* w)
             for (int j = 0; j < len; ++j) {
                 const double u = a[blk + j], v = a[blk + j + len];
                 const double sum = u + v, dif = u - v;
-                a[blk + j] = kSched.sum[s][blk + j] ? norm(sum) : sum;
-                a[blk + j + len] = (j == 0) ? (kSched.dif[s][blk + j + len] ? norm(dif) : dif) : mulmod(dif, w[j << s]);
+                a[blk + j] = S.sum[s][blk + j] ? norm(sum) : sum;
+                a[blk + j + len] = (j == 0) ? (S.dif[s][blk + j + len] ? norm(dif) : dif) : mulmod(dif, w[j << s]);
             }
         }
     }

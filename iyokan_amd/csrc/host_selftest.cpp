@@ -175,14 +175,14 @@ static void fp_forward(const double* in, double* out, const fp::HostTables& T)
     for (int t = 0; t < 32; ++t) {
         for (int j2 = 0; j2 < 32; ++j2) x[j2] = j2 ? fp::mulmod(in[t + 32 * j2], T.c.zf[j2]) : in[t];
         trk(x);
-        fp::ntt32_dif(x, T.c.w);
+        fp::ntt32_dif<fp::PASS1>(x, T.c.w);
         trk(x);
         for (int p = 0; p < 32; ++p) xbuf[brv5(p) * 33 + t] = fp::mulmod(x[p], T.tw_fwd[t * 32 + brv5(p)]);
     }
     for (int t = 0; t < 32; ++t) {
         for (int j1 = 0; j1 < 32; ++j1) x[j1] = xbuf[t * 33 + j1];
         trk(x);
-        fp::ntt32_dif(x, T.c.w);
+        fp::ntt32_dif<fp::PASS2>(x, T.c.w);
         trk(x);
         for (int p = 0; p < 32; ++p) out[t + 32 * brv5(p)] = x[p];
     }
@@ -194,13 +194,13 @@ static void fp_inverse(const double* in, double* out, const fp::HostTables& T)
     double x[32];
     for (int t = 0; t < 32; ++t) {  // lane = k2, natural k1 input
         for (int k1 = 0; k1 < 32; ++k1) x[k1] = fp::norm(in[t + 32 * k1]);
-        fp::ntt32_dif(x, T.c.w);
+        fp::ntt32_dif<fp::PASS1>(x, T.c.w);
         trk(x);
         for (int p = 0; p < 32; ++p) xbuf[inv_idx(p) * 33 + t] = fp::mulmod(x[p], T.tw_inv[t * 32 + inv_idx(p)]);
     }
     for (int t = 0; t < 32; ++t) {  // lane = j1
         for (int k2 = 0; k2 < 32; ++k2) x[k2] = xbuf[t * 33 + k2];
-        fp::ntt32_dif(x, T.c.w);
+        fp::ntt32_dif<fp::PASS2>(x, T.c.w);
         trk(x);
         for (int p = 0; p < 32; ++p) {
             const int j2 = inv_idx(p);
@@ -263,16 +263,16 @@ static void test_fp50()
             fp_forward(fd.data(), Fd.data(), T);
             fp_forward(fb.data(), Fb.data(), T);
             for (int i = 0; i < 1024; ++i) {
-                acc[i] += fp::mulmod(Fd[i], fp::norm(Fb[i]));  // BK is stored normalised, D is lazy (<= 3.2 p)
+                acc[i] += fp::mulmod(Fd[i], fp::norm(Fb[i]));  // BK is stored normalised, D is lazy (<= 4.08 p)
                 ref[i] += prod[i];
             }
         }
-        for (double v : acc) CHECK((v < 0 ? -v : v) < 7.0 * fp::P);
+        for (double v : acc) CHECK((v < 0 ? -v : v) < 7.6 * fp::P);
         std::vector<double> res(1024);
         fp_inverse(acc.data(), res.data(), T);
         for (int i = 0; i < 1024; ++i) CHECK(fp::to_torus32(res[i]) == ref[i]);
     }
-    CHECK(g_maxabs < 6.0);
+    CHECK(g_maxabs < 7.5);
     std::printf("fp50 worst-case external product ok (max |x|/p inside transforms = %.3f)\n", g_maxabs);
 }
 

@@ -275,13 +275,13 @@ __global__ __launch_bounds__(64) void bk_ntt_fp_kernel(const u32* __restrict__ b
         const double val = (double)(int32_t)(bk[src + t + 32 * j2] * scale);  // signed lift: |sum| < p/2 (fp50.hpp)
         x[j2] = j2 ? fp::mulmod(val, C.zf[j2]) : val;
     }
-    fp::ntt32_dif(x, C.w);
+    fp::ntt32_dif<fp::PASS1>(x, C.w);
 #pragma unroll
     for (int p = 0; p < 32; ++p) xbo[brv5(p) * XB_STRIDE + t] = fp::mulmod(x[p], tw_fwd[t * 32 + brv5(p)]);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 32; ++j) x[j] = xbo[t * XB_STRIDE + j];
-    fp::ntt32_dif(x, C.w);
+    fp::ntt32_dif<fp::PASS2>(x, C.w);
     if (live) {
 #pragma unroll
         for (int p = 0; p < 32; ++p) {
@@ -334,13 +334,14 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
 #pragma unroll
         for (int q = 0; q < 32; ++q) accum[q] = 0.0;
 
+        // L forward transforms (each followed by its MAC against the key rows), then the inverse transform;
+        // every iteration is pass 1 (DIF over the high index, inter-pass twiddle, 32 x 32 transpose) and
+        // pass 2 (DIF over the low index) with its own renormalisation schedule (fpntt32.hpp)
 #pragma unroll 1
-        for (int pass = 0; pass < 2 * L + 2; ++pass) {
-            const int lvl = pass >> 1;
-            const bool fwd = pass < 2 * L;
-            const bool first = (pass & 1) == 0;
+        for (int lvl = 0; lvl <= L; ++lvl) {
+            const bool fwd = lvl < L;
             int t = t0, h = h0;
-            asm volatile("" : "+v"(t), "+v"(h));  // keep address math inside the pass (see blind_rotate_kernel)
+            asm volatile("" : "+v"(t), "+v"(h));  // keep address math inside the iteration (see blind_rotate_kernel)
             u32* acc_h = acc_lds + h * NTT_N;
             u32* xb = acc_lds + 2 * NTT_N + h * XB_WORDS32;
             double* xb64_own = reinterpret_cast<double*>(xb);
@@ -349,41 +350,37 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
             const double* bkt = bk_step + (size_t)(((1 - h) * L + lvl) * 2 + h) * NTT_N + (size_t)t * 2;
             double b0o[2], b0t[2], b1o[2], b1t[2];
 
-            if (first) {
-                if (fwd) fp::fwd1_pre<D>(t, lvl, ab, acc_h, x, C.zf);
-                else {
+            if (fwd) fp::fwd1_pre<D>(t, lvl, ab, acc_h, x, C.zf);
+            else {
 #pragma unroll
-                    for (int q = 0; q < 32; ++q) x[q] = fp::norm(accum[q]);
-                }
+                for (int q = 0; q < 32; ++q) x[q] = fp::norm(accum[q]);
             }
-            else if (fwd) {
+            fp::ntt32_dif<fp::PASS1>(x, C.w);
+            if (fwd) {
+                fp::fwd1_twiddle(t, x, s_twf);
+                fp::xpose_write<false>(t, x, xb, false);
+                lds_sync();
+                fp::xpose_read_words(t, lo, xb);
+                lds_sync();
+                fp::xpose_write<false>(t, x, xb, true);
+            }
+            else {
+                fp::inv1_twiddle(t, x, s_twi);
+                fp::xpose_write<true>(t, x, xb, false);
+                lds_sync();
+                fp::xpose_read_words(t, lo, xb);
+                lds_sync();
+                fp::xpose_write<true>(t, x, xb, true);
+            }
+            lds_sync();
+            fp::xpose_read_hi(t, x, lo, xb);
+            lds_sync();
+
+            if (fwd) {
                 b0o[0] = bko[0]; b0o[1] = bko[1]; b0t[0] = bkt[0]; b0t[1] = bkt[1];
             }
-
-            fp::ntt32_dif(x, C.w);
-
-            if (first) {
-                if (fwd) {
-                    fp::fwd1_twiddle(t, x, s_twf);
-                    fp::xpose_write<false>(t, x, xb, false);
-                    lds_sync();
-                    br_xpose_read_lo(t, lo, xb);
-                    lds_sync();
-                    fp::xpose_write<false>(t, x, xb, true);
-                }
-                else {
-                    fp::inv1_twiddle(t, x, s_twi);
-                    fp::xpose_write<true>(t, x, xb, false);
-                    lds_sync();
-                    br_xpose_read_lo(t, lo, xb);
-                    lds_sync();
-                    fp::xpose_write<true>(t, x, xb, true);
-                }
-                lds_sync();
-                fp::xpose_read_hi(t, x, lo, xb);
-                lds_sync();
-            }
-            else if (fwd) {
+            fp::ntt32_dif<fp::PASS2>(x, C.w);
+            if (fwd) {
 #pragma unroll
                 for (int chunk = 0; chunk < 2; ++chunk) {
                     fp::share_write(t, chunk, x, xb64_own);
@@ -402,7 +399,7 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
                     }
                     lds_sync();
                 }
-                // magnitude discipline: each level adds two terms of <= 1.1 p; with 4 virtual levels the
+                // magnitude discipline: each level adds two terms of <= 1.27 p; with 4 virtual levels the
                 // running sum is renormalised half way so it can never reach 2^53 (8 p)
                 if (L > 3 && lvl == 1) {
 #pragma unroll
@@ -488,18 +485,18 @@ __global__ __launch_bounds__(64 * D::LV) void blind_rotate_fp_lat_kernel(
             const double* bkt = bk_step + (size_t)(((1 - h) * L + wave) * 2 + h) * NTT_N + (size_t)t * 2;
             // forward pass 1 of level `wave`
             fp::fwd1_pre<D>(t, wave, ab, acc_h, x, C.zf);
-            fp::ntt32_dif(x, C.w);
+            fp::ntt32_dif<fp::PASS1>(x, C.w);
             fp::fwd1_twiddle(t, x, s_twf);
             fp::xpose_write<false>(t, x, xb, false);
             lds_sync();
-            br_xpose_read_lo(t, lo, xb);
+            fp::xpose_read_words(t, lo, xb);
             lds_sync();
             fp::xpose_write<false>(t, x, xb, true);
             lds_sync();
             fp::xpose_read_hi(t, x, lo, xb);
             lds_sync();
             // forward pass 2 + MAC
-            fp::ntt32_dif(x, C.w);
+            fp::ntt32_dif<fp::PASS2>(x, C.w);
 #pragma unroll
             for (int q = 0; q < 32; ++q) accum[q] = 0.0;
 #pragma unroll
@@ -546,17 +543,17 @@ __global__ __launch_bounds__(64 * D::LV) void blind_rotate_fp_lat_kernel(
             u32* xb = wave_xb + h * XB_WORDS32;
 #pragma unroll
             for (int q = 0; q < 32; ++q) x[q] = fp::norm(accum[q]);
-            fp::ntt32_dif(x, C.w);
+            fp::ntt32_dif<fp::PASS1>(x, C.w);
             fp::inv1_twiddle(t, x, s_twi);
             fp::xpose_write<true>(t, x, xb, false);
             lds_sync();
-            br_xpose_read_lo(t, lo, xb);
+            fp::xpose_read_words(t, lo, xb);
             lds_sync();
             fp::xpose_write<true>(t, x, xb, true);
             lds_sync();
             fp::xpose_read_hi(t, x, lo, xb);
             lds_sync();
-            fp::ntt32_dif(x, C.w);
+            fp::ntt32_dif<fp::PASS2>(x, C.w);
             fp::inv2_post(t, x, acc_h, C.zi);
         }
         __syncthreads();  // accumulator of step i is complete before anyone derives step i+1's digits

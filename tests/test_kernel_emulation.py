@@ -60,4 +60,4 @@ def test_emulated_fp64_path_bit_exact(which, request):
         assert em.iyk_emul_blind_rotate_fp(ctypes.byref(p), lin.ctypes.data_as(u32p), bk.ctypes.data_as(dp),
                                            got.ctypes.data_as(u32p)) == 0
         assert np.array_equal(oracle128.bootstrap_lvl1(lin), got)
-    assert em.iyk_emul_fp_max_magnitude() < 6.0
+    assert em.iyk_emul_fp_max_magnitude() < 7.6
