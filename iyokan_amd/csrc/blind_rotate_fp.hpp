@@ -53,19 +53,52 @@ struct Decomp {
     IYK_HD static u32 key_scale(int v) { return (SPLIT_ == 2 && (v % SPLIT_ == 0)) ? (1u << HB) : 1u; }
 };
 
+// Twisted-digit table: ztab[j2 * 64 + (d + 32)] = d * zeta^j2 mod p for every digit value d in [-32, 32)
+// (both parameter sets: |d| <= 32 resp. 16) and every twist j2.  Built once per workgroup in LDS by the
+// same mulmod the transform uses, so a lookup is bit-identical to "convert, multiply, reduce" — and
+// replaces those 7 VALU instructions per coefficient and level by one LDS read.
+static constexpr int ZTAB_DIGITS = 64;
+static constexpr int ZTAB_ENTRIES = 32 * ZTAB_DIGITS;
+IYK_HD double ztab_entry(int e, const double* zf)
+{
+    const int j2 = e / ZTAB_DIGITS;
+    const double d = (double)((e % ZTAB_DIGITS) - ZTAB_DIGITS / 2);
+    return j2 ? mulmod(d, zf[j2]) : d;
+}
+
 // forward pass 1, pre: signed digit of virtual level v of ((X^abar - 1) acc_h)[t + 32 j2], times zeta^j2
 template <class D>
-IYK_HD void fwd1_pre(int t, int v, u32 abar, const u32* acc_h, double (&x)[32], const double* zf)
+IYK_HD void fwd1_pre(int t, int v, u32 abar, const u32* acc_h, double (&x)[32], const double* ztab)
 {
+    static_assert(D::max_digit() <= ZTAB_DIGITS / 2, "digit range exceeds the twist table");
+    u32 td[32];
+    // two sweeps so that the 64 accumulator reads, then the 32 table reads, are each issued back to back
+    // instead of one dependent LDS round trip per coefficient
+#if defined(__HIP_DEVICE_COMPILE__)
+    // PRECONDITION (both kernels' LDS maps honour it): acc_h is 4 KB aligned, so the wrapped byte address
+    // is one v_and_or: (4 idx mod 4096) | base.  Everything else is the generic code below, in bytes.
+    typedef const __attribute__((address_space(3))) u32* lds_u32;
+    const u32 acc_base = (u32)(size_t)(lds_u32)acc_h;
+    const u32 base4 = ((u32)t - abar) << 2;
 #pragma unroll
     for (int j2 = 0; j2 < 32; ++j2) {
-        const u32 idx = (((u32)t - abar) + 32u * (u32)j2) & (2 * NTT_N - 1);
-        u32 a = acc_h[idx & (NTT_N - 1)];
-        a = (idx & NTT_N) ? 0u - a : a;
-        const u32 td = a - acc_h[t + 32 * j2];
-        const double d = (double)D::digit(td, v);
-        x[j2] = (j2 == 0) ? d : mulmod(d, zf[j2]);
+        const u32 idx4 = base4 + 128u * (u32)j2;
+        const u32 neg = (u32)((i32)(idx4 << 19) >> 31);       // bit 12 of 4 idx = bit 10 of idx
+        const u32 a = *(lds_u32)(size_t)((idx4 & 0xFFCu) | acc_base);
+        td[j2] = (a ^ neg) + ((0u - acc_h[t + 32 * j2]) - neg);
     }
+#else
+    const u32 base = (u32)t - abar;
+#pragma unroll
+    for (int j2 = 0; j2 < 32; ++j2) {
+        const u32 idx = base + 32u * (u32)j2;                 // position of the rotated coefficient, mod 2N
+        const u32 neg = 0u - ((idx >> 10) & 1u);              // all ones where X^N = -1 flips the sign
+        const u32 a = (acc_h[idx & (NTT_N - 1)] ^ neg) - neg;
+        td[j2] = a - acc_h[t + 32 * j2];
+    }
+#endif
+#pragma unroll
+    for (int j2 = 0; j2 < 32; ++j2) x[j2] = ztab[j2 * ZTAB_DIGITS + (D::digit(td[j2], v) + ZTAB_DIGITS / 2)];
 }
 
 IYK_HD void fwd1_twiddle(int t, double (&x)[32], const double* twf_t)
@@ -144,6 +177,17 @@ IYK_HD void inv1_twiddle(int t, double (&x)[32], const double* twi_t)
 {
 #pragma unroll
     for (int p = 0; p < 32; ++p) x[p] = mulmod(x[p], twi_t[inv_index(p) * 32 + t]);
+}
+// the same with the 32 twiddles of this lane already in registers: tw[p] = twi_t[inv_index(p) * 32 + t]
+IYK_HD void inv1_twiddle_load(int t, double (&tw)[32], const double* twi_t)
+{
+#pragma unroll
+    for (int p = 0; p < 32; ++p) tw[p] = twi_t[inv_index(p) * 32 + t];
+}
+IYK_HD void inv1_twiddle_regs(double (&x)[32], const double (&tw)[32])
+{
+#pragma unroll
+    for (int p = 0; p < 32; ++p) x[p] = mulmod(x[p], tw[p]);
 }
 
 // inverse pass 2', post: zeta^(-j2), reduce to the centred representative (= the integer

@@ -193,6 +193,8 @@ void blind_rotate_fp(const iyk_params* p, const u32* lin, const double* bk_ntt, 
     constexpr int L = D::LV;
     const FpTables& T = fptables();
     const fp::NttConsts& C = T.t.c;
+    std::vector<double> ztab(fp::ZTAB_ENTRIES);  // the workgroup's twisted-digit table (LDS on the device)
+    for (int e = 0; e < fp::ZTAB_ENTRIES; ++e) ztab[e] = fp::ztab_entry(e, C.zf);
     std::vector<u32> wave_lds(BR_WAVE_LDS_WORDS + 2);
     u32* acc_lds = wave_lds.data() + ((reinterpret_cast<uintptr_t>(wave_lds.data()) & 7) ? 1 : 0);
     struct Lane {
@@ -220,7 +222,7 @@ void blind_rotate_fp(const iyk_params* p, const u32* lin, const double* bk_ntt, 
             {
                 Lane& r = R[lane];
                 if (first) {
-                    if (fwd) fp::fwd1_pre<D>(lane & 31, lvl, abar, acc_h(lane), r.x, C.zf);
+                    if (fwd) fp::fwd1_pre<D>(lane & 31, lvl, abar, acc_h(lane), r.x, ztab.data());
                     else
                         for (int q = 0; q < 32; ++q) r.x[q] = fp::norm(r.accum[q]);
                 }

@@ -173,12 +173,12 @@ int launch_br_fp(iyk_hip_stream* st, int first, int njobs, u32* d_tlwe1, int trl
     auto kern = blind_rotate_fp_kernel<DC>;
     if (!attr_set[st->gpu]) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)BR_LDS_BYTES));
+                                    (int)BR_FP_LDS_BYTES));
         attr_set[st->gpu] = true;
     }
     dim3 grid((njobs + BR_WAVES - 1) / BR_WAVES), block(64 * BR_WAVES);
-    hipLaunchKernelGGL(kern, grid, block, BR_LDS_BYTES, st->s, (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE,
-                       njobs, (const double*)D.bk_ntt, (const double*)D.tw_fwd, (const double*)D.tw_inv, D.fpc,
+    hipLaunchKernelGGL(kern, grid, block, BR_FP_LDS_BYTES, st->s, (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE,
+                       njobs, (const double*)D.bk_ntt, (const double*)D.tw_fwd, (const double*)D.tw_inv + NTT_N, D.fpc,
                        d_tlwe1 + (size_t)first * (trlwe ? 2 * NTT_N : NTT_N + 1), G.p.n, G.p.mu, ABAR_STRIDE, trlwe);
     HIP_TRY(hipGetLastError());
     return IYK_OK;
@@ -355,7 +355,7 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
     const double worst = 2.0 * (p.k + 1) * LV * p.N * dmax * 2147483648.0;
     const char* force = std::getenv("IYK_HIP_NTT");
     const bool use_fp = worst < fp::P && !(force && std::string(force) == "goldilocks");
-    std::vector<u64> twf(NTT_N), twi(NTT_N);
+    std::vector<u64> twf(NTT_N), twi(2 * NTT_N);  // twi: [k2][j1], then the transposed copy [j1][k2]
     fp::HostTables fpt;
     if (use_fp) {
         fp::make_tables(fpt);
@@ -365,6 +365,9 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
     else {
         ntt_make_tables(twf.data(), twi.data());
     }
+
+    for (int k2 = 0; k2 < 32; ++k2)
+        for (int j1 = 0; j1 < 32; ++j1) twi[NTT_N + j1 * 32 + k2] = twi[k2 * 32 + j1];
 
     const size_t bk_words = (size_t)iyk_bk_words(&p);
     const size_t polys = bk_words / NTT_N;
@@ -386,13 +389,13 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
         HIP_TRY(hipMalloc((void**)&D.bk_ntt, bk_words * sizeof(u64) * (use_fp ? split : 1)));
         HIP_TRY(hipMalloc((void**)&D.ksk, ksk_pad.size() * sizeof(u32)));
         HIP_TRY(hipMalloc((void**)&D.tw_fwd, NTT_N * sizeof(u64)));
-        HIP_TRY(hipMalloc((void**)&D.tw_inv, NTT_N * sizeof(u64)));
+        HIP_TRY(hipMalloc((void**)&D.tw_inv, 2 * NTT_N * sizeof(u64)));
         HIP_TRY(hipMalloc((void**)&D.fpc, sizeof(fp::NttConsts)));
         HIP_TRY(hipMemcpy(D.fpc, &fpt.c, sizeof(fp::NttConsts), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_bk, bk_torus, bk_words * sizeof(u32), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(D.ksk, ksk_pad.data(), ksk_pad.size() * sizeof(u32), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(D.tw_fwd, twf.data(), NTT_N * sizeof(u64), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(D.tw_inv, twi.data(), NTT_N * sizeof(u64), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(D.tw_inv, twi.data(), 2 * NTT_N * sizeof(u64), hipMemcpyHostToDevice));
         if (use_fp)
             hipLaunchKernelGGL(bk_ntt_fp_kernel, dim3((unsigned)((polys * split + 1) / 2)), dim3(64), 0, 0, d_bk,
                                (double*)D.bk_ntt, (const double*)D.tw_fwd, D.fpc, polys * split, (int)p.l, split,

@@ -291,25 +291,33 @@ __global__ __launch_bounds__(64) void bk_ntt_fp_kernel(const u32* __restrict__ b
     }
 }
 
+// LDS map of blind_rotate_fp_kernel (bytes): forward twiddles 8 K | twisted-digit table 16 K |
+// accumulators [wave][h][1024] u32 64 K (every polynomial 4 KB aligned) | transpose/share buffers
+// [wave][h][32][33] u32 66 K  = 154 KB of the CU's 160 KB, one 8-wave workgroup per CU.
+static constexpr size_t BR_FP_LDS_BYTES = NTT_N * sizeof(double) + fp::ZTAB_ENTRIES * sizeof(double) +
+                                          (size_t)BR_WAVES * 2 * NTT_N * sizeof(u32) +
+                                          (size_t)BR_WAVES * 2 * XB_WORDS32 * sizeof(u32);
+
 template <class D>
 __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
     const u32* __restrict__ abar_all, int njobs, const double* __restrict__ bk_ntt,
-    const double* __restrict__ tw_fwd, const double* __restrict__ tw_inv, const fp::NttConsts* __restrict__ Cp,
+    const double* __restrict__ tw_fwd, const double* __restrict__ tw_inv_t, const fp::NttConsts* __restrict__ Cp,
     u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride, int trlwe_mode)
 {
     // twist / 32-point twiddle constants are read with scalar loads where they are used: held by value
     // they overflow the SGPR file and come back through v_readlane (a VALU op per 32 bits)
     const fp::NttConsts& C = *Cp;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* s_twf = reinterpret_cast<double*>(smem);         // [k2][j1]
-    double* s_twi = s_twf + NTT_N;                           // [j1][k2]
-    u32* s_wave = reinterpret_cast<u32*>(s_twi + NTT_N);     // [BR_WAVES][BR_WAVE_LDS_WORDS]
+    extern __shared__ __attribute__((aligned(4096))) unsigned char smem[];
+    double* s_twf = reinterpret_cast<double*>(smem);                   // [k2][j1]
+    double* s_ztab = s_twf + NTT_N;                                    // [j2][digit + 32]
+    u32* s_acc = reinterpret_cast<u32*>(s_ztab + fp::ZTAB_ENTRIES);    // [BR_WAVES][2][NTT_N]
+    u32* s_xb = s_acc + BR_WAVES * 2 * NTT_N;                          // [BR_WAVES][2][XB_WORDS32]
 
     for (int e = threadIdx.x; e < NTT_N; e += 64 * BR_WAVES) {
         const int a = e >> 5, b = e & 31;
         s_twf[b * 32 + a] = tw_fwd[e];
-        s_twi[b * 32 + a] = tw_inv[e];
     }
+    for (int e = threadIdx.x; e < fp::ZTAB_ENTRIES; e += 64 * BR_WAVES) s_ztab[e] = fp::ztab_entry(e, C.zf);
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -320,7 +328,8 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
     if (!live) job = njobs - 1;
 
     constexpr int L = D::LV;  // (virtual) gadget levels
-    u32* acc_lds = s_wave + wave * BR_WAVE_LDS_WORDS;
+    u32* acc_lds = s_acc + wave * 2 * NTT_N;
+    u32* xb_lds = s_xb + wave * 2 * XB_WORDS32;
     const u32* abar = abar_all + (size_t)job * abar_stride;
 
     u32 lo[32];
@@ -334,82 +343,86 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
 #pragma unroll
         for (int q = 0; q < 32; ++q) accum[q] = 0.0;
 
-        // L forward transforms (each followed by its MAC against the key rows), then the inverse transform;
-        // every iteration is pass 1 (DIF over the high index, inter-pass twiddle, 32 x 32 transpose) and
-        // pass 2 (DIF over the low index) with its own renormalisation schedule (fpntt32.hpp)
+        // L forward transforms, each followed by its MAC against the key rows.  A transform is pass 1 (DIF
+        // over the high index, inter-pass twiddle, 32 x 32 transpose) and pass 2 (DIF over the low index),
+        // each with its own renormalisation schedule (fpntt32.hpp).
 #pragma unroll 1
-        for (int lvl = 0; lvl <= L; ++lvl) {
-            const bool fwd = lvl < L;
+        for (int lvl = 0; lvl < L; ++lvl) {
             int t = t0, h = h0;
             asm volatile("" : "+v"(t), "+v"(h));  // keep address math inside the iteration (see blind_rotate_kernel)
-            u32* acc_h = acc_lds + h * NTT_N;
-            u32* xb = acc_lds + 2 * NTT_N + h * XB_WORDS32;
+            const u32* acc_h = acc_lds + h * NTT_N;
+            u32* xb = xb_lds + h * XB_WORDS32;
             double* xb64_own = reinterpret_cast<double*>(xb);
-            const double* xb64_oth = reinterpret_cast<const double*>(acc_lds + 2 * NTT_N + (1 - h) * XB_WORDS32);
+            const double* xb64_oth = reinterpret_cast<const double*>(xb_lds + (1 - h) * XB_WORDS32);
             const double* bko = bk_step + (size_t)((h * L + lvl) * 2 + h) * NTT_N + (size_t)t * 2;
             const double* bkt = bk_step + (size_t)(((1 - h) * L + lvl) * 2 + h) * NTT_N + (size_t)t * 2;
             double b0o[2], b0t[2], b1o[2], b1t[2];
 
-            if (fwd) fp::fwd1_pre<D>(t, lvl, ab, acc_h, x, C.zf);
-            else {
-#pragma unroll
-                for (int q = 0; q < 32; ++q) x[q] = fp::norm(accum[q]);
-            }
+            fp::fwd1_pre<D>(t, lvl, ab, acc_h, x, s_ztab);
             fp::ntt32_dif<fp::PASS1>(x, C.w);
-            if (fwd) {
-                fp::fwd1_twiddle(t, x, s_twf);
-                fp::xpose_write<false>(t, x, xb, false);
-                lds_sync();
-                fp::xpose_read_words(t, lo, xb);
-                lds_sync();
-                fp::xpose_write<false>(t, x, xb, true);
-            }
-            else {
-                fp::inv1_twiddle(t, x, s_twi);
-                fp::xpose_write<true>(t, x, xb, false);
-                lds_sync();
-                fp::xpose_read_words(t, lo, xb);
-                lds_sync();
-                fp::xpose_write<true>(t, x, xb, true);
-            }
+            fp::fwd1_twiddle(t, x, s_twf);
+            fp::xpose_write<false>(t, x, xb, false);
+            lds_sync();
+            fp::xpose_read_words(t, lo, xb);
+            lds_sync();
+            fp::xpose_write<false>(t, x, xb, true);
             lds_sync();
             fp::xpose_read_hi(t, x, lo, xb);
             lds_sync();
 
-            if (fwd) {
-                b0o[0] = bko[0]; b0o[1] = bko[1]; b0t[0] = bkt[0]; b0t[1] = bkt[1];
-            }
+            b0o[0] = bko[0]; b0o[1] = bko[1]; b0t[0] = bkt[0]; b0t[1] = bkt[1];
             fp::ntt32_dif<fp::PASS2>(x, C.w);
-            if (fwd) {
 #pragma unroll
-                for (int chunk = 0; chunk < 2; ++chunk) {
-                    fp::share_write(t, chunk, x, xb64_own);
-                    lds_sync();
+            for (int chunk = 0; chunk < 2; ++chunk) {
+                fp::share_write(t, chunk, x, xb64_own);
+                lds_sync();
 #pragma unroll
-                    for (int mm = 0; mm < 8; mm += 2) {
-                        const int m = chunk * 8 + mm;
-                        b1o[0] = bko[(m + 1) * 64]; b1o[1] = bko[(m + 1) * 64 + 1];
-                        b1t[0] = bkt[(m + 1) * 64]; b1t[1] = bkt[(m + 1) * 64 + 1];
-                        fp::mac_pair(t, m, x, xb64_oth, b0o, b0t, accum);
-                        if (m + 2 < 16) {
-                            b0o[0] = bko[(m + 2) * 64]; b0o[1] = bko[(m + 2) * 64 + 1];
-                            b0t[0] = bkt[(m + 2) * 64]; b0t[1] = bkt[(m + 2) * 64 + 1];
-                        }
-                        fp::mac_pair(t, m + 1, x, xb64_oth, b1o, b1t, accum);
+                for (int mm = 0; mm < 8; mm += 2) {
+                    const int m = chunk * 8 + mm;
+                    b1o[0] = bko[(m + 1) * 64]; b1o[1] = bko[(m + 1) * 64 + 1];
+                    b1t[0] = bkt[(m + 1) * 64]; b1t[1] = bkt[(m + 1) * 64 + 1];
+                    fp::mac_pair(t, m, x, xb64_oth, b0o, b0t, accum);
+                    if (m + 2 < 16) {
+                        b0o[0] = bko[(m + 2) * 64]; b0o[1] = bko[(m + 2) * 64 + 1];
+                        b0t[0] = bkt[(m + 2) * 64]; b0t[1] = bkt[(m + 2) * 64 + 1];
                     }
-                    lds_sync();
+                    fp::mac_pair(t, m + 1, x, xb64_oth, b1o, b1t, accum);
                 }
-                // magnitude discipline: each level adds two terms of <= 1.27 p; with 4 virtual levels the
-                // running sum is renormalised half way so it can never reach 2^53 (8 p)
-                if (L > 3 && lvl == 1) {
-#pragma unroll
-                    for (int q = 0; q < 32; ++q) accum[q] = fp::norm(accum[q]);
-                }
-            }
-            else {
-                fp::inv2_post(t, x, acc_h, C.zi);
                 lds_sync();
             }
+            // magnitude discipline: each level adds two terms of <= 1.27 p; with 4 virtual levels the
+            // running sum is renormalised half way so it can never reach 2^53 (8 p)
+            if (L > 3 && lvl == 1) {
+#pragma unroll
+                for (int q = 0; q < 32; ++q) accum[q] = fp::norm(accum[q]);
+            }
+        }
+
+        // inverse transform of the NTT-domain sum, added to the accumulator.  Its inter-pass twiddles come
+        // straight from global memory (L2-resident, 8 KB) into the registers the now dead sum occupied: the
+        // loads are issued before pass 1 and land long before they are needed.
+        {
+            int t = t0, h = h0;
+            asm volatile("" : "+v"(t), "+v"(h));
+            u32* acc_h = acc_lds + h * NTT_N;
+            u32* xb = xb_lds + h * XB_WORDS32;
+            double twi[32];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) x[q] = fp::norm(accum[q]);
+            fp::inv1_twiddle_load(t, twi, tw_inv_t);
+            fp::ntt32_dif<fp::PASS1>(x, C.w);
+            fp::inv1_twiddle_regs(x, twi);
+            fp::xpose_write<true>(t, x, xb, false);
+            lds_sync();
+            fp::xpose_read_words(t, lo, xb);
+            lds_sync();
+            fp::xpose_write<true>(t, x, xb, true);
+            lds_sync();
+            fp::xpose_read_hi(t, x, lo, xb);
+            lds_sync();
+            fp::ntt32_dif<fp::PASS2>(x, C.w);
+            fp::inv2_post(t, x, acc_h, C.zi);
+            lds_sync();
         }
     }
 
@@ -437,7 +450,7 @@ static constexpr size_t BR_LAT_WAVE_WORDS = 2 * XB_WORDS32;  // u32 words of tra
 template <int L>
 constexpr size_t br_lat_lds_bytes()
 {
-    return 2 * NTT_N * sizeof(double) + (2 * NTT_N + L * BR_LAT_WAVE_WORDS) * sizeof(u32);
+    return (2 * NTT_N + fp::ZTAB_ENTRIES) * sizeof(double) + (2 * NTT_N + L * BR_LAT_WAVE_WORDS) * sizeof(u32);
 }
 
 template <class D>
@@ -448,10 +461,11 @@ __global__ __launch_bounds__(64 * D::LV) void blind_rotate_fp_lat_kernel(
 {
     const fp::NttConsts& C = *Cp;
     constexpr int L = D::LV;  // one wavefront per (virtual) gadget level
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(4096))) unsigned char smem[];
     double* s_twf = reinterpret_cast<double*>(smem);
     double* s_twi = s_twf + NTT_N;
-    u32* acc_lds = reinterpret_cast<u32*>(s_twi + NTT_N);   // [2][1024], shared by all waves
+    double* s_ztab = s_twi + NTT_N;                          // [j2][digit + 32]
+    u32* acc_lds = reinterpret_cast<u32*>(s_ztab + fp::ZTAB_ENTRIES);  // [2][1024], shared by all waves
     u32* s_xb = acc_lds + 2 * NTT_N;                         // [L][2][XB_WORDS32]
 
     for (int e = threadIdx.x; e < NTT_N; e += 64 * L) {
@@ -459,6 +473,7 @@ __global__ __launch_bounds__(64 * D::LV) void blind_rotate_fp_lat_kernel(
         s_twf[b * 32 + a] = tw_fwd[e];
         s_twi[b * 32 + a] = tw_inv[e];
     }
+    for (int e = threadIdx.x; e < fp::ZTAB_ENTRIES; e += 64 * L) s_ztab[e] = fp::ztab_entry(e, C.zf);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // = gadget level of this wave
     const int lane = threadIdx.x & 63;
     const int h0 = lane >> 5, t0 = lane & 31;
@@ -484,7 +499,7 @@ __global__ __launch_bounds__(64 * D::LV) void blind_rotate_fp_lat_kernel(
             const double* bko = bk_step + (size_t)((h * L + wave) * 2 + h) * NTT_N + (size_t)t * 2;
             const double* bkt = bk_step + (size_t)(((1 - h) * L + wave) * 2 + h) * NTT_N + (size_t)t * 2;
             // forward pass 1 of level `wave`
-            fp::fwd1_pre<D>(t, wave, ab, acc_h, x, C.zf);
+            fp::fwd1_pre<D>(t, wave, ab, acc_h, x, s_ztab);
             fp::ntt32_dif<fp::PASS1>(x, C.w);
             fp::fwd1_twiddle(t, x, s_twf);
             fp::xpose_write<false>(t, x, xb, false);
