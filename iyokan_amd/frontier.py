@@ -112,11 +112,10 @@ class PlainBitBackend:
         a[out] = res
 
     def write(self, slot, value):
-        self.arena[slot, 0] = int(value)
+        self.arena[slot, 0] = int(np.asarray(value).reshape(-1)[0])
 
     def write_many(self, slots, values):
-        for s_, v in zip(slots, values):
-            self.write(s_, v)
+        self.arena.numpy()[np.asarray(slots, dtype=np.int64), 0] = np.asarray(values, dtype=np.uint8).reshape(len(slots))
 
     def read(self, slot):
         return int(self.arena[slot, 0])

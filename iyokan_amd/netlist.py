@@ -249,6 +249,7 @@ class PlainSimulator:
         self.root = nl.roots()
         self.rins = [[self.root[j] for j in ins] for ins in nl.ins]
         self.dffs = [i for i, k in enumerate(nl.kinds) if k == "DFF"]
+        self._prog = None
         for i, v in nl.dff_init.items():
             self.val[i] = v
 
@@ -269,26 +270,45 @@ class PlainSimulator:
     def get_port(self, port):
         return sum(self.get_output(p, b) << b for (p, b) in self.nl.outputs if p == port)
 
-    def evaluate(self):
-        nl, v = self.nl, self.val
+    def _compile(self):
+        """Per level, per gate kind: (node ids, driver ids) as index arrays, so a clock of a 30 k-gate
+        system is a few hundred numpy gathers instead of a Python loop over gates."""
+        prog = []
         for lv in self.levels:
+            by_kind = defaultdict(list)
             for i in lv:
-                k, ins = nl.kinds[i], self.rins[i]
+                by_kind[self.nl.kinds[i]].append(i)
+            steps = []
+            for k, ids in by_kind.items():
+                idx = np.asarray(ids, dtype=np.int64)
+                ins = [np.asarray([self.rins[i][j] for i in ids], dtype=np.int64) for j in range(len(self.rins[ids[0]]))]
+                steps.append((k, idx, ins))
+            prog.append(steps)
+        self._prog = prog
+        self._dff_idx = np.asarray(self.dffs, dtype=np.int64)
+        self._dff_src = np.asarray([self.rins[i][0] for i in self.dffs], dtype=np.int64)
+
+    def evaluate(self):
+        if self._prog is None:
+            self._compile()
+        v = self.val
+        for steps in self._prog:
+            for k, idx, ins in steps:   # gates of one level are independent: any order within it
                 if k in _PLAIN:
-                    v[i] = _PLAIN[k](int(v[ins[0]]), int(v[ins[1]]))
+                    v[idx] = _PLAIN[k](v[ins[0]], v[ins[1]])
                 elif k == "MUX":
-                    v[i] = v[ins[1]] if v[ins[2]] else v[ins[0]]
+                    v[idx] = np.where(v[ins[2]] != 0, v[ins[1]], v[ins[0]])
                 elif k == "NOT":
-                    v[i] = 1 ^ v[ins[0]]
+                    v[idx] = 1 ^ v[ins[0]]
                 elif k == "CONSTONE":
-                    v[i] = 1
+                    v[idx] = 1
                 elif k == "CONSTZERO":
-                    v[i] = 0
+                    v[idx] = 0
 
     def tick(self):
-        nxt = [self.val[self.rins[i][0]] for i in self.dffs]   # two-phase: sample, then commit
-        for i, x in zip(self.dffs, nxt):
-            self.val[i] = x
+        if self._prog is None:
+            self._compile()
+        self.val[self._dff_idx] = self.val[self._dff_src]   # two-phase: the gather samples before the scatter commits
 
     def ram_image(self, nbits):
         return [int(self.val[self.nl.ram[i]]) for i in range(nbits)]

@@ -5,10 +5,16 @@ Covers the subset of Iyokan's TOML blueprint that the CAHP-with-MUX-memories sys
 
   [[file]]    type = "yosys-json" | "iyokanl1-json", path, name
   [[builtin]] type = "mux-rom" (in_addr_width, out_rdata_width)       -> makeROMWithMUX  (:2517-2593)
-              type = "mux-ram" (in_addr_width, in_wdata_width = out_rdata_width) -> precompiled 8/16/16 netlist (:2595-2628)
+              type = "mux-ram" (in_addr_width, in_wdata_width = out_rdata_width) -> makeRAMWithMUX (:2595-2762):
+                       the precompiled 8/16/16 netlist when its JSON is at hand, else the generated DMUX/MUX form
+              type = "rom" / "ram": the reference keeps these in CMUX memories evaluated by TFHEpp on the CPU
+                       (out of scope); they have the same ports and the same observable
+                       behaviour as the MUX forms (the reference's fixtures are shared between the two), so
+                       here they are LOWERED to the MUX forms and run on the gate path
   [connect]   "dst/port[a:b]" = "src/port[a:b]"   internal edge (dst input <- src output)
               "dst/port"      = "@name[a:b]"      system input  @name drives dst's input port
               "@name[a:b]"    = "src/port[a:b]"   system output @name reads src's output port
+              TOGND = ["@name[a:b]", ...]         declares (and thereby widens) @ports that drive nothing
 
 All sub-netlists are merged into ONE `Netlist`, connected inputs become alias wires of their drivers,
 so the plaintext simulator, the levelizer and the frontier executor run the whole system as a single
@@ -64,21 +70,65 @@ def make_rom_with_mux(in_addr_width, out_rdata_width):
     return nl
 
 
+def make_ram_with_mux(in_addr_width, data_width):
+    """MUX RAM, the structure of make1bitRAMWithMUX (/root/reference/src/iyokan.hpp:2648-2762): wren is
+    demultiplexed over the address bits (msb first: out0 = ANDNOT(in, a), out1 = AND(in, a)) into one
+    write-select per word; cell (addr, bit) = DFF fed by MUX(A = itself, B = wdata[bit], S = select[addr]);
+    the read side reduces the 2^aw cells of a bit with aw levels of MUX(even, odd, addr[i]), lsb first.
+    The select tree is shared by all data bits (the reference rebuilds it per bit; same function)."""
+    nl = N.Netlist()
+    addr = []
+    for i in range(in_addr_width):
+        nid = nl.add("INPUT")
+        nl.inputs[("addr", i)] = nid
+        addr.append(nid)
+    wren = nl.add("INPUT")
+    nl.inputs[("wren", 0)] = wren
+    sel = [wren]
+    for a in reversed(addr):
+        nxt = []
+        for src in sel:
+            nxt.append(nl.add("ANDNOT", [src, a]))
+            nxt.append(nl.add("AND", [src, a]))
+        sel = nxt
+    for bit in range(data_width):
+        wdata = nl.add("INPUT")
+        nl.inputs[("wdata", bit)] = wdata
+        work = []
+        for a in range(1 << in_addr_width):
+            mux = nl.add("MUX", [0, wdata, sel[a]])     # A patched below: the cell itself
+            ram = nl.add("DFF", [mux])
+            nl.ins[mux][0] = ram
+            nl.ram[a * data_width + bit] = ram
+            work.append(ram)
+        for i in range(in_addr_width):
+            work = [nl.add("MUX", [work[j], work[j + 1], addr[i]]) for j in range(0, len(work), 2)]
+        out = nl.add("OUTPUT", [work[0]])
+        nl.outputs[("rdata", bit)] = out
+    nl.validate()
+    return nl
+
+
 class System:
     """Merged netlist + where the blueprint's named things ended up."""
 
-    def __init__(self, nl, at_inputs, at_outputs, rom, ram):
+    def __init__(self, nl, at_inputs, at_outputs, rom, ram, at_widths=None, ram_shapes=None, rom_shapes=None):
         self.nl = nl
         self.at_inputs = at_inputs      # (name, bit) -> node id (INPUT)
         self.at_outputs = at_outputs    # (name, bit) -> node id
         self.rom = rom                  # builtin name -> {index: node id}
         self.ram = ram                  # builtin name -> {index: node id}
+        self.at_widths = at_widths or {}    # @port name -> declared width (incl. TOGND bits)
+        self.ram_shapes = ram_shapes or {}  # builtin name -> (addr width, data width)
+        self.rom_shapes = rom_shapes or {}
 
     def at_width(self, table, name):
+        if name in self.at_widths:
+            return self.at_widths[name]
         return 1 + max(b for (p, b) in table if p == name)
 
 
-def load_blueprint(path, mux_ram_json=None):
+def load_blueprint(path, mux_ram_dir=None):
     base = os.path.dirname(os.path.abspath(path))
     with open(path, "rb") as f:
         bp = tomli.load(f)
@@ -91,16 +141,26 @@ def load_blueprint(path, mux_ram_json=None):
             parts[fdesc["name"]] = N.load_iyokanl1_json(p)
         else:
             raise ValueError(f"Invalid file type: {fdesc['type']}")
+    ram_shapes, rom_shapes = {}, {}
     for b in bp.get("builtin", []):
-        if b["type"] == "mux-rom":
+        if b["type"] in ("mux-rom", "rom"):
             parts[b["name"]] = make_rom_with_mux(b["in_addr_width"], b["out_rdata_width"])
-        elif b["type"] == "mux-ram":
-            key = (b["in_addr_width"], b["in_wdata_width"], b["out_rdata_width"])
-            if key != (8, 16, 16):
-                raise ValueError(f"mux-ram {key}: only the precompiled 8/16/16 netlist is available")
-            parts[b["name"]] = N.load_iyokanl1_json(mux_ram_json or os.path.join(base, "mux-ram-8-16-16.min.json"), ram_width=16)
+            rom_shapes[b["name"]] = (b["in_addr_width"], b["out_rdata_width"])
+        elif b["type"] in ("mux-ram", "ram"):
+            if b["in_wdata_width"] != b["out_rdata_width"]:
+                raise ValueError("Invalid RAM size; RAM with different write/read data widths is not implemented")
+            # the reference embeds minimised netlists for some shapes (USE_PRECOMPILED_BINARY, iyokan.hpp:2609-2625):
+            # use the same file when it is at hand (next to the blueprint, one level up, or in mux_ram_dir)
+            fname = "mux-ram-{}-{}-{}.min.json".format(b["in_addr_width"], b["in_wdata_width"], b["out_rdata_width"])
+            cands = [os.path.join(d, fname) for d in ([mux_ram_dir] if mux_ram_dir else []) + [base, os.path.dirname(base)]]
+            pre = next((c for c in cands if os.path.exists(c)), None)
+            if pre:
+                parts[b["name"]] = N.load_iyokanl1_json(pre, ram_width=b["in_wdata_width"])
+            else:
+                parts[b["name"]] = make_ram_with_mux(b["in_addr_width"], b["in_wdata_width"])
+            ram_shapes[b["name"]] = (b["in_addr_width"], b["in_wdata_width"])
         else:
-            raise ValueError(f"unsupported builtin type {b['type']} (CMUX memories are out of scope)")
+            raise ValueError(f"Invalid builtin type: {b['type']}")
 
     # ---- merge: renumber every part into one node space ---------------------------------------
     nl = N.Netlist()
@@ -130,8 +190,22 @@ def load_blueprint(path, mux_ram_json=None):
         except KeyError:
             raise ValueError(f"no output port {node}/{port}[{bit}]")
 
-    at_inputs, at_outputs = {}, {}
+    at_inputs, at_outputs, at_widths = {}, {}, {}
+
+    def widen(name, bit):
+        at_widths[name] = max(at_widths.get(name, 0), bit + 1)
+
     for dst, src in bp.get("connect", {}).items():
+        if dst == "TOGND":
+            for port_str in src:
+                if not port_str.startswith("@"):
+                    raise ValueError(f"Invalid port name for TOGND: {port_str}")
+                _, gport, gbits = _parse_ports(port_str)
+                for gb in gbits:
+                    widen(gport, gb)
+            continue
+        if not dst or not src or (dst[0] == "@" and src[0] == "@"):
+            raise ValueError(f"Invalid connect: {dst} = {src}")
         dnode, dport, dbits = _parse_ports(dst)
         snode, sport, sbits = _parse_ports(src)
         if len(dbits) != len(sbits):
@@ -141,8 +215,10 @@ def load_blueprint(path, mux_ram_json=None):
                 if snode is None:
                     raise ValueError(f"Invalid connect: {dst} = {src}")
                 at_outputs.setdefault((dport, db), out_node(snode, sport, sb))
+                widen(dport, db)
             elif snode is None:                    # "node/port" = "@in"
                 at_inputs.setdefault((sport, sb), in_node(dnode, dport, db))
+                widen(sport, sb)
             else:                                  # internal edge: dst input becomes an alias of src output
                 d = in_node(dnode, dport, db)
                 nl.kinds[d] = "OUTPUT"
@@ -153,4 +229,4 @@ def load_blueprint(path, mux_ram_json=None):
     for name, cells in ram.items():
         nl.ram.update({(name, idx): nid for idx, nid in cells.items()})
     nl.validate()
-    return System(nl, at_inputs, at_outputs, rom, ram)
+    return System(nl, at_inputs, at_outputs, rom, ram, at_widths, ram_shapes, rom_shapes)

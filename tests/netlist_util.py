@@ -6,7 +6,16 @@ import tomli
 
 from iyokan_amd import netlist as N
 
-GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "netlists")
+REFTEST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reftest")
+
+
+def gold(name):
+    """Path of a fixture file by base name; tests/golden/reftest mirrors the layout of the reference's test/ tree."""
+    for sub in ("", "config-toml", "yosys-json", "iyokanl1-json", "in", "out"):
+        p = os.path.join(REFTEST, sub, name)
+        if os.path.exists(p):
+            return p
+    raise FileNotFoundError(name)
 
 
 def load_packet(path):

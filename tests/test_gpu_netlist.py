@@ -9,7 +9,7 @@ import pytest
 from iyokan_amd import client
 from iyokan_amd import netlist as N
 from iyokan_amd.frontier import FrontierExecutor, FrontierPlan, HipBackend
-from netlist_util import GOLD, drive_cycle, input_streams, load_packet
+from netlist_util import gold, drive_cycle, input_streams, load_packet
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -47,7 +47,7 @@ def _make(nl, keys, seed=100):
 
 
 def test_counter_4bit_on_gpu(gpu, keys128):
-    nl = N.load_iyokanl1_json(os.path.join(GOLD, "counter-4bit-iyokanl1.json"))
+    nl = N.load_iyokanl1_json(gold("counter-4bit-iyokanl1.json"))
     plan, be, ex, set_enc = _make(nl, keys128)
     set_enc("reset", 0, 1)
     ex.run()
@@ -63,8 +63,8 @@ def test_counter_4bit_on_gpu(gpu, keys128):
 def test_mux_ram_config3_two_clocks(gpu, keys128):
     """BASELINE config #3: mux-ram-8-16-16, inputs of test08 (fresh encryptions), RAM zero-initialised;
     clock 0 (18 985 blind rotations in 14 level batches) then a clock edge and clock 1."""
-    nl = N.load_iyokanl1_json(os.path.join(GOLD, "mux-ram-8-16-16.min.json"))
-    streams = input_streams(load_packet(os.path.join(GOLD, "test08.in")))
+    nl = N.load_iyokanl1_json(gold("mux-ram-8-16-16.min.json"))
+    streams = input_streams(load_packet(gold("test08.in")))
     plan, be, ex, set_enc = _make(nl, keys128)
     sim = N.PlainSimulator(nl)
     for c in range(2):
@@ -93,8 +93,8 @@ def test_cahp_system_config4_on_gpu(gpu, keys128):
 
     sysm = load_cahp()
     nl = sysm.nl
-    req = load_packet(os.path.join(GOLD, "test09.in"))
-    want = load_packet(os.path.join(GOLD, "test09-ruby.out"))
+    req = load_packet(gold("test09.in"))
+    want = load_packet(gold("test09-ruby.out"))
     mem = packet_memories(sysm, req)
     rom_nodes = {nid for cells in sysm.rom.values() for nid in cells.values()}
     plan = FrontierPlan(nl, 1)
@@ -121,6 +121,42 @@ def test_cahp_system_config4_on_gpu(gpu, keys128):
         got = client.decrypt_bits(keys128, be.read_many([plan.slot[nl.outputs[k]] for k in keys_]))
         assert N.bytes_from_bits(list(got)) == entry["bytes"], entry["name"]
     be.close()
+
+
+@pytest.mark.parametrize("blueprint,req,want,ncycles", [
+    ("counter-4bit.toml", "test13.in", "test13.out", 3),
+    ("addr-register-4bit.toml", "test16.in", "test16.out", 3),
+    ("div-8bit.toml", "test05.in", "test05.out", 1),
+    ("rom-4-8.toml", "test15.in", "test15.out", 1),
+    ("dff-reset.toml", "test23.in", "test23.out", 1),
+    ("mux-ram-addr8bit.toml", "test06.in", "test06.out", 16),
+    ("cahp-pearl-mux.toml", "test09.in", "test09-pearl.out", -1),
+])
+def test_reference_vectors_encrypted(gpu, keys128, blueprint, req, want, ncycles):
+    """The reference's cufhe-* cases (test.rb:314-346): request encrypted bit by bit, the blueprint run on
+    the GPU through the same runner as the plaintext cases (runner.run_packet + CipherEngine), the result
+    decrypted and compared with the expected packet."""
+    import torch
+
+    from iyokan_amd.packet import PlainPacket
+    from iyokan_amd.runner import CipherEngine, run_packet
+    from iyokan_amd.system import load_blueprint
+
+    sysm = load_blueprint(gold(blueprint))
+    plan = FrontierPlan(sysm.nl, 1)
+    be = HipBackend(plan.num_slots, keys128.params, torch.device("cuda", 0))
+    seed = {"v": 7000}
+
+    def encrypt(bits):
+        seed["v"] += 1
+        return client.encrypt_bits(keys128, bits, seed=seed["v"])
+
+    eng = CipherEngine(FrontierExecutor(plan, be), encrypt, lambda rows: client.decrypt_bits(keys128, rows),
+                       client.trivial(keys128.params, 0))
+    got = run_packet(sysm, PlainPacket.load(gold(req)), cycles=ncycles, engine=eng)
+    expected = PlainPacket.load(gold(want))
+    be.close()
+    assert got.same_content(expected), got.diff(expected)
 
 
 def test_cpp_host_runtime_on_gpu(gpu, keys128):

@@ -7,19 +7,19 @@ import pytest
 
 from iyokan_amd import netlist as N
 from iyokan_amd.frontier import FrontierExecutor, FrontierPlan, PlainBitBackend
-from netlist_util import GOLD, drive_cycle, input_streams, load_packet, run_plain
+from netlist_util import gold, drive_cycle, input_streams, load_packet, run_plain
 
 
 def test_counter_yosys_matches_test13():
-    nl = N.load_yosys_json(os.path.join(GOLD, "counter-4bit-yosys.json"))
-    want = load_packet(os.path.join(GOLD, "test13.out"))
+    nl = N.load_yosys_json(gold("counter-4bit-yosys.json"))
+    want = load_packet(gold("test13.out"))
     sim = run_plain(nl, {}, want["cycles"], use_reset=True)
     assert N.bytes_from_bits([sim.get_output("io_out", b) for b in range(4)]) == want["bits"][0]["bytes"]
 
 
 def test_counter_l1_sequence_like_test0():
     """/root/reference/src/test0.cpp:403-431: 16 clocks count 0..15."""
-    nl = N.load_iyokanl1_json(os.path.join(GOLD, "counter-4bit-iyokanl1.json"))
+    nl = N.load_iyokanl1_json(gold("counter-4bit-iyokanl1.json"))
     sim = N.PlainSimulator(nl)
     sim.set_input("reset", 0, 1)
     sim.evaluate()
@@ -33,8 +33,8 @@ def test_counter_l1_sequence_like_test0():
 @pytest.mark.parametrize("loader,name", [(N.load_yosys_json, "addr-4bit-yosys.json"),
                                          (N.load_iyokanl1_json, "addr-4bit-iyokanl1.json")])
 def test_adder_matches_test04(loader, name):
-    nl = loader(os.path.join(GOLD, name))
-    req, want = load_packet(os.path.join(GOLD, "test04.in")), load_packet(os.path.join(GOLD, "test04.out"))
+    nl = loader(gold(name))
+    req, want = load_packet(gold("test04.in")), load_packet(gold("test04.out"))
     streams = input_streams(req)
     port_a = "io_inA" if ("io_inA", 0) in nl.inputs else "A"
     port_b = "io_inB" if ("io_inB", 0) in nl.inputs else "B"
@@ -47,11 +47,11 @@ def test_adder_matches_test04(loader, name):
 
 def test_mux_ram_8_16_16_matches_test08():
     """BASELINE config #3 netlist, full 8-clock run of test.rb's `mux-ram-8-16-16` case."""
-    nl = N.load_iyokanl1_json(os.path.join(GOLD, "mux-ram-8-16-16.min.json"))
+    nl = N.load_iyokanl1_json(gold("mux-ram-8-16-16.min.json"))
     c = nl.counts()
     assert c["MUX"] == 5872 and c["DFF"] == 4096 and nl.rotations() == 18985
     assert len(nl.levelise()) == 14
-    req, want = load_packet(os.path.join(GOLD, "test08.in")), load_packet(os.path.join(GOLD, "test08.out"))
+    req, want = load_packet(gold("test08.in")), load_packet(gold("test08.out"))
     sim = run_plain(nl, input_streams(req), want["cycles"], use_reset=False)
     rdata = N.bytes_from_bits([sim.get_output("rdata", b) for b in range(16)])
     assert rdata == want["bits"][0]["bytes"]
@@ -59,7 +59,7 @@ def test_mux_ram_8_16_16_matches_test08():
 
 
 def test_cahp_ruby_statistics():
-    nl = N.load_yosys_json(os.path.join(GOLD, "cahp-ruby-core-yosys.json"))
+    nl = N.load_yosys_json(gold("cahp-ruby-core-yosys.json"))
     assert nl.rotations() == 4281 and len(nl.levelise()) == 41 and nl.counts()["DFF"] == 483
 
 
@@ -80,8 +80,8 @@ def _frontier_vs_sim(nl, streams, cycles, world, rank, dist):
 
 
 def test_frontier_single_rank_matches_simulator():
-    nl = N.load_iyokanl1_json(os.path.join(GOLD, "mux-ram-8-16-16.min.json"))
-    req = load_packet(os.path.join(GOLD, "test08.in"))
+    nl = N.load_iyokanl1_json(gold("mux-ram-8-16-16.min.json"))
+    req = load_packet(gold("test08.in"))
     _frontier_vs_sim(nl, input_streams(req), 3, 1, 0, None)
 
 
@@ -91,8 +91,8 @@ def _gloo_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        nl = N.load_iyokanl1_json(os.path.join(GOLD, "mux-ram-8-16-16.min.json"))
-        req = load_packet(os.path.join(GOLD, "test08.in"))
+        nl = N.load_iyokanl1_json(gold("mux-ram-8-16-16.min.json"))
+        req = load_packet(gold("test08.in"))
         ex = _frontier_vs_sim(nl, input_streams(req), 2, world, rank, dist)
         q.put((rank, ex.collectives))
     finally:
@@ -118,7 +118,7 @@ def test_frontier_two_ranks_gloo():
 
 
 def test_plan_shards_are_balanced():
-    nl = N.load_iyokanl1_json(os.path.join(GOLD, "mux-ram-8-16-16.min.json"))
+    nl = N.load_iyokanl1_json(gold("mux-ram-8-16-16.min.json"))
     plan = FrontierPlan(nl, 8)
     for L in plan.levels:
         sizes = [len(d[0]) for d in L["rank_desc"]]

@@ -7,11 +7,11 @@ import numpy as np
 from iyokan_amd import netlist as N
 from iyokan_amd.frontier import FrontierExecutor, FrontierPlan, PlainBitBackend
 from iyokan_amd.system import load_blueprint, make_rom_with_mux
-from netlist_util import GOLD, load_packet
+from netlist_util import gold, load_packet
 
 
 def load_cahp():
-    return load_blueprint(os.path.join(GOLD, "cahp-ruby-mux.toml"))
+    return load_blueprint(gold("cahp-ruby-mux.toml"))
 
 
 def packet_memories(sysm, req):
@@ -57,11 +57,11 @@ import pytest
 
 @pytest.mark.parametrize("core,rot", [("ruby", 4281), ("pearl", 3662)])
 def test_cahp_system_matches_test09(core, rot):
-    sysm = load_blueprint(os.path.join(GOLD, f"cahp-{core}-mux.toml"))
+    sysm = load_blueprint(gold(f"cahp-{core}-mux.toml"))
     nl = sysm.nl
     assert nl.rotations() == rot + 8128 + 18985     # core + ROM + RAM
-    req = load_packet(os.path.join(GOLD, "test09.in"))
-    want = load_packet(os.path.join(GOLD, f"test09-{core}.out"))
+    req = load_packet(gold("test09.in"))
+    want = load_packet(gold(f"test09-{core}.out"))
     sim = run_system_plain(sysm, req, want["cycles"])
     for entry in want["bits"]:
         name, size = entry["name"], entry["size"]
@@ -76,7 +76,7 @@ def test_cahp_system_frontier_plan_matches_simulator():
     is not meaningful, so world = 1) equals the simulator for 3 clocks."""
     sysm = load_cahp()
     nl = sysm.nl
-    req = load_packet(os.path.join(GOLD, "test09.in"))
+    req = load_packet(gold("test09.in"))
     mem = packet_memories(sysm, req)
     plan = FrontierPlan(nl, 1)
     ex = FrontierExecutor(plan, PlainBitBackend(plan.num_slots))

@@ -36,7 +36,7 @@ def main():
     from iyokan_amd import netlist as N
     from iyokan_amd.frontier import FrontierExecutor, FrontierPlan, HipBackend
     from iyokan_amd.params import params_128bit
-    from netlist_util import GOLD, drive_cycle, input_streams, load_packet
+    from netlist_util import gold, drive_cycle, input_streams, load_packet
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -49,10 +49,10 @@ def main():
     if kind == "blueprint":
         from iyokan_amd.system import load_blueprint
 
-        nl = load_blueprint(os.path.join(GOLD, fname)).nl
+        nl = load_blueprint(gold(fname)).nl
     else:
-        nl = (N.load_iyokanl1_json if kind == "l1" else N.load_yosys_json)(os.path.join(GOLD, fname))
-    streams = input_streams(load_packet(os.path.join(GOLD, pkt))) if pkt else {}
+        nl = (N.load_iyokanl1_json if kind == "l1" else N.load_yosys_json)(gold(fname))
+    streams = input_streams(load_packet(gold(pkt))) if pkt else {}
     p = params_128bit()
     keys = client.keygen(p, seed=1)   # deterministic: every rank derives identical keys (bench.py shows the RCCL broadcast)
     hip.initialize(keys, device_ids=(local,))
