@@ -104,6 +104,43 @@ IYK_HD void ntt32_dif(double (&a)[32], const double* w)
     }
 }
 
+// One HALF of the same 32-point DIF, for the two-waves-per-transform latency kernel: stage 0 yields the
+// 16 sums (HALF 0) or the 16 twiddled differences (HALF 1) of the inputs, stages 1..4 stay inside that
+// 16-block.  y[q] is position 16 * HALF + q of the full transform's output; operations, renormalisation
+// schedule (absolute positions) and therefore magnitudes are exactly those of ntt32_dif<PASS>.
+template <int PASS, int HALF>
+IYK_HD void ntt32_dif_half(const double (&x)[32], double (&y)[16], const double* w)
+{
+    constexpr const NormSched& S = PASS == PASS1 ? kSched1 : kSched2;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double u = x[j], v = x[j + 16];
+        if (HALF == 0) {
+            const double sum = u + v;
+            y[j] = S.sum[0][j] ? norm(sum) : sum;
+        }
+        else {
+            const double dif = u - v;
+            y[j] = (j == 0) ? (S.dif[0][16] ? norm(dif) : dif) : mulmod(dif, w[j]);
+        }
+    }
+#pragma unroll
+    for (int s = 1; s < 5; ++s) {
+        const int len = 16 >> s;
+#pragma unroll
+        for (int blk = 0; blk < 16; blk += 2 * len) {
+#pragma unroll
+            for (int j = 0; j < len; ++j) {
+                const int a = blk + j, b = blk + j + len;
+                const double u = y[a], v = y[b];
+                const double sum = u + v, dif = u - v;
+                y[a] = S.sum[s][16 * HALF + a] ? norm(sum) : sum;
+                y[b] = (j == 0) ? (S.dif[s][16 * HALF + b] ? norm(dif) : dif) : mulmod(dif, w[j << s]);
+            }
+        }
+    }
+}
+
 struct HostTables {
     NttConsts c;
     double tw_fwd[NTT_N];  // [j1][k2]

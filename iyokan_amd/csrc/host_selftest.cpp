@@ -272,6 +272,26 @@ static void test_fp50()
         fp_inverse(acc.data(), res.data(), T);
         for (int i = 0; i < 1024; ++i) CHECK(fp::to_torus32(res[i]) == ref[i]);
     }
+    // the two halves of the split DIF (two-waves-per-transform latency kernel) reproduce the full DIF bit for bit
+    for (int rep = 0; rep < 64; ++rep) {
+        double x1[32], x2[32], y0[16], y1[16];
+        for (int j = 0; j < 32; ++j) {
+            const double v = (double)(int64_t)(rnd() % (uint64_t)(fp::P_INT)) - fp::P / 2;   // |v| <= p/2
+            x1[j] = fp::norm(v);
+            x2[j] = fp::norm(v) * ((rep & 1) ? 1.0 : 1.0);
+        }
+        double a[32], b[32];
+        for (int j = 0; j < 32; ++j) { a[j] = x1[j]; b[j] = x2[j]; }
+        fp::ntt32_dif<fp::PASS1>(a, T.c.w);
+        fp::ntt32_dif_half<fp::PASS1, 0>(x1, y0, T.c.w);
+        fp::ntt32_dif_half<fp::PASS1, 1>(x1, y1, T.c.w);
+        for (int q = 0; q < 16; ++q) CHECK(a[q] == y0[q] && a[16 + q] == y1[q]);
+        for (int j = 0; j < 32; ++j) b[j] = x2[j] = fp::mulmod(a[j], T.tw_fwd[(rep % 32) * 32 + brv5(j)]);   // pass-2 sized inputs
+        fp::ntt32_dif<fp::PASS2>(b, T.c.w);
+        fp::ntt32_dif_half<fp::PASS2, 0>(x2, y0, T.c.w);
+        fp::ntt32_dif_half<fp::PASS2, 1>(x2, y1, T.c.w);
+        for (int q = 0; q < 16; ++q) CHECK(b[q] == y0[q] && b[16 + q] == y1[q]);
+    }
     CHECK(g_maxabs < 7.5);
     std::printf("fp50 worst-case external product ok (max |x|/p inside transforms = %.3f)\n", g_maxabs);
 }

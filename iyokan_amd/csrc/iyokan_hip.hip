@@ -55,6 +55,7 @@ struct Global {
     u32 ksk_stride = 0;
     bool use_fp = false;          // FP64 path (fp50.hpp) instead of Goldilocks integers
     int lat_threshold = 1280;      // rotations per batch at or below which the low-latency kernel is used
+    int lat2_threshold = 256;      // ... and at or below which its two-waves-per-level variant is used
     fp::NttConsts fpc{};
     std::vector<Device> devs;
     std::atomic<int> nstreams{0};
@@ -206,21 +207,46 @@ int launch_br_fp_lat(iyk_hip_stream* st, int first, int njobs, u32* d_tlwe1, int
     return IYK_OK;
 }
 
-// Measured (profiles/r01_sweep_kernels.txt): the wave-per-rotation kernel runs 2048 rotations per 28 ms
-// round; the one-wave-per-level kernel takes 7 ms for <= 256 and ~21 ms per 1024.  So: full 2048-rounds
-// on the former, a remainder of up to lat_threshold rotations on the latter.
+// narrowest frontiers: one rotation per workgroup of 2 L waves, each wave one half of every 32-point DIF
+// (kernels.hpp, blind_rotate_fp_lat2_kernel)
+template <class DC>
+int launch_br_fp_lat2(iyk_hip_stream* st, int first, int njobs, u32* d_tlwe1, int trlwe)
+{
+    static bool attr_set[64] = {};
+    const Device& D = G.devs[st->gpu];
+    auto kern = blind_rotate_fp_lat2_kernel<DC>;
+    constexpr int L = DC::LV;
+    constexpr size_t lds = BrLat2Lds<L>::BYTES;
+    if (!attr_set[st->gpu]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        attr_set[st->gpu] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3(128 * L), lds, st->s,
+                       (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE, njobs, (const double*)D.bk_ntt,
+                       (const double*)D.tw_fwd, (const double*)D.tw_inv, D.fpc,
+                       d_tlwe1 + (size_t)first * (trlwe ? 2 * NTT_N : NTT_N + 1), G.p.n, G.p.mu, ABAR_STRIDE, trlwe);
+    HIP_TRY(hipGetLastError());
+    return IYK_OK;
+}
+
+// Measured (profiles/r01_sweep_kernels.txt): the wave-per-rotation kernel runs 2048 rotations per 23 ms
+// round; the one-wave-per-level kernel takes 6.6 ms for <= 256 and ~19 ms per 1024; the two-waves-per-level
+// kernel is the fastest for at most lat2_threshold rotations (one workgroup per CU).  So: full 2048-rounds on
+// the first, a remainder of up to lat_threshold rotations on the second or third.
 template <class DC>
 int dispatch_fp(iyk_hip_stream* st, int njobs, u32* d_tlwe1, int trlwe)
 {
     int rc;
-    const char* lat = std::getenv("IYK_HIP_LATENCY_KERNEL");  // "0" disables, "1" forces (A/B, tests)
-    const bool force_on = lat && lat[0] == '1', force_off = lat && lat[0] == '0';
-    if (force_on) return launch_br_fp_lat<DC>(st, 0, njobs, d_tlwe1, trlwe);
-    if (force_off) return launch_br_fp<DC>(st, 0, njobs, d_tlwe1, trlwe);
+    const char* lat = std::getenv("IYK_HIP_LATENCY_KERNEL");  // "0" / "1" / "2" force one kernel (A/B, tests)
+    if (lat && lat[0] == '2') return launch_br_fp_lat2<DC>(st, 0, njobs, d_tlwe1, trlwe);
+    if (lat && lat[0] == '1') return launch_br_fp_lat<DC>(st, 0, njobs, d_tlwe1, trlwe);
+    if (lat && lat[0] == '0') return launch_br_fp<DC>(st, 0, njobs, d_tlwe1, trlwe);
     const int round = 2048;
     const int rem = njobs % round, full = njobs - rem;
     if (rem > G.lat_threshold) return launch_br_fp<DC>(st, 0, njobs, d_tlwe1, trlwe);
     if (full && (rc = launch_br_fp<DC>(st, 0, full, d_tlwe1, trlwe))) return rc;
+    if (rem && rem <= G.lat2_threshold) return launch_br_fp_lat2<DC>(st, full, rem, d_tlwe1, trlwe);
     if (rem) return launch_br_fp_lat<DC>(st, full, rem, d_tlwe1, trlwe);
     return IYK_OK;
 }

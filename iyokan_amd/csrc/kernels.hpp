@@ -588,6 +588,185 @@ __global__ __launch_bounds__(64 * D::LV) void blind_rotate_fp_lat_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Low-latency variant 2: ONE ROTATION PER WORKGROUP of 2 L wavefronts.  Wave (lvl, half) owns gadget level
+// lvl and one HALF of the outputs of each 32-point DIF of that level's transform (fpntt32.hpp,
+// ntt32_dif_half): it reads all 32 inputs of its column (lane = (h, t) as everywhere), runs stage 0 for its
+// half (the 16 sums, or the 16 twiddled differences) and stages 1..4 inside that 16-block.  So per step a
+// wave issues ~0.6x the instructions of the one-wave-per-level kernel; the price is that the two waves of a
+// level meet in LDS at every transpose (workgroup barriers instead of wave-local fences) and that both derive
+// all 32 digits of a column.  Every wave leaves its partial NTT-domain sum in its own share area; waves
+// (0, half) add them up and run the inverse transform, again one half of every DIF each.  Four workgroup
+// barriers per step.  Same arithmetic, same schedules, same bits.
+//
+// LDS (bytes): twiddles fwd + inv 16 K | twisted digits 16 K | accumulator 8 K (4 KB aligned polynomials) |
+// transposes [L][h][32][33] f64 (8448 each) | MAC share / partial sums [2L waves][h][16][32] f64.
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS operations (lgkmcnt), NOT for its
+// outstanding global loads — __syncthreads() would also drain vmcnt and so expose the latency of the key
+// rows prefetched at the top of the step at the very first barrier (measured: 0.5 ms of 6.5 per rotation).
+__device__ __forceinline__ void wg_barrier_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int LV>
+struct BrLat2Lds {
+    static constexpr size_t XPOSE = (size_t)LV * 2 * 32 * XB_STRIDE * sizeof(double);
+    static constexpr size_t SHARE = (size_t)2 * LV * 2 * 16 * 32 * sizeof(double);
+    static constexpr size_t FIXED = (2 * NTT_N + fp::ZTAB_ENTRIES) * sizeof(double) + 2 * NTT_N * sizeof(u32);
+    // the share area is separate when it fits (no barrier between the transposed reads and the share writes),
+    // otherwise it sits on the transpose buffers of its own level
+    static constexpr bool ALIAS_SHARE = FIXED + XPOSE + SHARE > 160 * 1024;
+    static constexpr size_t BYTES = FIXED + (ALIAS_SHARE ? XPOSE : XPOSE + SHARE);
+    static_assert(BYTES <= 160 * 1024, "latency kernel 2 does not fit the CU's LDS");
+    static_assert(!ALIAS_SHARE || 2 * 16 * 32 * sizeof(double) <= 32 * XB_STRIDE * sizeof(double), "share alias too small");
+};
+
+template <class D>
+__global__ __launch_bounds__(128 * D::LV) void blind_rotate_fp_lat2_kernel(
+    const u32* __restrict__ abar_all, int njobs, const double* __restrict__ bk_ntt,
+    const double* __restrict__ tw_fwd, const double* __restrict__ tw_inv, const fp::NttConsts* __restrict__ Cp,
+    u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride, int trlwe_mode)
+{
+    const fp::NttConsts& C = *Cp;
+    constexpr int L = D::LV;
+    typedef BrLat2Lds<L> M;
+    constexpr int NT = 128 * L;
+    extern __shared__ __attribute__((aligned(4096))) unsigned char smem[];
+    double* s_twf = reinterpret_cast<double*>(smem);                      // [k2][j1]
+    double* s_twi = s_twf + NTT_N;                                        // [j1][k2]
+    double* s_ztab = s_twi + NTT_N;                                       // [j2][digit + 32]
+    u32* acc_lds = reinterpret_cast<u32*>(s_ztab + fp::ZTAB_ENTRIES);     // [2][1024]
+    double* s_scr = reinterpret_cast<double*>(acc_lds + 2 * NTT_N);
+    double* s_xp = s_scr;                                                 // [L][2][32][33]
+
+    for (int e = threadIdx.x; e < NTT_N; e += NT) {
+        const int a = e >> 5, b = e & 31;
+        s_twf[b * 32 + a] = tw_fwd[e];
+        s_twi[b * 32 + a] = tw_inv[e];
+    }
+    for (int e = threadIdx.x; e < fp::ZTAB_ENTRIES; e += NT) s_ztab[e] = fp::ztab_entry(e, C.zf);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lvl = wave >> 1, half = wave & 1;
+    const int lane = threadIdx.x & 63;
+    const int h0 = lane >> 5, t0 = lane & 31;
+    const int job = blockIdx.x;
+    const u32* abar = abar_all + (size_t)job * abar_stride;
+    if (wave == 0) br_init_acc(h0, t0, abar[n], mu, acc_lds + h0 * NTT_N);
+    wg_barrier_lds();
+
+    double x[32], y[16], accum[16];
+
+    for (u32 i = 0; i < n; ++i) {
+        const u32 ab = abar[i];
+        const double* bk_step = bk_ntt + (size_t)i * (2 * L) * 2 * NTT_N;
+        int t = t0, h = h0;
+        asm volatile("" : "+v"(t), "+v"(h));
+        u32* acc_h = acc_lds + h * NTT_N;
+        double* xp = s_xp + (size_t)(lvl * 2 + h) * 32 * XB_STRIDE;      // this level's transpose buffer, polynomial h
+        // MAC share area of this wave: [h][16][32]
+        double* sh = M::ALIAS_SHARE ? s_xp + (size_t)(lvl * 2 + half) * 32 * XB_STRIDE
+                                    : s_scr + M::XPOSE / sizeof(double) + (size_t)wave * 2 * 16 * 32;
+        double* sh_own = sh + h * 16 * 32;
+        const double* sh_oth = sh + (1 - h) * 16 * 32;
+        const double* bko = bk_step + (size_t)((h * L + lvl) * 2 + h) * NTT_N + (size_t)t * 2 + half;
+        const double* bkt = bk_step + (size_t)(((1 - h) * L + lvl) * 2 + h) * NTT_N + (size_t)t * 2 + half;
+
+        // ---- forward transform of level lvl, this wave's half of each pass --------------------------
+        // key rows of this half: k1 = brv5(16 half + q) = 2 brv4(q) + half, at pair index brv4(q) of the device layout
+        double bo[16], bt[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            bo[q] = bko[(brv5(q) >> 1) * 64];
+            bt[q] = bkt[(brv5(q) >> 1) * 64];
+        }
+        fp::fwd1_pre<D>(t, lvl, ab, acc_h, x, s_ztab);
+        if (half == 0) fp::ntt32_dif_half<fp::PASS1, 0>(x, y, C.w);
+        else fp::ntt32_dif_half<fp::PASS1, 1>(x, y, C.w);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int k2 = half ? brv5(16 + q) : brv5(q);
+            xp[k2 * XB_STRIDE + t] = fp::mulmod(y[q], s_twf[k2 * 32 + t]);
+        }
+        wg_barrier_lds();
+#pragma unroll
+        for (int j = 0; j < 32; ++j) x[j] = xp[t * XB_STRIDE + j];
+        if (M::ALIAS_SHARE) wg_barrier_lds();  // both waves have read the transposes before the share area reuses them
+        if (half == 0) fp::ntt32_dif_half<fp::PASS2, 0>(x, y, C.w);
+        else fp::ntt32_dif_half<fp::PASS2, 1>(x, y, C.w);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sh_own[q * 32 + t] = y[q];
+        lds_sync();  // the other polynomial's spectrum sits in the other half of this same wave
+#pragma unroll
+        for (int q = 0; q < 16; ++q) accum[q] = fp::mulmod(y[q], bo[q]) + fp::mulmod(sh_oth[q * 32 + t], bt[q]);
+        if (L > 3) {  // L partial sums of <= 2.6 p each could exceed 2^53: reduce each first
+#pragma unroll
+            for (int q = 0; q < 16; ++q) accum[q] = fp::norm(accum[q]);
+        }
+        // ---- reduce over the levels + inverse transform (waves (0, half)) ----------------------------
+        // a wave's partial sums replace its own share area ([h][16][32], same shape): no one else touches it
+        lds_sync();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sh_own[q * 32 + t] = accum[q];
+        wg_barrier_lds();
+        if (lvl == 0) {
+#pragma unroll
+            for (int k1 = 0; k1 < 32; ++k1) {
+                // k1 = brv5(16 hf + q): hf = k1 & 1, q = brv5(k1 & 30); written by waves (l, hf), l = 0 .. L-1
+                const int hf = k1 & 1, q = brv5(k1 & 30);
+                double sum = 0.0;
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    const double* src = M::ALIAS_SHARE ? s_xp + (size_t)(l * 2 + hf) * 32 * XB_STRIDE
+                                                       : s_scr + M::XPOSE / sizeof(double) + (size_t)(l * 2 + hf) * 2 * 16 * 32;
+                    const double v = src[(h * 16 + q) * 32 + t];
+                    sum = l ? sum + v : v;
+                }
+                x[k1] = fp::norm(sum);
+            }
+        }
+        if (M::ALIAS_SHARE) wg_barrier_lds();  // the inverse transpose reuses level 0's buffers = share areas just read
+        double* xpi = s_xp + (size_t)h * 32 * XB_STRIDE;
+        if (lvl == 0) {
+            if (half == 0) fp::ntt32_dif_half<fp::PASS1, 0>(x, y, C.w);
+            else fp::ntt32_dif_half<fp::PASS1, 1>(x, y, C.w);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int j1 = half ? inv_index(16 + q) : inv_index(q);
+                xpi[j1 * XB_STRIDE + t] = fp::mulmod(y[q], s_twi[j1 * 32 + t]);
+            }
+        }
+        wg_barrier_lds();
+        if (lvl == 0) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) x[j] = xpi[t * XB_STRIDE + j];
+            if (half == 0) fp::ntt32_dif_half<fp::PASS2, 0>(x, y, C.w);
+            else fp::ntt32_dif_half<fp::PASS2, 1>(x, y, C.w);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int j2 = half ? inv_index(16 + q) : inv_index(q);
+                const double v = fp::norm(j2 == 0 ? y[q] : fp::mulmod(y[q], C.zi[j2]));
+                acc_h[t + 32 * j2] += fp::to_torus32(v);
+            }
+        }
+        wg_barrier_lds();  // accumulator of step i is complete before anyone derives step i+1's digits
+    }
+
+    if (wave == 0) {
+        if (trlwe_mode) {  // raw accumulator: TRLWE (a(X), b(X)), 2N words per job
+            u32* out = tlwe1_out + (size_t)job * (2 * NTT_N);
+            for (int j = lane; j < 2 * NTT_N; j += 64) out[j] = acc_lds[j];
+        }
+        else {
+            u32* out = tlwe1_out + (size_t)job * (NTT_N + 1);
+            for (int j = lane; j < NTT_N; j += 64) out[j] = (j == 0) ? acc_lds[0] : 0u - acc_lds[NTT_N - j];
+            if (lane == 0) out[NTT_N] = acc_lds[NTT_N];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // TRLWE -> TLWE lvl1 at index 0 (TFHEpp SampleExtractIndex(., 0)): a'[0] = a[0], a'[j] = -a[N-j], b' = b[0].
 // src_index[job] selects the TRLWE; rows of N+1 words are written to `rot` for the key switch.
 __global__ __launch_bounds__(256) void sample_extract_kernel(const u32* __restrict__ trlwe,

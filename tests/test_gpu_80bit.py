@@ -10,12 +10,16 @@ from iyokan_amd.params import OPS, PLAIN
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("path", ["fp50", "goldilocks"])
-def test_80bit_gates_bit_exact(path, keys80, oracle80):
-    """Both exact-arithmetic paths at the 80-bit set: FP64 field with split digits (default) and the
-    64-bit integer field (IYK_HIP_NTT=goldilocks)."""
+@pytest.mark.parametrize("path,kernel", [("fp50", "0"), ("fp50", "1"), ("fp50", "2"), ("goldilocks", None)])
+def test_80bit_gates_bit_exact(path, kernel, keys80, oracle80, monkeypatch):
+    """Both exact-arithmetic paths at the 80-bit set: FP64 field with split digits (default; each of its
+    three rotation kernels forced in turn) and the 64-bit integer field (IYK_HIP_NTT=goldilocks)."""
     from iyokan_amd import hip
 
+    if kernel is None:
+        monkeypatch.delenv("IYK_HIP_LATENCY_KERNEL", raising=False)
+    else:
+        monkeypatch.setenv("IYK_HIP_LATENCY_KERNEL", kernel)
     old = os.environ.get("IYK_HIP_NTT")
     if path == "goldilocks":
         os.environ["IYK_HIP_NTT"] = "goldilocks"

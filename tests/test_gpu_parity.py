@@ -213,9 +213,10 @@ def test_full_size_flat_nand_property(gpu128, keys128, oracle128):
     assert np.array_equal(got[sample], ref[nin:])
 
 
-def test_both_rotation_kernels_agree(gpu128, keys128, oracle128):
-    """The wave-per-rotation kernel and the 3-wave low-latency kernel (IYK_HIP_LATENCY_KERNEL=0/1 forces
-    one or the other; default picks by batch size) must produce identical ciphertexts, equal to the oracle."""
+def test_all_rotation_kernels_agree(gpu128, keys128, oracle128):
+    """The wave-per-rotation kernel, the wave-per-level and the two-waves-per-level low-latency kernels
+    (IYK_HIP_LATENCY_KERNEL=0/1/2 forces one; default picks by batch size) must produce identical
+    ciphertexts, equal to the oracle."""
     hip, st = gpu128
     p = keys128.params
     rng = np.random.default_rng(41)
@@ -230,7 +231,7 @@ def test_both_rotation_kernels_agree(gpu128, keys128, oracle128):
     results = {}
     old = os.environ.get("IYK_HIP_LATENCY_KERNEL")
     try:
-        for mode in ("0", "1"):
+        for mode in ("0", "1", "2"):
             os.environ["IYK_HIP_LATENCY_KERNEL"] = mode
             results[mode] = _run(hip, st, host, ops, in0, in1, in2, out)
     finally:
@@ -239,6 +240,7 @@ def test_both_rotation_kernels_agree(gpu128, keys128, oracle128):
         else:
             os.environ["IYK_HIP_LATENCY_KERNEL"] = old
     assert np.array_equal(results["0"], results["1"])
+    assert np.array_equal(results["0"], results["2"])
     ref = host.copy()
     oracle128.gate_batch(ops, in0, in1, in2, out, ref, nthreads=os.cpu_count() or 1)
     assert np.array_equal(results["0"], ref)

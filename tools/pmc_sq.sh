@@ -10,11 +10,13 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
            "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" \
-           "SQ_INST_CYCLES_VMEM_RD SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_SMEM"; do
+           "SQ_INST_CYCLES_VMEM_RD SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_SMEM" \
+           "SQ_WAIT_INST_VMEM SQ_WAIT_INST_SCA SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU" \
+           "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_WAVE32 SQ_WAVES"; do
     i=$((i+1))
     d=/tmp/pmc_$tag_$i
     rm -rf $d
-    timeout 300 rocprofv3 --pmc $grp -d $d -o pmc -- python bench.py --gates 8192 --steps 1 --warmup 0 --cpu-sample 0 > /tmp/pmc_$i.log 2>&1
+    timeout 300 rocprofv3 --pmc $grp -d $d -o pmc -- python bench.py --gates ${GATES:-8192} --steps 1 --warmup 0 --cpu-sample 0 > /tmp/pmc_$i.log 2>&1
     db=$(find $d -name "*.db" | head -1)
     if [ -n "$db" ]; then python tools/rocprof_summary.py $db --pmc | grep "blind_rotate" >> $out; else echo "# group failed: $grp" >> $out; tail -3 /tmp/pmc_$i.log >> $out; fi
 done
