@@ -221,7 +221,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("u32 torus; NTT in f64 mod 2^50-16383 (exact FMA arithmetic)" if fp_path
+            "dtype": ("u32 torus; NTT in f64 mod p = 3*2^48+1097729 (exact FMA arithmetic)" if fp_path
                       else "u32 torus; NTT in u64 mod 2^64-2^32+1"),
             "data": "synthetic",
             "config": {

@@ -174,7 +174,7 @@ int iyk_hip_timing_log_begin(iyk_hip_stream* st);
 int iyk_hip_timing_log_end(iyk_hip_stream* st, uint64_t* batches, double* blind_rotate_ms,
                            double* keyswitch_ms);
 
-/* Which exact-arithmetic field the blind rotation runs in: 1 = p = 2^50 - 16383 on the FP64 FMA
+/* Which exact-arithmetic field the blind rotation runs in: 1 = p = 3 * 2^48 + 1097729 on the FP64 FMA
  * pipe (default where its exactness bound holds: the 128-bit set), 0 = 2^64 - 2^32 + 1 in 64-bit
  * integers (80-bit set, or forced with the environment variable IYK_HIP_NTT=goldilocks at init).
  * Both give results bit-identical to the oracle. */

@@ -1,7 +1,7 @@
 // blind_rotate_fp.hpp — per-lane phases of one CMUX step on the FP64 path (fp50.hpp).
 //
 // Identical lane layout, LDS layout and pass structure to blind_rotate_core.hpp (v3); only the
-// field changes: residues mod p = 2^50 - 16383 held as lazily-reduced integers in doubles, exact
+// field changes: residues mod p = 3 * 2^48 + 1097729 held as lazily-reduced integers in doubles, exact
 // FMA arithmetic, general twiddles.  BK is stored in the same device layout (bk_dev_index) as
 // balanced doubles, 8 bytes per coefficient — the algorithmic byte count is unchanged.
 // Instruction budget per CMUX step and lane: ~9.5 k VALU vs ~31 k on the integer path.

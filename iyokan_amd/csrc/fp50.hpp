@@ -1,17 +1,19 @@
-// fp50.hpp — exact arithmetic in Z_p, p = 2^50 - 16383, on the FP64 FMA pipe.
+// fp50.hpp — exact arithmetic in Z_p, p = 3 * 2^48 + 1097729 (a 50-bit prime), on the FP64 FMA pipe.
 //
 // Why: the Goldilocks path (goldilocks.hpp) costs ~30 integer VALU instructions per radix-2
 // butterfly on gfx950 and sits at the integer-issue ceiling.  IEEE-754 double
 // FMA gives EXACT modular products of 50-bit residues in 6 instructions (TwoProduct + Barrett
-// quotient by rint), and v_fma_f64 / v_mul_f64 / v_add_f64 / v_rndne_f64 issue at the same rate
-// as 64-bit integer ops (profiles/r01_ubench_valu_occupancy.txt).  Residues are integers held in
-// doubles in a LAZY BALANCED range |x| <= K p with K p < 2^53, so additions need no correction.
+// quotient by rint).  Residues are integers held in doubles in a LAZY BALANCED range |x| <= K p with
+// K p < 2^53, so additions need no correction.
 //
 // Exactness of the external product needs p > 2 |sum|.  With the gadget digits |d| <= Bg/2 and
 // the bootstrapping key lifted as SIGNED 32-bit (same result mod 2^32):
-//     |sum| <= (k+1) l N (Bg/2) 2^31 = 6 * 1024 * 32 * 2^31 = 2^48.58  (128-bit set)  <  p / 2.67
-// so the centred representative of the NTT result IS the integer convolution.  (The 80-bit set,
-// Bg/2 = 512, would need p > 2^53: it stays on the Goldilocks path.)
+//     |sum| <= (k+1) l N (Bg/2) 2^31 = 6 * 1024 * 32 * 2^31 = 0.375 * 2^50   (128-bit set)
+// so the centred representative of the NTT result IS the integer convolution as soon as p > 0.75 * 2^50.
+// p is the smallest prime = 1 (mod 2048) above that (plus 2^20 of slack): the smaller p, the more lazy
+// headroom — 2^53 / p = 10.67 — and the fewer renormalisations the transforms need (fpntt32.hpp: 20 per
+// transform; the earlier choice p = 2^50 - 16383, headroom 8, needed 33).  The 80-bit set splits its
+// digits (blind_rotate_fp.hpp, Decomp) so that its |sum| <= 0.25 * 2^50 fits the same field.
 //
 // Every operation below is a single correctly-rounded IEEE operation (compile with
 // -ffp-contract=off so nothing is fused behind our back); the same code runs on host and device
@@ -31,16 +33,20 @@
 namespace iyk {
 namespace fp {
 
-static constexpr uint64_t P_INT = 1125899906826241ull;  // 2^50 - 16383, prime, = 1 (mod 16384)
-static constexpr double P = 1125899906826241.0;
-static constexpr double U = 1.0 / 1125899906826241.0;   // correctly rounded 1/p
-static constexpr uint64_t GENERATOR = 22;
+static constexpr uint64_t P_INT = 844424931229697ull;  // 3 * 2^48 + 1097729 = 0x300000010c001, prime, = 1 (mod 2048)
+static constexpr double P = 844424931229697.0;
+static constexpr double U = 1.0 / 844424931229697.0;   // correctly rounded 1/p
+static constexpr uint64_t GENERATOR = 3;               // 3^((p-1)/2048) has order exactly 2048
+static constexpr double HEADROOM = 9007199254740992.0 / 844424931229697.0;  // 2^53 / p = 10.67: |x| must stay below this many p
+// a mulmod whose first operand is bounded by A p (second: |b| <= p/2) returns |r| <= (0.5 + MM_SLOPE A) p:
+// quotient estimate off by <= 0.5 + A p / 2^53, plus the low half of the product, <= A p^2 / 2^54
+static constexpr double MM_SLOPE = 1.5 * 844424931229697.0 / 9007199254740992.0;  // 0.1406
 
 IYK_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 IYK_HD double rint_(double x) { return __builtin_rint(x); }  // round to nearest even (v_rndne_f64)
 
-// a*b mod p for integers |a| <= 5p, |b| <= p/2 held in doubles; result r = a*b (mod p), an
-// integer with |r| <= (0.5 + 3A/16) p where |a| <= A p (see DESIGN.md §4.1 "FP64 path").
+// a*b mod p for integers |a| <= A p < 2^53, |b| <= p/2 held in doubles; result r = a*b (mod p), an
+// integer with |r| <= (0.5 + MM_SLOPE A) p (see DESIGN.md §4.1 "FP64 path").
 //   h + l = a*b exactly (TwoProduct); q = rint(h/p); r = (h - q p) + l, each step exact.
 IYK_HD double mulmod(double a, double b)
 {

@@ -7,16 +7,16 @@
 // with zeta = psi^32 (order 64), w32 = zeta^2.  Inverse = forward DIF with the output index
 // negated, tw_inv[k2][j1] = psi^(-j1(2k2+1)) / N, post-twist zeta^(-j2).
 //
-// Magnitude discipline (units of p; every value must stay < 8 = 2^53 / p so that all additions are
-// exact integers).  A mulmod whose first operand is bounded by A p returns |r| <= (0.5 + 3A/16) p.
+// Magnitude discipline (units of p; every value must stay < HEADROOM = 2^53 / p = 10.67 so that all
+// additions are exact integers).  A mulmod whose first operand is bounded by A p returns
+// |r| <= (0.5 + MM_SLOPE A) p, MM_SLOPE = 0.1406 (fp50.hpp).
 // Bounds are propagated at COMPILE TIME through the butterfly network (make_norm_sched) and a sum /
 // twiddle-free difference is renormalised exactly where its static bound would exceed the per-stage
 // threshold.  Two schedules, one per pass of the four-step transform, chained by static_asserts:
-//   PASS1 (inputs <= 0.51 p: digits times twist, or a renormalised accumulator): 10 norms,
-//         outputs <= 7.03 p -> the inter-pass twiddle mulmod returns <= 1.82 p
-//   PASS2 (inputs <= 1.82 p): 23 norms, outputs <= 4.08 p -> each MAC term is <= 1.27 p, six of them
-//         (three gadget levels x two rows) stay below 7.6 p; no intermediate exceeds 7.46 p
-// (a single schedule good for both passes needs 34 + 34 norms of 3 instructions each).
+//   PASS1 (inputs <= 0.51 p: digits times twist, or a renormalised accumulator): 5 norms,
+//         outputs <= 7.55 p -> the inter-pass twiddle mulmod returns <= 1.57 p
+//   PASS2 (inputs <= 1.57 p): 15 norms, outputs <= 5.93 p -> each MAC term is <= 1.34 p, six of them
+//         (three gadget levels x two rows) stay below 8.1 p; no intermediate exceeds 8.16 p
 // host_selftest.cpp / the emulation tests track the observed maxima against these bounds.
 #pragma once
 #include "fp50.hpp"
@@ -42,7 +42,7 @@ struct NormSched {
 struct NormThresholds {
     double beta[5];
 };
-constexpr double mm_bound(double t) { return 0.5 + 3.0 * t / 16.0; }
+constexpr double mm_bound(double t) { return 0.5 + MM_SLOPE * t; }
 static constexpr double NORM_BOUND = 0.51;  // |norm(x)| <= p/2 + 1
 constexpr NormSched make_norm_sched(double b0, NormThresholds th)
 {
@@ -73,15 +73,16 @@ constexpr NormSched make_norm_sched(double b0, NormThresholds th)
 }
 enum { PASS1 = 0, PASS2 = 1 };
 static constexpr double PASS1_INPUT_BOUND = NORM_BOUND;
-static constexpr NormSched kSched1 = make_norm_sched(PASS1_INPUT_BOUND, {{1.25, 2.25, 3.0, 4.0, 1e9}});
+static constexpr NormSched kSched1 = make_norm_sched(PASS1_INPUT_BOUND, {{1.5, 2.5, 4.5, 5.5, 1e9}});
 static constexpr double PASS2_INPUT_BOUND = mm_bound(kSched1.out_bound);  // after the inter-pass twiddle
-static constexpr NormSched kSched2 = make_norm_sched(PASS2_INPUT_BOUND, {{3.75, 5.0, 3.75, 2.5, 1e9}});
+static constexpr NormSched kSched2 = make_norm_sched(PASS2_INPUT_BOUND, {{3.5, 2.0, 3.0, 5.0, 1e9}});
 static constexpr double MAC_TERM_BOUND = mm_bound(kSched2.out_bound);
-static_assert(kSched1.mid_bound < 7.5 && kSched1.out_bound < 7.5, "pass-1 magnitude discipline violated");
-static_assert(kSched2.mid_bound < 7.5 && kSched2.out_bound < 7.5, "pass-2 magnitude discipline violated");
-static_assert(6 * MAC_TERM_BOUND < 7.9, "six MAC terms must stay below 2^53");
-static_assert(NORM_BOUND + 4 * MAC_TERM_BOUND < 7.9, "LV = 4: renormalised half sum + four more terms");
-static_assert(kSched1.norms == 10 && kSched2.norms == 23, "schedule changed: update the comments");
+static constexpr double SAFE = 0.95 * HEADROOM;  // 5 % slack below 2^53 on every statically bounded quantity
+static_assert(kSched1.mid_bound < SAFE && kSched1.out_bound < SAFE, "pass-1 magnitude discipline violated");
+static_assert(kSched2.mid_bound < SAFE && kSched2.out_bound < SAFE, "pass-2 magnitude discipline violated");
+static_assert(6 * MAC_TERM_BOUND < SAFE, "six MAC terms must stay below 2^53");
+static_assert(NORM_BOUND + 4 * MAC_TERM_BOUND < SAFE, "LV = 4: renormalised half sum + four more terms");
+static_assert(kSched1.norms == 5 && kSched2.norms == 15, "schedule changed: update the comments");
 
 // cyclic 32-point DIF, natural in, bit-reversed out; twiddle of position j at stage s is w[j << s]
 template <int PASS>

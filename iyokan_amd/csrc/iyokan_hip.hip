@@ -4,7 +4,7 @@
 // twiddle tables) per GPU, streams with their (double-buffered) staging buffers, and turns a batch of
 // gate descriptors into a fixed launch sequence: elementwise (NOT/COPY/CONST), modswitch, blind rotation
 // (wave-per-rotation kernel for full rounds of 2048 + 3-wave kernel for the remainder), keyswitch_init +
-// keyswitch.  Chooses the exact-arithmetic field at init (FP64 p = 2^50-16383 where its bound holds,
+// keyswitch.  Chooses the exact-arithmetic field at init (FP64 p = 3*2^48+1097729 where its bound holds,
 // else / on request the 64-bit Goldilocks integers).  Replaces the cuFHE host API used at
 // /root/reference/src/iyokan_cufhe.cpp:530-536,721 and /root/reference/src/iyokan_cufhe.hpp:8-27,249-261.
 #include <hip/hip_runtime.h>
@@ -41,7 +41,7 @@ int fail(int code, const std::string& msg)
 
 struct Device {
     int ordinal = -1;
-    u64* bk_ntt = nullptr;   // NTT-domain BK: u64 residues mod 2^64-2^32+1, or doubles mod 2^50-16383 (fp path)
+    u64* bk_ntt = nullptr;   // NTT-domain BK: u64 residues mod 2^64-2^32+1, or doubles mod p = 3*2^48+1097729 (fp path)
     u32* ksk = nullptr;
     u64* tw_fwd = nullptr;   // u64 or double tables, same size
     u64* tw_inv = nullptr;
@@ -341,7 +341,7 @@ int iyk_hip_get_params(iyk_params* out)
     return IYK_OK;
 }
 
-/* 1 = FP64 field path (p = 2^50 - 16383), 0 = Goldilocks integer path */
+/* 1 = FP64 field path (p = 3 * 2^48 + 1097729), 0 = Goldilocks integer path */
 int iyk_hip_ntt_path(void) { return G.init ? (G.use_fp ? 1 : 0) : IYK_ERR_STATE; }
 
 int iyk_hip_resident_key_bytes(uint64_t* out)
@@ -370,7 +370,7 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
     HIP_TRY(hipGetDeviceCount(&avail));
     if (avail < 1) return fail(IYK_ERR_HIP, "no HIP device visible");
 
-    // Path choice: the FP64 field (p = 2^50 - 16383) is exact iff 2 * (k+1) l N (Bg/2) 2^31 < p
+    // Path choice: the FP64 field (p = 3 * 2^48 + 1097729) is exact iff 2 * (k+1) l N (Bg/2) 2^31 < p
     // (fp50.hpp); true for the 128-bit set, false for the 80-bit one.  IYK_HIP_NTT=goldilocks forces
     // the 64-bit integer path (kept as the cross-check and for A/B measurements).
     // (128-bit set: 3 levels of 6-bit digits; 80-bit set: each 10-bit digit split into two 5-bit halves,

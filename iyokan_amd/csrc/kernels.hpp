@@ -249,7 +249,7 @@ static constexpr size_t BR_LDS_BYTES = 2 * NTT_N * sizeof(u64) + (size_t)BR_WAVE
 
 // ------------------------------------------------------------------------------------------
 // FP64 path (fp50.hpp / blind_rotate_fp.hpp): same launch geometry, LDS layout and pass
-// structure as blind_rotate_kernel, arithmetic mod p = 2^50 - 16383 on the FMA pipe.
+// structure as blind_rotate_kernel, arithmetic mod p = 3 * 2^48 + 1097729 (fp50.hpp) on the FMA pipe.
 // BK rows for the FP path: [n][c][v][cc] with v a VIRTUAL level (Decomp): source row c*L + v/split,
 // coefficients scaled by 2^hb (mod 2^32) for the hi part, lifted as signed 32-bit.
 __global__ __launch_bounds__(64) void bk_ntt_fp_kernel(const u32* __restrict__ bk, double* __restrict__ bk_ntt,
@@ -390,8 +390,8 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
                 }
                 lds_sync();
             }
-            // magnitude discipline: each level adds two terms of <= 1.27 p; with 4 virtual levels the
-            // running sum is renormalised half way so it can never reach 2^53 (8 p)
+            // magnitude discipline: each level adds two terms of <= 1.34 p; with 4 virtual levels the
+            // running sum is renormalised half way so it can never reach 2^53 (10.67 p)
             if (L > 3 && lvl == 1) {
 #pragma unroll
                 for (int q = 0; q < 32; ++q) accum[q] = fp::norm(accum[q]);
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(64 * D::LV) void blind_rotate_fp_lat_kernel(
                 lds_sync();
             }
         }
-        if (L > 3) {  // L partial sums of <= 2.2 p each could exceed 2^53: reduce each first
+        if (L > 3) {  // L partial sums of <= 2.7 p each could exceed 2^53: reduce each first
 #pragma unroll
             for (int q = 0; q < 32; ++q) accum[q] = fp::norm(accum[q]);
         }
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(128 * D::LV) void blind_rotate_fp_lat2_kernel(
         lds_sync();  // the other polynomial's spectrum sits in the other half of this same wave
 #pragma unroll
         for (int q = 0; q < 16; ++q) accum[q] = fp::mulmod(y[q], bo[q]) + fp::mulmod(sh_oth[q * 32 + t], bt[q]);
-        if (L > 3) {  // L partial sums of <= 2.6 p each could exceed 2^53: reduce each first
+        if (L > 3) {  // L partial sums of <= 2.7 p each could exceed 2^53: reduce each first
 #pragma unroll
             for (int q = 0; q < 16; ++q) accum[q] = fp::norm(accum[q]);
         }
