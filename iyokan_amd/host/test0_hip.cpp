@@ -4,17 +4,23 @@
 // `--hip`, for the MI355X backend on fresh encryptions and on trivial ciphertexts (the
 // reference's GPU tests use only trivial ones: /root/reference/src/test0.cpp:702-710).
 // Known answers: NOT :56-67, MUX :86-94, binary gates :130-136, sequential circuit :368-389,
-// 4-bit counter sequence :403-431 (here built gate by gate instead of read from JSON).
+// 4-bit counter sequence :403-431 (built gate by gate, and read from JSON); the circuits read from
+// Iyokan-L1 JSON :157-334 (pass / and / and-4_2 / mux / addr / register) with readers.hpp, plus the same
+// adder and counter read from their Yosys JSON.
 //
-//   test0_hip            plain backend only (runs anywhere)
-//   test0_hip --hip      plain + HIP backend (needs a GPU)
+//   test0_hip                       plain backend only (runs anywhere)
+//   test0_hip --hip                 plain + HIP backend (needs a GPU)
+//   test0_hip --fixtures DIR ...    also the JSON circuits; DIR mirrors the reference's test/ tree
 #include <array>
 #include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
 
+#include <fstream>
+
 #include "iyokan_hip.hpp"
+#include "readers.hpp"
 
 using namespace iyk::host;
 
@@ -256,9 +262,121 @@ void testShiftRegister(H& h)
     }
 }
 
+// ---- circuits read from JSON (/root/reference/src/test0.cpp:157-334, 403-431) ----------------
+static std::string g_fixtures;  // directory laid out like the reference's test/ (iyokanl1-json/, yosys-json/)
+
+template <class H>
+typename H::Net loadNet(typename H::Factory& f, const std::string& rel, bool yosys)
+{
+    std::ifstream ifs(g_fixtures + "/" + rel);
+    if (!ifs) {
+        std::printf("FAIL cannot open fixture %s/%s\n", g_fixtures.c_str(), rel.c_str());
+        std::exit(1);
+    }
+    return yosys ? readNetworkFromYosysJSON<typename H::Builder>(f, ifs) : readNetworkFromJSON<typename H::Builder>(f, ifs);
+}
+template <class H>
+void setPort(H& h, typename H::Net& net, const char* port, int width, unsigned v)
+{
+    for (int i = 0; i < width; ++i) h.set(net, port, i, (v >> i) & 1);
+}
+template <class H>
+unsigned getPort(H& h, typename H::Net& net, const char* port, int width)
+{
+    unsigned v = 0;
+    for (int i = 0; i < width; ++i) v |= (unsigned)h.out(net, port, i) << i;
+    return v;
+}
+
+template <class H>
+void testFromJSON(H& h)
+{
+    {   // pass-4bit: out = in
+        typename H::Factory f;
+        auto net = loadNet<H>(f, "iyokanl1-json/pass-4bit-iyokanl1.json", false);
+        setPort(h, net, "io_in", 4, 0b0110);
+        h.run(net, f);
+        CHECK(getPort(h, net, "io_out", 4) == 0b0110);
+    }
+    {   // and-4bit: 0b1100 & 0b1010 = 0b1000
+        typename H::Factory f;
+        auto net = loadNet<H>(f, "iyokanl1-json/and-4bit-iyokanl1.json", false);
+        setPort(h, net, "io_inA", 4, 0b1100);
+        setPort(h, net, "io_inB", 4, 0b1010);
+        h.run(net, f);
+        CHECK(getPort(h, net, "io_out", 4) == 0b1000);
+    }
+    {   // and-4_2bit: (0b1101 & 0b1111) -> low two bits 0b01
+        typename H::Factory f;
+        auto net = loadNet<H>(f, "iyokanl1-json/and-4_2bit-iyokanl1.json", false);
+        setPort(h, net, "io_inA", 4, 0b1101);
+        setPort(h, net, "io_inB", 4, 0b1111);
+        h.run(net, f);
+        CHECK(getPort(h, net, "io_out", 2) == 0b01);
+    }
+    {   // mux-4bit: sel ? B : A
+        typename H::Factory f;
+        auto net = loadNet<H>(f, "iyokanl1-json/mux-4bit-iyokanl1.json", false);
+        setPort(h, net, "io_inA", 4, 0b1100);
+        setPort(h, net, "io_inB", 4, 0b1010);
+        h.set(net, "io_sel", 0, 0);
+        h.run(net, f);
+        CHECK(getPort(h, net, "io_out", 4) == 0b1100);
+        h.tick(net, f);
+        h.set(net, "io_sel", 0, 1);
+        h.run(net, f);
+        CHECK(getPort(h, net, "io_out", 4) == 0b1010);
+    }
+    for (int yosys = 0; yosys < 2; ++yosys) {   // addr-4bit: 0b1100 + 0b1010 = 0b0110 (mod 16), both readers
+        typename H::Factory f;
+        auto net = loadNet<H>(f, yosys ? "yosys-json/addr-4bit-yosys.json" : "iyokanl1-json/addr-4bit-iyokanl1.json", yosys);
+        setPort(h, net, "io_inA", 4, 0b1100);
+        setPort(h, net, "io_inB", 4, 0b1010);
+        h.run(net, f);
+        CHECK(getPort(h, net, "io_out", 4) == 0b0110);
+    }
+    {   // register-4bit: reset, store, read back
+        typename H::Factory f;
+        auto net = loadNet<H>(f, "iyokanl1-json/register-4bit-iyokanl1.json", false);
+        setPort(h, net, "io_in", 4, 0b1100);
+        h.set(net, "reset", 0, 1);
+        h.run(net, f);
+        h.tick(net, f);
+        h.set(net, "reset", 0, 0);
+        h.run(net, f);
+        h.tick(net, f);
+        CHECK(getPort(h, net, "io_out", 4) == 0);
+        h.run(net, f);
+        h.tick(net, f);
+        CHECK(getPort(h, net, "io_out", 4) == 0b1100);
+    }
+    for (int yosys = 0; yosys < 2; ++yosys) {   // counter-4bit: counts 0, 1, 2, ... after the reset cycle
+        typename H::Factory f;
+        auto net = loadNet<H>(f, yosys ? "yosys-json/counter-4bit-yosys.json" : "iyokanl1-json/counter-4bit-iyokanl1.json", yosys);
+        h.set(net, "reset", 0, 1);
+        h.run(net, f);
+        h.set(net, "reset", 0, 0);
+        for (unsigned clk = 0; clk < 6; ++clk) {
+            h.tick(net, f);
+            h.run(net, f);
+            CHECK(getPort(h, net, "io_out", 4) == clk);
+        }
+    }
+    {   // div-8bit through the Yosys reader, the values of the reference's test05: 159 / 53 = 3
+        typename H::Factory f;
+        auto net = loadNet<H>(f, "yosys-json/div-8bit-yosys.json", true);
+        h.set(net, "reset", 0, 0);
+        setPort(h, net, "io_in_a", 8, 159);
+        setPort(h, net, "io_in_b", 8, 53);
+        h.run(net, f);
+        CHECK(getPort(h, net, "io_out", 8) == 3);
+    }
+}
+
 template <class H>
 void runAll(H& h, const char* tag)
 {
+    if (!g_fixtures.empty()) testFromJSON(h);
     testNOT(h);
     testMUX(h);
     testBinopGates(h);
@@ -275,6 +393,7 @@ int main(int argc, char** argv)
     for (int i = 1; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--hip")) with_hip = true;
         if (!std::strcmp(argv[i], "--80bit")) use80 = true;
+        if (!std::strcmp(argv[i], "--fixtures") && i + 1 < argc) g_fixtures = argv[++i];
     }
     PlainHarness ph;
     runAll(ph, "plain");

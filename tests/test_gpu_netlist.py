@@ -164,7 +164,8 @@ def test_cpp_host_runtime_on_gpu(gpu, keys128):
     gpu.cleanup()   # the C++ binary initialises the library in its own process
     try:
         exe = os.path.join(ROOT, "iyokan_amd", "host", "test0_hip")
-        out = subprocess.run([exe, "--hip"], capture_output=True, text=True, timeout=600)
+        fixtures = os.path.join(ROOT, "tests", "golden", "reftest")
+        out = subprocess.run([exe, "--hip", "--fixtures", fixtures], capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stdout + out.stderr
         assert "ALL OK" in out.stdout
     finally:
