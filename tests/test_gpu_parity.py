@@ -246,12 +246,14 @@ def test_all_rotation_kernels_agree(gpu128, keys128, oracle128):
     assert np.array_equal(results["0"], ref)
 
 
-def test_mid_size_batch_uses_both_kernels(gpu128, keys128):
-    """2048 + 300 rotations: full round on the wave-per-rotation kernel, remainder on the 3-wave kernel;
-    every output must decrypt correctly (size-independent property) and inputs stay untouched."""
+@pytest.mark.parametrize("rem", [100, 300])
+def test_mid_size_batch_uses_both_kernels(gpu128, keys128, rem):
+    """2048 + rem rotations: full round on the wave-per-rotation kernel, remainder on a low-latency kernel
+    (two waves per level for rem <= 256, one wave per level above); every output must decrypt correctly
+    (size-independent property) and inputs stay untouched."""
     hip, st = gpu128
     rng = np.random.default_rng(43)
-    nin, ng = 512, 2348
+    nin, ng = 512, 2048 + rem
     bits = rng.integers(0, 2, size=nin).astype(np.uint8)
     ia = rng.integers(0, nin, size=ng).astype(np.int32)
     ib = rng.integers(0, nin, size=ng).astype(np.int32)
