@@ -68,6 +68,33 @@ def test_all_gate_kinds_bit_exact_vs_oracle(gpu128, keys128, oracle128):
     assert list(client.decrypt_bits(keys128, got[nin:])) == want
 
 
+def test_two_levels_of_random_gates_bit_exact_vs_oracle(gpu128, keys128, oracle128):
+    """600 random binary / MUX gates on fresh encryptions, then 600 more on the OUTPUTS of the first level
+    (bootstrapped ciphertexts have a different noise shape than fresh ones): every ciphertext word must
+    equal the oracle's.  Crosses the dispatch boundaries (600 + MUX rotations > 256: one-wave-per-level
+    kernel; nothing here fills a 2048 round)."""
+    hip, st = gpu128
+    p = keys128.params
+    rng = np.random.default_rng(1234)
+    nin, ng = 96, 600
+    bits = rng.integers(0, 2, size=nin).astype(np.uint8)
+    host = np.zeros((nin + 2 * ng, p.n + 1), dtype=np.uint32)
+    host[:nin] = client.encrypt_bits(keys128, bits, seed=4242)
+    kinds = BINOPS + ["MUX", "MUX"]
+    ref = host.copy()
+    got = host.copy()
+    lo, hi = 0, nin
+    for level in range(2):
+        ops = np.array([OPS[kinds[k]] for k in rng.integers(0, len(kinds), size=ng)], dtype=np.int32)
+        in0, in1, in2 = (rng.integers(lo, hi, size=ng).astype(np.int32) for _ in range(3))
+        in2 = np.where(ops == OPS["MUX"], in2, -1).astype(np.int32)
+        out = np.arange(nin + level * ng, nin + (level + 1) * ng, dtype=np.int32)
+        got = _run(hip, st, got, ops, in0, in1, in2, out)
+        oracle128.gate_batch(ops, in0, in1, in2, out, ref, nthreads=os.cpu_count() or 1)
+        lo, hi = nin + level * ng, nin + (level + 1) * ng
+    assert np.array_equal(got, ref)
+
+
 def test_reference_truth_tables_on_gpu(gpu128, keys128):
     """test0-style known answers (/root/reference/src/test0.cpp:86-94,130-136) on fresh encryptions."""
     hip, st = gpu128
