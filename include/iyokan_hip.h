@@ -175,9 +175,13 @@ int iyk_hip_timing_log_end(iyk_hip_stream* st, uint64_t* batches, double* blind_
                            double* keyswitch_ms);
 
 /* Which exact-arithmetic field the blind rotation runs in: 1 = p = 3 * 2^48 + 1097729 on the FP64 FMA
- * pipe (default where its exactness bound holds: the 128-bit set), 0 = 2^64 - 2^32 + 1 in 64-bit
- * integers (80-bit set, or forced with the environment variable IYK_HIP_NTT=goldilocks at init).
- * Both give results bit-identical to the oracle. */
+ * pipe (default for both parameter sets; the 80-bit set splits its digits), 0 = 2^64 - 2^32 + 1 in 64-bit
+ * integers (forced with the environment variable IYK_HIP_NTT=goldilocks at init, or chosen when a
+ * parameter set does not meet the FP64 field's exactness bound).  Both give identical ciphertexts.
+ *
+ * A/B knob for tests and measurements, read at every batch: IYK_HIP_LATENCY_KERNEL = 0 / 1 / 2 forces the
+ * wave-per-rotation, the wave-per-level or the two-waves-per-level blind-rotate kernel; unset = chosen by
+ * batch size. */
 int iyk_hip_ntt_path(void);
 
 /* Bytes of device memory holding keys on one GPU (NTT-domain BK + padded KSK + tables). */
