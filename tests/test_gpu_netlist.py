@@ -131,6 +131,8 @@ def test_cahp_system_config4_on_gpu(gpu, keys128):
     ("dff-reset.toml", "test23.in", "test23.out", 1),
     ("mux-ram-addr8bit.toml", "test06.in", "test06.out", 16),
     ("cahp-pearl-mux.toml", "test09.in", "test09-pearl.out", -1),
+    ("cahp-diamond.toml", "test00.in", "test00-diamond.out", -1),      # two RAMs; rom / ram builtins lowered to MUX forms
+    ("ram-addr9bit.toml", "test07.in", "test07.out", 16),              # TOGND-widened @addr stream
 ])
 def test_reference_vectors_encrypted(gpu, keys128, blueprint, req, want, ncycles):
     """The reference's cufhe-* cases (test.rb:314-346): request encrypted bit by bit, the blueprint run on
