@@ -86,3 +86,33 @@ class Oracle:
     def tlwe1_phase(self, t1):
         t1 = np.ascontiguousarray(t1, dtype=np.uint32)
         return lib().orc_tlwe1_phase(ctypes.byref(self.p), _p(t1), _p(self.keys.s1))
+
+
+class OracleBackend:
+    """Ciphertext arena in host memory, gates evaluated by the CPU oracle: the frontier executor's backend
+    interface (gate_batch / write / read ...) so that whole netlists run ENCRYPTED without a GPU.
+    Test infrastructure only — BASELINE config #1 ("test0-equivalent self-check on the CPU oracle")."""
+
+    def __init__(self, num_slots, oracle, nthreads=None):
+        self.oracle = oracle
+        self.arena = np.zeros((num_slots, oracle.p.n + 1), dtype=np.uint32)
+        self.nthreads = nthreads or (os.cpu_count() or 1)
+
+    def gate_batch(self, ops, in0, in1, in2, out):
+        if len(ops):
+            self.oracle.gate_batch(ops, in0, in1, in2, out, self.arena, nthreads=self.nthreads)
+
+    def write(self, slot, tlwe):
+        self.arena[slot] = np.asarray(tlwe, dtype=np.uint32)
+
+    def write_many(self, slots, rows):
+        self.arena[np.asarray(slots, dtype=np.int64)] = np.asarray(rows, dtype=np.uint32).reshape(len(slots), -1)
+
+    def read(self, slot):
+        return self.arena[slot].copy()
+
+    def read_many(self, slots):
+        return self.arena[np.asarray(slots, dtype=np.int64)].copy()
+
+    def sync(self):
+        pass
