@@ -311,6 +311,8 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
     double* s_twf = reinterpret_cast<double*>(smem);                   // [k2][j1]
     double* s_ztab = s_twf + NTT_N;                                    // [j2][digit + 32]
     u32* s_acc = reinterpret_cast<u32*>(s_ztab + fp::ZTAB_ENTRIES);    // [BR_WAVES][2][NTT_N]
+    static_assert(((NTT_N + fp::ZTAB_ENTRIES) * sizeof(double)) % 4096 == 0 && (NTT_N * sizeof(u32)) % 4096 == 0,
+                  "fwd1_pre needs every accumulator polynomial 4 KB aligned");
     u32* s_xb = s_acc + BR_WAVES * 2 * NTT_N;                          // [BR_WAVES][2][XB_WORDS32]
 
     for (int e = threadIdx.x; e < NTT_N; e += 64 * BR_WAVES) {
@@ -466,6 +468,7 @@ __global__ __launch_bounds__(64 * D::LV) void blind_rotate_fp_lat_kernel(
     double* s_twi = s_twf + NTT_N;
     double* s_ztab = s_twi + NTT_N;                          // [j2][digit + 32]
     u32* acc_lds = reinterpret_cast<u32*>(s_ztab + fp::ZTAB_ENTRIES);  // [2][1024], shared by all waves
+    static_assert(((2 * NTT_N + fp::ZTAB_ENTRIES) * sizeof(double)) % 4096 == 0, "fwd1_pre needs 4 KB aligned accumulators");
     u32* s_xb = acc_lds + 2 * NTT_N;                         // [L][2][XB_WORDS32]
 
     for (int e = threadIdx.x; e < NTT_N; e += 64 * L) {
@@ -638,6 +641,7 @@ __global__ __launch_bounds__(128 * D::LV) void blind_rotate_fp_lat2_kernel(
     double* s_twi = s_twf + NTT_N;                                        // [j1][k2]
     double* s_ztab = s_twi + NTT_N;                                       // [j2][digit + 32]
     u32* acc_lds = reinterpret_cast<u32*>(s_ztab + fp::ZTAB_ENTRIES);     // [2][1024]
+    static_assert(((2 * NTT_N + fp::ZTAB_ENTRIES) * sizeof(double)) % 4096 == 0, "fwd1_pre needs 4 KB aligned accumulators");
     double* s_scr = reinterpret_cast<double*>(acc_lds + 2 * NTT_N);
     double* s_xp = s_scr;                                                 // [L][2][32][33]
 
