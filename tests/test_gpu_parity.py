@@ -273,6 +273,23 @@ def test_all_rotation_kernels_agree(gpu128, keys128, oracle128):
     assert np.array_equal(results["0"], ref)
 
 
+def test_repeated_batches_are_bit_identical(gpu128, keys128):
+    """Determinism: the same 2500-gate batch run three times (key-switch partial sums are combined by
+    integer atomics, whose order varies) gives identical ciphertext words every time."""
+    hip, st = gpu128
+    rng = np.random.default_rng(99)
+    nin, ng = 256, 2500
+    bits = rng.integers(0, 2, size=nin).astype(np.uint8)
+    host = np.zeros((nin + ng, keys128.params.n + 1), dtype=np.uint32)
+    host[:nin] = client.encrypt_bits(keys128, bits, seed=31337)
+    ops = rng.choice([OPS["NAND"], OPS["OR"], OPS["MUX"]], size=ng).astype(np.int32)
+    in0, in1, in2 = (rng.integers(0, nin, size=ng).astype(np.int32) for _ in range(3))
+    in2 = np.where(ops == OPS["MUX"], in2, -1).astype(np.int32)
+    out = np.arange(nin, nin + ng, dtype=np.int32)
+    runs = [_run(hip, st, host, ops, in0, in1, in2, out) for _ in range(3)]
+    assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])
+
+
 @pytest.mark.parametrize("rem", [100, 300])
 def test_mid_size_batch_uses_both_kernels(gpu128, keys128, rem):
     """2048 + rem rotations: full round on the wave-per-rotation kernel, remainder on a low-latency kernel
