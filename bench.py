@@ -33,7 +33,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gates", type=int, default=65536, help="gates per step per GPU")
     ap.add_argument("--params", default="128bit", choices=["128bit", "80bit"])
-    ap.add_argument("--op", default="NAND")
+    ap.add_argument("--op", default="NAND", choices=["AND", "NAND", "ANDNOT", "OR", "NOR", "ORNOT", "XOR", "XNOR"],
+                    help="binary gate of the flat batch (BASELINE config #2 is NAND)")
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="gates timed on the CPU oracle for cpu_baseline (-1: sized for ~15 s, 0: skip)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
