@@ -52,6 +52,16 @@ __device__ __forceinline__ void lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS operations (lgkmcnt), NOT for its
+// outstanding global loads — __syncthreads() would also drain vmcnt and so expose the latency of the key
+// rows prefetched at the top of the step at the very first barrier (measured: 0.5 ms of 6.5 per rotation).
+__device__ __forceinline__ void wg_barrier_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ------------------------------------------------------------------------------------------
 // BK: [polys][1024] u32 torus -> [polys][1024] u64 NTT domain in the device layout of
 // bk_dev_index (pairs of k1 adjacent so the MAC issues 16-byte loads).
@@ -543,7 +553,7 @@ __global__ __launch_bounds__(64 * D::LV) void blind_rotate_fp_lat_kernel(
 #pragma unroll
                 for (int q = 0; q < 16; ++q) mine[q * 64 + lane] = accum[16 * chunk + q];
             }
-            __syncthreads();
+            wg_barrier_lds();
             if (wave == 0) {
 #pragma unroll
                 for (int w = 1; w < L; ++w) {
@@ -552,7 +562,7 @@ __global__ __launch_bounds__(64 * D::LV) void blind_rotate_fp_lat_kernel(
                     for (int q = 0; q < 16; ++q) accum[16 * chunk + q] += other[q * 64 + lane];
                 }
             }
-            __syncthreads();
+            wg_barrier_lds();
         }
         if (wave == 0) {
             int t = t0, h = h0;
@@ -574,7 +584,7 @@ __global__ __launch_bounds__(64 * D::LV) void blind_rotate_fp_lat_kernel(
             fp::ntt32_dif<fp::PASS2>(x, C.w);
             fp::inv2_post(t, x, acc_h, C.zi);
         }
-        __syncthreads();  // accumulator of step i is complete before anyone derives step i+1's digits
+        wg_barrier_lds();  // accumulator of step i is complete before anyone derives step i+1's digits
     }
 
     if (wave == 0) {
@@ -603,16 +613,6 @@ __global__ __launch_bounds__(64 * D::LV) void blind_rotate_fp_lat_kernel(
 //
 // LDS (bytes): twiddles fwd + inv 16 K | twisted digits 16 K | accumulator 8 K (4 KB aligned polynomials) |
 // transposes [L][h][32][33] f64 (8448 each) | MAC share / partial sums [2L waves][h][16][32] f64.
-// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS operations (lgkmcnt), NOT for its
-// outstanding global loads — __syncthreads() would also drain vmcnt and so expose the latency of the key
-// rows prefetched at the top of the step at the very first barrier (measured: 0.5 ms of 6.5 per rotation).
-__device__ __forceinline__ void wg_barrier_lds()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 template <int LV>
 struct BrLat2Lds {
     static constexpr size_t XPOSE = (size_t)LV * 2 * 32 * XB_STRIDE * sizeof(double);
