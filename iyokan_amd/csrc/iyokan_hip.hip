@@ -55,7 +55,8 @@ struct Global {
     u32 ksk_stride = 0;
     bool use_fp = false;          // FP64 path (fp50.hpp) instead of Goldilocks integers
     int lat_threshold = 1280;      // rotations per batch at or below which the low-latency kernel is used
-    int lat2_threshold = 256;      // ... and at or below which its two-waves-per-level variant is used
+    int lat2_threshold = 0;        // ... and at or below which its two-waves-per-level variant is used (0: never —
+                                   // since the one-wave-per-level kernel prefetches its key rows it is the faster one)
     fp::NttConsts fpc{};
     std::vector<Device> devs;
     std::atomic<int> nstreams{0};
@@ -231,9 +232,9 @@ int launch_br_fp_lat2(iyk_hip_stream* st, int first, int njobs, u32* d_tlwe1, in
 }
 
 // Measured (profiles/r01_sweep_kernels.txt): the wave-per-rotation kernel runs 2048 rotations per 23 ms
-// round; the one-wave-per-level kernel takes 6.6 ms for <= 256 and ~19 ms per 1024; the two-waves-per-level
-// kernel is the fastest for at most lat2_threshold rotations (one workgroup per CU).  So: full 2048-rounds on
-// the first, a remainder of up to lat_threshold rotations on the second or third.
+// round; the one-wave-per-level kernel takes 6.3 ms for <= 256 and ~18 ms per 1024; the two-waves-per-level
+// kernel (6.4 ms, 25 ms per 1024) is kept for A/B only.  So: full 2048-rounds on the first, a remainder of
+// up to lat_threshold rotations on the second.
 template <class DC>
 int dispatch_fp(iyk_hip_stream* st, int njobs, u32* d_tlwe1, int trlwe)
 {

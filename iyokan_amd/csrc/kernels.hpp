@@ -511,6 +511,13 @@ __global__ __launch_bounds__(64 * D::LV) void blind_rotate_fp_lat_kernel(
             const double* xb64_oth = reinterpret_cast<const double*>(wave_xb + (1 - h) * XB_WORDS32);
             const double* bko = bk_step + (size_t)((h * L + wave) * 2 + h) * NTT_N + (size_t)t * 2;
             const double* bkt = bk_step + (size_t)(((1 - h) * L + wave) * 2 + h) * NTT_N + (size_t)t * 2;
+            // key rows of the first MAC chunk are fetched now: a lone wave has nothing else to hide their latency with
+            double bo0[8][2], bt0[8][2];
+#pragma unroll
+            for (int mm = 0; mm < 8; ++mm) {
+                bo0[mm][0] = bko[mm * 64]; bo0[mm][1] = bko[mm * 64 + 1];
+                bt0[mm][0] = bkt[mm * 64]; bt0[mm][1] = bkt[mm * 64 + 1];
+            }
             // forward pass 1 of level `wave`
             fp::fwd1_pre<D>(t, wave, ab, acc_h, x, s_ztab);
             fp::ntt32_dif<fp::PASS1>(x, C.w);
@@ -534,8 +541,8 @@ __global__ __launch_bounds__(64 * D::LV) void blind_rotate_fp_lat_kernel(
 #pragma unroll
                 for (int mm = 0; mm < 8; ++mm) {
                     const int m = chunk * 8 + mm;
-                    const double bo[2] = {bko[m * 64], bko[m * 64 + 1]};
-                    const double bt[2] = {bkt[m * 64], bkt[m * 64 + 1]};
+                    const double bo[2] = {chunk ? bko[m * 64] : bo0[mm][0], chunk ? bko[m * 64 + 1] : bo0[mm][1]};
+                    const double bt[2] = {chunk ? bkt[m * 64] : bt0[mm][0], chunk ? bkt[m * 64 + 1] : bt0[mm][1]};
                     fp::mac_pair(t, m, x, xb64_oth, bo, bt, accum);
                 }
                 lds_sync();
