@@ -499,8 +499,10 @@ __global__ __launch_bounds__(64 * D::LV) void blind_rotate_fp_lat_kernel(
     double x[32], accum[32];
     u32* wave_xb = s_xb + wave * BR_LAT_WAVE_WORDS;
 
+    u32 ab_next = abar[0];
     for (u32 i = 0; i < n; ++i) {
-        const u32 ab = abar[i];
+        const u32 ab = ab_next;
+        ab_next = abar[i + 1 < n ? i + 1 : i];  // next step's exponent: its scalar-load latency hides behind this step
         const double* bk_step = bk_ntt + (size_t)i * (2 * L) * 2 * NTT_N;
         {
             int t = t0, h = h0;
