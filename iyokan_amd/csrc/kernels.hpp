@@ -301,6 +301,37 @@ __global__ __launch_bounds__(64) void bk_ntt_fp_kernel(const u32* __restrict__ b
     }
 }
 
+// 32 x 32 transpose of the doubles of one polynomial in TWO rounds of 16 rows through a [16][33] f64
+// buffer (the footprint of the u32 [32][33] matrix): round A carries the rows < 16, read by the lanes
+// t < 16; round B the rest.  64-bit LDS accesses, paired by the compiler: ~48 LDS instructions per transpose
+// instead of 96 for the (low words, high words) rounds — every instruction of a wave takes one of its issue
+// turns, LDS ones included.
+template <bool INV>
+__device__ __forceinline__ void xpose64(int t, double (&x)[32], double* xb64)
+{
+    double y[32];
+#pragma unroll
+    for (int p = 0; p < 32; ++p)
+        if (xpose_row<INV>(p) < 16) xb64[xpose_row<INV>(p) * XB_STRIDE + t] = x[p];
+    lds_sync();
+    if (t < 16) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) y[j] = xb64[t * XB_STRIDE + j];
+    }
+    lds_sync();
+#pragma unroll
+    for (int p = 0; p < 32; ++p)
+        if (xpose_row<INV>(p) >= 16) xb64[(xpose_row<INV>(p) - 16) * XB_STRIDE + t] = x[p];
+    lds_sync();
+    if (t >= 16) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) y[j] = xb64[(t - 16) * XB_STRIDE + j];
+    }
+    lds_sync();
+#pragma unroll
+    for (int j = 0; j < 32; ++j) x[j] = y[j];
+}
+
 // LDS map of blind_rotate_fp_kernel (bytes): forward twiddles 8 K | twisted-digit table 16 K |
 // accumulators [wave][h][1024] u32 64 K (every polynomial 4 KB aligned) | transpose/share buffers
 // [wave][h][32][33] u32 66 K  = 154 KB of the CU's 160 KB, one 8-wave workgroup per CU.
@@ -344,7 +375,6 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
     u32* xb_lds = s_xb + wave * 2 * XB_WORDS32;
     const u32* abar = abar_all + (size_t)job * abar_stride;
 
-    u32 lo[32];
     double x[32], accum[32];
     br_init_acc(h0, t0, abar[n], mu, acc_lds + h0 * NTT_N);
     lds_sync();
@@ -373,14 +403,7 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
             fp::fwd1_pre<D>(t, lvl, ab, acc_h, x, s_ztab);
             fp::ntt32_dif<fp::PASS1>(x, C.w);
             fp::fwd1_twiddle(t, x, s_twf);
-            fp::xpose_write<false>(t, x, xb, false);
-            lds_sync();
-            fp::xpose_read_words(t, lo, xb);
-            lds_sync();
-            fp::xpose_write<false>(t, x, xb, true);
-            lds_sync();
-            fp::xpose_read_hi(t, x, lo, xb);
-            lds_sync();
+            xpose64<false>(t, x, xb64_own);
 
             b0o[0] = bko[0]; b0o[1] = bko[1]; b0t[0] = bkt[0]; b0t[1] = bkt[1];
             fp::ntt32_dif<fp::PASS2>(x, C.w);
@@ -424,14 +447,7 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
             fp::inv1_twiddle_load(t, twi, tw_inv_t);
             fp::ntt32_dif<fp::PASS1>(x, C.w);
             fp::inv1_twiddle_regs(x, twi);
-            fp::xpose_write<true>(t, x, xb, false);
-            lds_sync();
-            fp::xpose_read_words(t, lo, xb);
-            lds_sync();
-            fp::xpose_write<true>(t, x, xb, true);
-            lds_sync();
-            fp::xpose_read_hi(t, x, lo, xb);
-            lds_sync();
+            xpose64<true>(t, x, reinterpret_cast<double*>(xb));
             fp::ntt32_dif<fp::PASS2>(x, C.w);
             fp::inv2_post(t, x, acc_h, C.zi);
             lds_sync();
