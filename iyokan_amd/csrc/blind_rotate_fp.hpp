@@ -66,16 +66,13 @@ IYK_HD double ztab_entry(int e, const double* zf)
     return j2 ? mulmod(d, zf[j2]) : d;
 }
 
-// forward pass 1, pre: signed digit of virtual level v of ((X^abar - 1) acc_h)[t + 32 j2], times zeta^j2
-template <class D>
-IYK_HD void fwd1_pre(int t, int v, u32 abar, const u32* acc_h, double (&x)[32], const double* ztab)
+// forward pass 1, pre, in two parts.  fwd1_diff: td[j2] = ((X^abar - 1) acc_h)[t + 32 j2], the same for every
+// gadget level of a CMUX step, so the one-wave-per-rotation kernel computes it ONCE per step and keeps it in
+// 32 registers.  fwd1_digits: signed digit of virtual level v of td, times zeta^j2, from the table.
+IYK_HD void fwd1_diff(int t, u32 abar, const u32* acc_h, u32 (&td)[32])
 {
-    static_assert(D::max_digit() <= ZTAB_DIGITS / 2, "digit range exceeds the twist table");
-    u32 td[32];
-    // two sweeps so that the 64 accumulator reads, then the 32 table reads, are each issued back to back
-    // instead of one dependent LDS round trip per coefficient
 #if defined(__HIP_DEVICE_COMPILE__)
-    // PRECONDITION (both kernels' LDS maps honour it): acc_h is 4 KB aligned, so the wrapped byte address
+    // PRECONDITION (every kernel's LDS map honours it): acc_h is 4 KB aligned, so the wrapped byte address
     // is one v_and_or: (4 idx mod 4096) | base.  Everything else is the generic code below, in bytes.
     typedef const __attribute__((address_space(3))) u32* lds_u32;
     const u32 acc_base = (u32)(size_t)(lds_u32)acc_h;
@@ -97,8 +94,21 @@ IYK_HD void fwd1_pre(int t, int v, u32 abar, const u32* acc_h, double (&x)[32], 
         td[j2] = a - acc_h[t + 32 * j2];
     }
 #endif
+}
+template <class D>
+IYK_HD void fwd1_digits(int v, const u32 (&td)[32], double (&x)[32], const double* ztab)
+{
+    static_assert(D::max_digit() <= ZTAB_DIGITS / 2, "digit range exceeds the twist table");
 #pragma unroll
     for (int j2 = 0; j2 < 32; ++j2) x[j2] = ztab[j2 * ZTAB_DIGITS + (D::digit(td[j2], v) + ZTAB_DIGITS / 2)];
+}
+// both parts in one go (low-latency kernels: a wave owns one level, nothing to share)
+template <class D>
+IYK_HD void fwd1_pre(int t, int v, u32 abar, const u32* acc_h, double (&x)[32], const double* ztab)
+{
+    u32 td[32];
+    fwd1_diff(t, abar, acc_h, td);
+    fwd1_digits<D>(v, td, x, ztab);
 }
 
 IYK_HD void fwd1_twiddle(int t, double (&x)[32], const double* twf_t)

@@ -384,6 +384,13 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
         const double* bk_step = bk_ntt + (size_t)i * (2 * L) * 2 * NTT_N;
 #pragma unroll
         for (int q = 0; q < 32; ++q) accum[q] = 0.0;
+        // ((X^abar - 1) acc)[t + 32 j2] is the same for every gadget level of this step: derived once
+        u32 td[32];
+        {
+            int t = t0, h = h0;
+            asm volatile("" : "+v"(t), "+v"(h));
+            fp::fwd1_diff(t, ab, acc_lds + h * NTT_N, td);
+        }
 
         // L forward transforms, each followed by its MAC against the key rows.  A transform is pass 1 (DIF
         // over the high index, inter-pass twiddle, 32 x 32 transpose) and pass 2 (DIF over the low index),
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
             const double* bkt = bk_step + (size_t)(((1 - h) * L + lvl) * 2 + h) * NTT_N + (size_t)t * 2;
             double b0o[2], b0t[2], b1o[2], b1t[2];
 
-            fp::fwd1_pre<D>(t, lvl, ab, acc_h, x, s_ztab);
+            fp::fwd1_digits<D>(lvl, td, x, s_ztab);
             fp::ntt32_dif<fp::PASS1>(x, C.w);
             fp::fwd1_twiddle(t, x, s_twf);
             xpose64<false>(t, x, xb64_own);
