@@ -54,7 +54,7 @@ struct Global {
     iyk_params p{};
     u32 ksk_stride = 0;
     bool use_fp = false;          // FP64 path (fp50.hpp) instead of Goldilocks integers
-    int lat_threshold = 1280;      // rotations per batch at or below which the low-latency kernel is used
+    int lat_threshold = 1100;      // rotations per batch at or below which the low-latency kernel is used
     int lat2_threshold = 0;        // ... and at or below which its two-waves-per-level variant is used (0: never —
                                    // since the one-wave-per-level kernel prefetches its key rows it is the faster one)
     fp::NttConsts fpc{};
