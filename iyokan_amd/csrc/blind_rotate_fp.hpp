@@ -208,7 +208,13 @@ IYK_HD void inv2_post(int t, const double (&x)[32], u32* acc_h, const double* zi
     for (int p = 0; p < 32; ++p) {
         const int j2 = inv_index(p);
         const double v = norm(j2 == 0 ? x[p] : mulmod(x[p], zi[j2]));
+#if defined(__HIP_DEVICE_COMPILE__)
+        // ds_add_u32 without return: no read round trip (each word has exactly one writer, so this is not about
+        // atomicity, only about not waiting for the old value)
+        __hip_atomic_fetch_add(acc_h + t + 32 * j2, to_torus32(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#else
         acc_h[t + 32 * j2] += to_torus32(v);
+#endif
     }
 }
 
