@@ -4,7 +4,7 @@
 // field changes: residues mod p = 3 * 2^48 + 1097729 held as lazily-reduced integers in doubles, exact
 // FMA arithmetic, general twiddles.  BK is stored in the same device layout (bk_dev_index) as
 // balanced doubles, 8 bytes per coefficient — the algorithmic byte count is unchanged.
-// Instruction budget per CMUX step and lane: ~9.5 k VALU vs ~31 k on the integer path.
+// Instruction budget per CMUX step and lane: ~7.0 k VALU vs ~31 k on the integer path.
 #pragma once
 #include "blind_rotate_core.hpp"
 #include "fpntt32.hpp"
@@ -117,7 +117,8 @@ IYK_HD void fwd1_twiddle(int t, double (&x)[32], const double* twf_t)
     for (int p = 0; p < 32; ++p) x[p] = mulmod(x[p], twf_t[brv5(p) * 32 + t]);
 }
 
-// 32 x 32 transpose of 64-bit values through the u32 [32][33] LDS matrix, (lo, hi) rounds
+// 32 x 32 transpose of 64-bit values through the u32 [32][33] LDS matrix, (lo, hi) rounds (low-latency
+// kernels and the CPU emulation; the wave-per-rotation kernel uses xpose64 in kernels.hpp)
 template <bool INV>
 IYK_HD void xpose_write(int t, const double (&x)[32], u32* xb, bool hi)
 {
