@@ -379,8 +379,10 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
     br_init_acc(h0, t0, abar[n], mu, acc_lds + h0 * NTT_N);
     lds_sync();
 
+    u32 ab_next = abar[0];
     for (u32 i = 0; i < n; ++i) {
-        const u32 ab = abar[i];
+        const u32 ab = ab_next;
+        ab_next = abar[i + 1 < n ? i + 1 : i];  // next step's exponent: its scalar-load latency hides behind this step
         const double* bk_step = bk_ntt + (size_t)i * (2 * L) * 2 * NTT_N;
 #pragma unroll
         for (int q = 0; q < 32; ++q) accum[q] = 0.0;
