@@ -173,6 +173,8 @@ IYK_HD void share_write(int t, int chunk, const double (&x)[32], double* xb64_ow
 
 // accum_h[k1] += D_own[k] BK[r_own][h][k] + D_other[k] BK[r_other][h][k] for k1 = 2m, 2m+1
 // (six such terms per k1 over the three gadget levels: |accum| <= 6.6 p < 2^53)
+// FIRST: the sum starts here (first gadget level of a step): no zeroing, one addition less per value
+template <bool FIRST = false>
 IYK_HD void mac_pair(int t, int m, const double (&x)[32], const double* xb64_oth, const double (&bo)[2],
                      const double (&bt)[2], double (&accum)[32])
 {
@@ -180,7 +182,8 @@ IYK_HD void mac_pair(int t, int m, const double (&x)[32], const double* xb64_oth
     for (int e = 0; e < 2; ++e) {
         const int k1 = 2 * m + e;
         const double xo = xb64_oth[(k1 & 15) * 32 + t];
-        accum[k1] = (accum[k1] + mulmod(x[brv5(k1)], bo[e])) + mulmod(xo, bt[e]);
+        const double own = mulmod(x[brv5(k1)], bo[e]);
+        accum[k1] = (FIRST ? own : accum[k1] + own) + mulmod(xo, bt[e]);
     }
 }
 

@@ -384,8 +384,6 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
         const u32 ab = ab_next;
         ab_next = abar[i + 1 < n ? i + 1 : i];  // next step's exponent: its scalar-load latency hides behind this step
         const double* bk_step = bk_ntt + (size_t)i * (2 * L) * 2 * NTT_N;
-#pragma unroll
-        for (int q = 0; q < 32; ++q) accum[q] = 0.0;
         // ((X^abar - 1) acc)[t + 32 j2] is the same for every gadget level of this step: derived once
         u32 td[32];
         {
@@ -416,23 +414,45 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
 
             b0o[0] = bko[0]; b0o[1] = bko[1]; b0t[0] = bkt[0]; b0t[1] = bkt[1];
             fp::ntt32_dif<fp::PASS2>(x, C.w);
+            if (lvl == 0) {  // the NTT-domain sum starts with this level: assigned, not accumulated
 #pragma unroll
-            for (int chunk = 0; chunk < 2; ++chunk) {
-                fp::share_write(t, chunk, x, xb64_own);
-                lds_sync();
+                for (int chunk = 0; chunk < 2; ++chunk) {
+                    fp::share_write(t, chunk, x, xb64_own);
+                    lds_sync();
 #pragma unroll
-                for (int mm = 0; mm < 8; mm += 2) {
-                    const int m = chunk * 8 + mm;
-                    b1o[0] = bko[(m + 1) * 64]; b1o[1] = bko[(m + 1) * 64 + 1];
-                    b1t[0] = bkt[(m + 1) * 64]; b1t[1] = bkt[(m + 1) * 64 + 1];
-                    fp::mac_pair(t, m, x, xb64_oth, b0o, b0t, accum);
-                    if (m + 2 < 16) {
-                        b0o[0] = bko[(m + 2) * 64]; b0o[1] = bko[(m + 2) * 64 + 1];
-                        b0t[0] = bkt[(m + 2) * 64]; b0t[1] = bkt[(m + 2) * 64 + 1];
+                    for (int mm = 0; mm < 8; mm += 2) {
+                        const int m = chunk * 8 + mm;
+                        b1o[0] = bko[(m + 1) * 64]; b1o[1] = bko[(m + 1) * 64 + 1];
+                        b1t[0] = bkt[(m + 1) * 64]; b1t[1] = bkt[(m + 1) * 64 + 1];
+                        fp::mac_pair<true>(t, m, x, xb64_oth, b0o, b0t, accum);
+                        if (m + 2 < 16) {
+                            b0o[0] = bko[(m + 2) * 64]; b0o[1] = bko[(m + 2) * 64 + 1];
+                            b0t[0] = bkt[(m + 2) * 64]; b0t[1] = bkt[(m + 2) * 64 + 1];
+                        }
+                        fp::mac_pair<true>(t, m + 1, x, xb64_oth, b1o, b1t, accum);
                     }
-                    fp::mac_pair(t, m + 1, x, xb64_oth, b1o, b1t, accum);
+                    lds_sync();
                 }
-                lds_sync();
+            }
+            else {
+#pragma unroll
+                for (int chunk = 0; chunk < 2; ++chunk) {
+                    fp::share_write(t, chunk, x, xb64_own);
+                    lds_sync();
+#pragma unroll
+                    for (int mm = 0; mm < 8; mm += 2) {
+                        const int m = chunk * 8 + mm;
+                        b1o[0] = bko[(m + 1) * 64]; b1o[1] = bko[(m + 1) * 64 + 1];
+                        b1t[0] = bkt[(m + 1) * 64]; b1t[1] = bkt[(m + 1) * 64 + 1];
+                        fp::mac_pair(t, m, x, xb64_oth, b0o, b0t, accum);
+                        if (m + 2 < 16) {
+                            b0o[0] = bko[(m + 2) * 64]; b0o[1] = bko[(m + 2) * 64 + 1];
+                            b0t[0] = bkt[(m + 2) * 64]; b0t[1] = bkt[(m + 2) * 64 + 1];
+                        }
+                        fp::mac_pair(t, m + 1, x, xb64_oth, b1o, b1t, accum);
+                    }
+                    lds_sync();
+                }
             }
             // magnitude discipline: each level adds two terms of <= 1.34 p; with 4 virtual levels the
             // running sum is renormalised half way so it can never reach 2^53 (10.67 p)
