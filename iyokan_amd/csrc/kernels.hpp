@@ -580,8 +580,6 @@ __global__ __launch_bounds__(64 * D::LV) void blind_rotate_fp_lat_kernel(
             // forward pass 2 + MAC
             fp::ntt32_dif<fp::PASS2>(x, C.w);
 #pragma unroll
-            for (int q = 0; q < 32; ++q) accum[q] = 0.0;
-#pragma unroll
             for (int chunk = 0; chunk < 2; ++chunk) {
                 fp::share_write(t, chunk, x, xb64_own);
                 lds_sync();
@@ -590,7 +588,7 @@ __global__ __launch_bounds__(64 * D::LV) void blind_rotate_fp_lat_kernel(
                     const int m = chunk * 8 + mm;
                     const double bo[2] = {chunk ? bko[m * 64] : bo0[mm][0], chunk ? bko[m * 64 + 1] : bo0[mm][1]};
                     const double bt[2] = {chunk ? bkt[m * 64] : bt0[mm][0], chunk ? bkt[m * 64 + 1] : bt0[mm][1]};
-                    fp::mac_pair(t, m, x, xb64_oth, bo, bt, accum);
+                    fp::mac_pair<true>(t, m, x, xb64_oth, bo, bt, accum);  // a wave owns one level: its partial sum starts here
                 }
                 lds_sync();
             }
