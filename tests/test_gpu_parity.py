@@ -273,6 +273,30 @@ def test_all_rotation_kernels_agree(gpu128, keys128, oracle128):
     assert np.array_equal(results["0"], ref)
 
 
+def test_in_place_outputs(gpu128, keys128, oracle128):
+    """A gate may write its result over one of its own inputs (the reference's tasks own separate buffers, a
+    device arena invites reuse): every input of a batch is consumed before any output is written, so the result
+    equals the one computed into a fresh slot."""
+    hip, st = gpu128
+    p = keys128.params
+    rng = np.random.default_rng(77)
+    n = 40
+    bits = rng.integers(0, 2, size=2 * n).astype(np.uint8)
+    host = np.zeros((3 * n, p.n + 1), dtype=np.uint32)
+    host[: 2 * n] = client.encrypt_bits(keys128, bits, seed=555)
+    ops = rng.choice([OPS["NAND"], OPS["XOR"], OPS["ORNOT"], OPS["NOT"]], size=n).astype(np.int32)
+    in0 = np.arange(n, dtype=np.int32)
+    in1 = np.where(ops == OPS["NOT"], -1, np.arange(n, 2 * n)).astype(np.int32)
+    in2 = np.full(n, -1, dtype=np.int32)
+    fresh = _run(hip, st, host, ops, in0, in1, in2, np.arange(2 * n, 3 * n, dtype=np.int32))
+    inplace = _run(hip, st, host, ops, in0, in1, in2, in0)          # out slot = first input slot
+    assert np.array_equal(inplace[:n], fresh[2 * n:])
+    assert np.array_equal(inplace[n: 2 * n], host[n: 2 * n])
+    ref = host.copy()
+    oracle128.gate_batch(ops, in0, in1, in2, np.arange(2 * n, 3 * n, dtype=np.int32), ref, nthreads=os.cpu_count() or 1)
+    assert np.array_equal(fresh[2 * n:], ref[2 * n:])
+
+
 def test_repeated_batches_are_bit_identical(gpu128, keys128):
     """Determinism: the same 2500-gate batch run three times (key-switch partial sums are combined by
     integer atomics, whose order varies) gives identical ciphertext words every time."""
