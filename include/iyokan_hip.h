@@ -122,11 +122,12 @@ int iyk_hip_arena_download(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t
 /* Evaluate `count` mutually independent gates on arena slots, asynchronously on `st`.
  * Replaces `count` calls of cufhe::And/Nand/.../Mux/Not<lvl0param>(out, in.., st)
  * (/root/reference/src/iyokan_cufhe.hpp:249-261) with ONE batched launch sequence:
- *   linear step -> blind rotation (n CMUX external products, N-point negacyclic NTT over
- *   2^64-2^32+1) -> sample-extract(0) -> identity key-switch.
+ *   linear step -> blind rotation (n CMUX external products, exact N-point negacyclic NTT, see
+ *   iyk_hip_ntt_path) -> sample-extract(0) -> identity key-switch.
  * ops/in0/in1/in2/out are HOST arrays of length count (copied before return); in1/in2 are
- * ignored where the gate has fewer inputs (use -1).  No output slot may be an input of a
- * gate in the same batch.  Results are bit-identical to the CPU restatement in oracle/. */
+ * ignored where the gate has fewer inputs (use -1).  A gate may write its output over one of its
+ * OWN inputs; no output slot may be an input of ANOTHER gate of the same batch (the gates are
+ * independent by contract).  Results are bit-identical to the CPU restatement in oracle/. */
 int iyk_hip_gate_batch(iyk_hip_stream* st, uint32_t* d_arena, uint64_t count, const int32_t* ops,
                        const int32_t* in0, const int32_t* in1, const int32_t* in2,
                        const int32_t* out);
