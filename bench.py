@@ -1,14 +1,20 @@
 #!/usr/bin/env python3
 """bench.py — TFHE gate bootstraps/sec on MI355X (BASELINE.json metric).
 
-Workload (BASELINE.json configs[1], SURVEY.md §8d "Config 2"): a flat DAG of independent
+Workload (BASELINE.json configs[1], SURVEY.md §8d "Config 2"): a flat DAG of 65 536 independent
 HomNAND gates at the 128-bit parameter set, inputs are FRESH encryptions (never trivial
 ciphertexts, which skip every CMUX).  One "step" = one pass of the hot path over the whole
 batch: iyk_hip_gate_batch -> {blind_rotate kernel, keyswitch kernel}, inputs and keys already
-resident in HBM.  With N > 1 (one process per GPU, launched by torch.distributed.run) the batch
-is sharded by replication of the per-GPU work: every rank processes its own `--gates` gates,
-there is no data-path collective for a flat DAG ("scaling": "weak"); the key material is
+resident in HBM.  With N > 1 (one process per GPU, launched by torch.distributed.run) the SAME
+65 536-gate batch is sharded over the ranks (8 192 gates per GPU at N = 8), with no
+data-path collective for a flat DAG: "scaling": "strong".  The weak-scaling figure (every rank its own
+65 536 gates) is measured right after and reported as the extra field "weak".  The key material is
 generated on rank 0 and broadcast once over RCCL.
+
+The `roofline` object keeps the contract's HBM figure (algorithmic bytes / kernel time / 8 TB/s) and says
+what the counters say beside it: the kernel is bound by FP64 VALU issue, `roofline.valu` prices the measured
+instruction count (SQ_INSTS_VALU pass committed under profiles/) against 4 cycles per wave-instruction per
+SIMD, and `traffic_over_algorithmic` shows the key stream is served by L2.
 
 Prints ONE JSON line on rank 0 (see README of the contract in DESIGN.md §Measurement).
 """
@@ -24,6 +30,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_BYTES_PER_S = 8.0e12  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# VALU issue ceiling (same guide): 256 CUs x 4 SIMDs; a wave64 FP64 (or 32-bit integer) instruction occupies a
+# SIMD's 16 lanes for 4 cycles; peak engine clock 2.4 GHz -> 1.667 ns per wave-instruction per SIMD
+N_SIMDS = 256 * 4
+VALU_PEAK_NS = 4.0 / 2.4
 
 
 def parse_args():
@@ -31,7 +41,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--gates", type=int, default=65536, help="gates per step per GPU")
+    ap.add_argument("--gates", type=int, default=65536, help="gates per step, whole job (sharded over the GPUs)")
+    ap.add_argument("--no-weak", action="store_true", help="skip the extra weak-scaling measurement at N > 1")
     ap.add_argument("--params", default="128bit", choices=["128bit", "80bit"])
     ap.add_argument("--op", default="NAND", choices=["AND", "NAND", "ANDNOT", "OR", "NOR", "ORNOT", "XOR", "XNOR"],
                     help="binary gate of the flat batch (BASELINE config #2 is NAND)")
@@ -42,20 +53,30 @@ def parse_args():
     return ap.parse_args()
 
 
-def traffic_bytes(args, gates):
-    """HBM bytes per blind_rotate launch measured by a separate rocprofv3 --pmc pass (committed under
-    profiles/), or None when no measurement matches this workload."""
-    if args.traffic_bytes is not None:
-        return args.traffic_bytes
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    try:
-        t = json.load(open(path))
-        w = t["workload"]
-        if w["gates_per_launch"] == gates and w["params"] == args.params and w["op"] == args.op:
-            return t["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+COUNTER_FILES = ("r02_counters.json", "r01_traffic.json")  # newest first
+
+
+def counters(args, gates):
+    """PMC results of the dominant kernel for this workload (separate rocprofv3 --pmc passes, committed under
+    profiles/ by tools/profile_round.sh): HBM traffic, VALU instruction count, busy cycles.  None when no
+    committed measurement matches (gates per launch, parameter set, gate kind)."""
+    for name in COUNTER_FILES:
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", name)))
+            w = t["workload"]
+            if w["gates_per_launch"] == gates and w["params"] == args.params and w["op"] == args.op:
+                t["_file"] = "profiles/" + name
+                return t
+        except (OSError, KeyError, ValueError):
+            continue
     return None
+
+
+def shard(total, world, rank):
+    """Contiguous block of a `total`-gate flat batch owned by `rank` (counts differ by at most one)."""
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, base + (1 if rank < extra else 0)
 
 
 def baseline_metric():
@@ -90,11 +111,12 @@ def empty_keys(params):
                          np.zeros(params.bk_words, np.uint32), np.zeros(params.ksk_words, np.uint32))
 
 
-def cpu_baseline(keys, params, op_code, sample, data_seed, budget_s=15.0):
-    """Oracle (kind 'port') timed on this host's cores on a bounded sample of the same workload.
+def cpu_baseline(keys, params, op_code, sample, data_seed, budget_s=20.0):
+    """The oracle (kind 'port') timed on ALL of this host's cores on a bounded sample of the same workload.
 
-    A first probe chunk (one gate per thread) sizes the sample so the whole leg takes ~budget_s.
-    """
+    Both exact restatements are timed (oracle/tfhe_oracle_fp.c: FP64-field products, AVX2 loops; oracle/tfhe_oracle.c:
+    Goldilocks 128-bit products) and the FASTER one is the reported value.  A first probe chunk (one gate per
+    thread) sizes the sample so the whole leg takes ~budget_s."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     from iyokan_amd import client
@@ -103,10 +125,10 @@ def cpu_baseline(keys, params, op_code, sample, data_seed, budget_s=15.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 64))
+    threads = max(1, cores)
     orc = oracle_lib.Oracle(keys)
 
-    def run(count, seed):
+    def run(count, seed, mode):
         rng = np.random.default_rng(seed)
         bits = rng.integers(0, 2, size=2 * count).astype(np.uint8)
         arena = np.zeros((3 * count, params.n + 1), dtype=np.uint32)
@@ -114,22 +136,33 @@ def cpu_baseline(keys, params, op_code, sample, data_seed, budget_s=15.0):
         idx = np.arange(count, dtype=np.int32)
         t0 = time.perf_counter()
         orc.gate_batch(np.full(count, op_code, dtype=np.int32), idx, idx + count, np.full(count, -1, dtype=np.int32),
-                       idx + 2 * count, arena, nthreads=threads)
+                       idx + 2 * count, arena, nthreads=threads, mode=mode)
         dt = time.perf_counter() - t0
         dec = client.decrypt_bits(keys, arena[2 * count:])
         assert np.array_equal(dec, 1 - (bits[:count] & bits[count:])), "oracle decrypt mismatch"
         return dt
 
-    probe_dt = run(threads, data_seed)
-    if sample < 0:
-        sample = int(max(threads, min(64 * threads, threads * (budget_s - probe_dt) / max(probe_dt, 1e-3))))
-        sample -= sample % threads
-        sample = max(sample, threads)
-    dt = run(sample, data_seed + 1)
+    modes = ["fp", "goldilocks"] if orc.has_fp() else ["goldilocks"]
+    results = {}
+    for mode in modes:
+        share = budget_s / len(modes)
+        probe_dt = run(threads, data_seed, mode)
+        n = sample
+        if n < 0:
+            n = int(max(threads, min(64 * threads, threads * (share - probe_dt) / max(probe_dt, 1e-3))))
+            n -= n % threads
+            n = max(n, threads)
+        dt = run(n, data_seed + 1, mode)
+        results[mode] = (n / dt, n, dt)
     orc.close()
-    return {"value": sample / dt, "unit": "gates/s", "cores": threads, "kind": "port",
-            "sample": f"{sample} NAND gates of the same workload in {dt:.1f} s (own exact-NTT CPU restatement "
-                      f"oracle/tfhe_oracle.c, OpenMP over gates, {threads} threads of {cores} visible cores); not TFHEpp"}
+    best = max(results, key=lambda m: results[m][0])
+    rate, n, dt = results[best]
+    names = {"fp": "oracle/tfhe_oracle_fp.c (FP64-field products)", "goldilocks": "oracle/tfhe_oracle.c (Goldilocks products)"}
+    return {"value": rate, "unit": "gates/s", "cores": threads, "kind": "port",
+            "sample": f"{n} NAND gates of the same workload in {dt:.1f} s on {threads} threads (all {cores} visible cores), "
+                      f"own exact CPU restatement {names[best]}, OpenMP over gates; not TFHEpp",
+            "restatements": {m: {"gates_per_s": r[0], "sample_gates": r[1], "seconds": r[2]} for m, r in results.items()},
+            "ms_per_gate_per_thread": threads / rate * 1e3}
 
 
 def main():
@@ -138,7 +171,7 @@ def main():
     import torch.distributed as dist
 
     from iyokan_amd import client, hip
-    from iyokan_amd.params import OPS, params_by_name
+    from iyokan_amd.params import OPS, PLAIN, params_by_name
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,7 +189,9 @@ def main():
 
     params = params_by_name(args.params)
     op_code = OPS[args.op]
-    G = args.gates
+    G_total = args.gates
+    _, G_mine = shard(G_total, world, rank)      # strong scaling: this rank's block of the one batch
+    G_alloc = G_total if (world > 1 and not args.no_weak) else G_mine   # the weak leg runs G_total gates per rank
 
     # ---- keys: rank 0 generates, RCCL broadcast (north_star: "bootstrapping key broadcast once") ----
     keys = client.keygen(params, seed=1) if rank == 0 else empty_keys(params)
@@ -164,61 +199,111 @@ def main():
         keys = broadcast_keys(keys, dist, dev, rank)
     hip.initialize(keys, device_ids=(local_rank,))
 
-    # ---- synthetic inputs: 2G fresh encryptions per rank (distinct data seed per rank) ----
+    # ---- synthetic inputs: fresh encryptions, distinct per rank (seeded); layout [in0 | in1 | out] ----
     rng = np.random.default_rng(1000 + rank)
-    bits = rng.integers(0, 2, size=2 * G).astype(np.uint8)
+    bits = rng.integers(0, 2, size=2 * G_alloc).astype(np.uint8)
     enc = client.encrypt_bits(keys, bits, seed=2 + rank)
-    arena_t = torch.zeros((3 * G, params.n + 1), dtype=torch.int32, device=dev)
-    arena_t[: 2 * G].copy_(torch.from_numpy(enc.view(np.int32)))
+    arena_t = torch.zeros((3 * G_alloc, params.n + 1), dtype=torch.int32, device=dev)
+    arena_t[: 2 * G_alloc].copy_(torch.from_numpy(enc.view(np.int32)))
     del enc
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.synchronize()
     st = hip.Stream(0, hip_stream=tstream.cuda_stream)
     arena = hip.Arena.from_torch(arena_t)
-    idx = np.arange(G, dtype=np.int32)
-    ops = np.full(G, op_code, dtype=np.int32)
-    in0, in1, in2, out = idx, idx + G, np.full(G, -1, dtype=np.int32), idx + 2 * G
 
-    def step():
-        st.gate_batch(arena, ops, in0, in1, in2, out)
+    def batch(count):
+        idx = np.arange(count, dtype=np.int32)
+        return (np.full(count, op_code, dtype=np.int32), idx, idx + G_alloc, np.full(count, -1, dtype=np.int32),
+                idx + 2 * G_alloc)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    st.timing_log_begin()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    nb, br_ms, ks_ms = st.timing_log_end()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(count, steps, warmup):
+        """W untimed + exactly K timed steps of `count` gates on this rank, barrier + synchronize on both sides,
+        MAX over ranks; also the summed kernel times from HIP events on the launch stream."""
+        desc = batch(count)
+        for _ in range(warmup):
+            st.gate_batch(arena, *desc)
+        fence()
+        st.timing_log_begin()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            st.gate_batch(arena, *desc)
+        fence()
+        elapsed = time.perf_counter() - t0
+        nb, br_ms, ks_ms = st.timing_log_end()
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, nb, br_ms, ks_ms
+
+    elapsed, nb, br_ms, ks_ms = timed(G_mine, args.steps, args.warmup)
 
     # ---- correctness of what was just timed: decrypt every output of the last step ----
-    got = arena_t[2 * G:].cpu().numpy().view(np.uint32)
-    from iyokan_amd.params import PLAIN
-
-    want = np.array([PLAIN[args.op](int(a), int(b)) for a, b in zip(bits[:G], bits[G:])], dtype=np.uint8)
+    got = arena_t[2 * G_alloc: 2 * G_alloc + G_mine].cpu().numpy().view(np.uint32)
+    want = np.array([PLAIN[args.op](int(a), int(b)) for a, b in zip(bits[:G_mine], bits[G_alloc: G_alloc + G_mine])],
+                    dtype=np.uint8)
     decrypt_ok = bool(np.array_equal(client.decrypt_bits(keys, got), want))
+
+    weak = None
+    if world > 1 and not args.no_weak:
+        w_elapsed, _, _, _ = timed(G_total, args.steps, 1)
+        weak = {"value": G_total * world * args.steps / w_elapsed, "unit": "gates/s",
+                "gates_per_step_per_gpu": G_total, "ms_per_step": w_elapsed / args.steps * 1e3, "scaling": "weak"}
 
     if rank == 0:
         fp_path = hip.ntt_path() == "fp50"
-        gates_total = G * args.steps * world
-        value = gates_total / elapsed
+        value = G_total * args.steps / elapsed
         b_gate = params.gate_algorithmic_bytes(rotations=1, inputs=2)
         # dominant kernel = blind_rotate: its share of B_gate is the BK stream + its own I/O
         br_bytes_per_gate = params.n * params.trgsw_rows * (params.k + 1) * params.N * 8 \
             + 2 * (params.n + 1) * 4 + (params.N + 1) * 4
         br_avg_s = (br_ms / max(nb, 1)) * 1e-3
-        achieved = br_bytes_per_gate * G / br_avg_s if br_avg_s > 0 else 0.0
+        achieved = br_bytes_per_gate * G_mine / br_avg_s if br_avg_s > 0 else 0.0
+        pmc = counters(args, G_mine)
+        traffic = args.traffic_bytes if args.traffic_bytes is not None else (pmc or {}).get("traffic_bytes_per_launch")
+        roofline = {
+            # what the counters show (profiles/): FP64 VALU issue, not HBM — see "valu" and "traffic_over_algorithmic"
+            "bound": "valu",
+            "bound_note": "measured bound: FP64 VALU issue (see valu{}); achieved/peak/frac are the SURVEY 8(d) CONTRACT figure "
+                          "(algorithmic key bytes / kernel time against HBM peak) — the key stream is served by L2, see "
+                          "traffic_over_algorithmic",
+            "contract_bound": "hbm",
+            "kernel": "blind_rotate_fp_kernel" if fp_path else "blind_rotate_kernel",
+            "achieved": achieved / 1e9,
+            "peak": HBM_PEAK_BYTES_PER_S / 1e9,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_BYTES_PER_S,
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": br_bytes_per_gate * G_mine,
+            "traffic_over_algorithmic": (traffic / (br_bytes_per_gate * G_mine)) if traffic else None,
+            "measured_hbm_GBps": (traffic / br_avg_s / 1e9) if (traffic and br_avg_s > 0) else None,
+            "avg_launch_ms": br_avg_s * 1e3,
+            "keyswitch_avg_launch_ms": ks_ms / max(nb, 1),
+            "gate_bytes": b_gate,
+            "gate_frac": value / world * b_gate / HBM_PEAK_BYTES_PER_S,
+        }
+        if pmc and pmc.get("valu_insts_per_launch") and br_avg_s > 0:
+            insts = pmc["valu_insts_per_launch"]
+            steps_per_launch = G_mine * params.n              # one wave per rotation, n CMUX steps each
+            ns = br_avg_s * 1e9 / (insts / N_SIMDS)
+            valu = {
+                "insts_per_launch": insts,
+                "insts_per_step_per_wave": insts / steps_per_launch,
+                "ns_per_winstr_per_simd": ns,                # live duration / committed instruction count
+                "peak_ns": VALU_PEAK_NS,                     # 4 cycles @ 2.4 GHz
+                "frac": VALU_PEAK_NS / ns,
+                "source": pmc["_file"],
+            }
+            if pmc.get("sustained_clock_ghz"):               # busy cycles / duration of the profiled launch
+                clk = pmc["sustained_clock_ghz"]
+                valu["sustained_clock_ghz"] = clk
+                valu["frac_at_sustained_clock"] = (4.0 / clk) / ns
+            roofline["valu"] = valu
         line = {
             "metric": baseline_metric() if args.params == "128bit" else "TFHE gate bootstraps/sec (80-bit params)",
             "value": value,
@@ -228,33 +313,22 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": ("u32 torus; NTT in f64 mod p = 3*2^48+1097729 (exact FMA arithmetic)" if fp_path
                       else "u32 torus; NTT in u64 mod 2^64-2^32+1"),
             "data": "synthetic",
             "config": {
-                "workload": f"{G} independent Hom{args.op} gates per GPU per step (flat DAG), {args.params} params, "
-                            "fresh encryptions, keys+ciphertexts resident in HBM",
+                "workload": f"{G_total} independent Hom{args.op} gates per step (flat DAG), {args.params} params, "
+                            f"fresh encryptions, keys+ciphertexts resident in HBM; sharded {G_mine} per GPU",
                 "params": {k: v for k, v in params.as_dict().items() if k not in ("alpha0", "alpha1")},
-                "gates_per_step_per_gpu": G,
+                "gates_per_step": G_total,
+                "gates_per_step_per_gpu": G_mine,
                 "parallelism": f"frontier sharded over {world} GPU(s), no data-path collective (flat DAG)",
                 "decrypt_check": decrypt_ok,
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "blind_rotate_fp_kernel" if fp_path else "blind_rotate_kernel",
-                "achieved": achieved / 1e9,
-                "peak": HBM_PEAK_BYTES_PER_S / 1e9,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_BYTES_PER_S,
-                "traffic": traffic_bytes(args, G),
-                "algorithmic_bytes_per_launch": br_bytes_per_gate * G,
-                "avg_launch_ms": br_avg_s * 1e3,
-                "keyswitch_avg_launch_ms": ks_ms / max(nb, 1),
-                "gate_bytes": b_gate,
-                "gate_frac": value / world * b_gate / HBM_PEAK_BYTES_PER_S,
-            },
+            "roofline": roofline,
+            "weak": weak,
         }
         if world == 1 and args.cpu_sample != 0:
             line["cpu_baseline"] = cpu_baseline(keys, params, op_code, args.cpu_sample, data_seed=99)

@@ -3,7 +3,7 @@
  * This is the library boundary that replaces the cuFHE C++ API used by Iyokan's GPU worker
  * (/root/reference/src/iyokan_cufhe.{hpp,cpp}, /root/reference/src/tfhepp_cufhe_wrapper.hpp).
  * Each entry point cites the reference call it replaces.  Plain C types only: pointers,
- * sizes, ints.  No function throws or aborts; every function returns an int status
+ * sizes, ints.  No function throws or aborts (host allocation failure is IYK_ERR_NOMEM); every function returns an int status
  * (IYK_OK == 0, negative on error) and iyk_hip_last_error() describes the last failure on
  * the calling thread.  The reference ignores cuFHE's return values and dies via
  * error::die() -> exit(1) (/root/reference/src/error.hpp:22-48); the C++ adapter
@@ -97,25 +97,67 @@ int iyk_hip_stream_destroy(iyk_hip_stream* st);
  * work enqueued so far has finished, 0 = still running, < 0 = error.  Never blocks. */
 int iyk_hip_stream_query(iyk_hip_stream* st);
 
+/* GPU index (0 .. ngpu-1) the stream was created on. */
+int iyk_hip_stream_gpu(iyk_hip_stream* st);
+
 /* Blocks until the stream is idle (the reference spins on StreamQuery instead:
  * /root/reference/src/iyokan_cufhe.hpp:723-735). */
 int iyk_hip_stream_sync(iyk_hip_stream* st);
 
 /* ---- device-resident ciphertext arena -------------------------------------------------- */
 
-/* Device buffer of `slots` TLWE lvl0 ciphertexts on the stream's GPU.  Replaces the
+/* Every call that takes an arena pointer also takes `arena_slots`, the number of ciphertexts the buffer
+ * holds: all slot indices are validated against it and a bad descriptor is IYK_ERR_INVALID, never an
+ * out-of-bounds device access. */
+
+/* Device buffer of `slots` TLWE lvl0 ciphertexts on GPU gpu_index.  Replaces the
  * per-device mirror behind cufhe::Ctxt<lvl0param> (/root/reference/src/tfhepp_cufhe_wrapper.hpp:43-66);
  * a caller that already owns device memory (a torch tensor) may pass its pointer to the
  * batch calls directly instead. */
 int iyk_hip_arena_alloc(int gpu_index, uint64_t slots, uint32_t** d_arena_out);
 int iyk_hip_arena_free(int gpu_index, uint32_t* d_arena);
 
-/* Host <-> arena copies, ordered on the stream (Ctxt::tlwehost <-> device;
- * /root/reference/src/iyokan_cufhe.hpp:217-222,238-241). */
-int iyk_hip_arena_upload(iyk_hip_stream* st, uint32_t* d_arena, uint64_t first_slot, uint64_t count,
-                         const uint32_t* host_tlwe);
-int iyk_hip_arena_download(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t first_slot,
-                           uint64_t count, uint32_t* host_tlwe);
+/* Host <-> arena copies of a CONTIGUOUS slot range, ordered on the stream (Ctxt::tlwehost <-> device;
+ * /root/reference/src/iyokan_cufhe.hpp:217-222,238-241).  The host buffer must stay valid until the
+ * stream is idle. */
+int iyk_hip_arena_upload(iyk_hip_stream* st, uint32_t* d_arena, uint64_t arena_slots, uint64_t first_slot,
+                         uint64_t count, const uint32_t* host_tlwe);
+int iyk_hip_arena_download(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t arena_slots,
+                           uint64_t first_slot, uint64_t count, uint32_t* host_tlwe);
+
+/* The same for a LIST of slots: host row j <-> arena slot slots[j].  One transfer + one scatter / gather
+ * kernel for all the INPUT / OUTPUT / RAM cells of a network instead of one synchronous 2.5 KB copy per
+ * cell (TaskCUFHEGateMem::set/get, /root/reference/src/iyokan_cufhe.hpp:80-88, copies per ciphertext).
+ * upload_slots copies the host rows before returning; download_slots' host buffer must stay valid until
+ * the stream is idle. */
+int iyk_hip_arena_upload_slots(iyk_hip_stream* st, uint32_t* d_arena, uint64_t arena_slots, uint64_t count,
+                               const int32_t* slots, const uint32_t* host_tlwe);
+int iyk_hip_arena_download_slots(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t arena_slots,
+                                 uint64_t count, const int32_t* slots, uint32_t* host_tlwe);
+
+/* Device -> device copy of a slot range (same or another GPU), ordered on `st`: growing an arena, the
+ * DFF latch of a whole register file. */
+int iyk_hip_arena_copy(iyk_hip_stream* st, uint32_t* d_dst, uint64_t dst_slots, uint64_t dst_first,
+                       const uint32_t* d_src, uint64_t src_slots, uint64_t src_first, uint64_t count);
+
+/* In-process multi-GPU (cufhe::SetGPUNum shape: streams of several GPUs driven by one host thread,
+ * /root/reference/src/main.cpp:147-148): copy the listed slots of the arena replica on st_src's GPU to the
+ * SAME slots of the replica on st_dst's GPU — gather on the source stream, one peer copy over xGMI and a
+ * scatter on the destination stream, ordered by events (no host synchronisation).  This is the exchange of a
+ * frontier's outputs at a level boundary; the reference bounces every ciphertext through host memory. */
+int iyk_hip_arena_sync_slots(iyk_hip_stream* st_src, const uint32_t* d_src, uint64_t src_slots,
+                             iyk_hip_stream* st_dst, uint32_t* d_dst, uint64_t dst_slots, uint64_t count,
+                             const int32_t* slots);
+
+/* TRLWE lvl1 buffers (a(X) then b(X), 2N words each) for the CMUX-memory tasks: replaces
+ * cufhe::cuFHETRLWElvl1 (/root/reference/src/iyokan_cufhe.hpp:592-661).  upload / download move a
+ * contiguous range; the host side holds TFHEpp::TRLWE<lvl1param> in the same word order. */
+int iyk_hip_trlwe_alloc(int gpu_index, uint64_t count, uint32_t** d_trlwe_out);
+int iyk_hip_trlwe_free(int gpu_index, uint32_t* d_trlwe);
+int iyk_hip_trlwe_upload(iyk_hip_stream* st, uint32_t* d_trlwe, uint64_t trlwe_slots, uint64_t first,
+                         uint64_t count, const uint32_t* host_trlwe);
+int iyk_hip_trlwe_download(iyk_hip_stream* st, const uint32_t* d_trlwe, uint64_t trlwe_slots, uint64_t first,
+                           uint64_t count, uint32_t* host_trlwe);
 
 /* ---- the hot path ---------------------------------------------------------------------- */
 
@@ -127,9 +169,12 @@ int iyk_hip_arena_download(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t
  * ops/in0/in1/in2/out are HOST arrays of length count (copied before return); in1/in2 are
  * ignored where the gate has fewer inputs (use -1).  A gate may write its output over one of its
  * OWN inputs; no output slot may be an input of ANOTHER gate of the same batch (the gates are
- * independent by contract).  Results are bit-identical to the CPU restatement in oracle/. */
-int iyk_hip_gate_batch(iyk_hip_stream* st, uint32_t* d_arena, uint64_t count, const int32_t* ops,
-                       const int32_t* in0, const int32_t* in1, const int32_t* in2,
+ * independent by contract).  Every index must lie in [0, arena_slots): anything else is IYK_ERR_INVALID.
+ * With the environment variable IYK_HIP_DEBUG=1 at iyk_hip_init the independence contract itself is
+ * verified (duplicate outputs, a gate reading another gate's output) and violations are IYK_ERR_INVALID.
+ * Results are bit-identical to the CPU restatement in oracle/. */
+int iyk_hip_gate_batch(iyk_hip_stream* st, uint32_t* d_arena, uint64_t arena_slots, uint64_t count,
+                       const int32_t* ops, const int32_t* in0, const int32_t* in1, const int32_t* in2,
                        const int32_t* out);
 
 /* One gate on HOST ciphertexts, same shape as cufhe::Nand(out, in0, in1, st): H2D of the
@@ -144,23 +189,25 @@ int iyk_hip_gate_host(iyk_hip_stream* st, int op, const uint32_t* in0, const uin
  * /root/reference/src/iyokan_cufhe.hpp:634-635, but extracted at index 0): for each job
  * lin = sa*arena[ia] + sb*arena[ib] + (0,..,0,off) -> TLWE lvl1 u32[N+1] at d_tlwe1 + job*(N+1).
  * Host arrays of length count; ib may be -1. */
-int iyk_hip_blind_rotate_batch(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t count,
-                               const int32_t* ia, const int32_t* ib, const int32_t* sa,
+int iyk_hip_blind_rotate_batch(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t arena_slots,
+                               uint64_t count, const int32_t* ia, const int32_t* ib, const int32_t* sa,
                                const int32_t* sb, const uint32_t* off, uint32_t* d_tlwe1);
 
-/* Blind rotation only, result left as a TRLWE lvl1 (a(X) then b(X), 2N words per job at
- * d_trlwe + job*2N).  Replaces cufhe::GateBootstrappingTLWE2TRLWElvl01NTT(cuFHETRLWElvl1&, Ctxt&, st)
- * (/root/reference/src/iyokan_cufhe.hpp:634-635).  Same job description as iyk_hip_blind_rotate_batch. */
-int iyk_hip_bootstrap_trlwe_batch(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t count,
-                                  const int32_t* ia, const int32_t* ib, const int32_t* sa,
-                                  const int32_t* sb, const uint32_t* off, uint32_t* d_trlwe);
+/* Blind rotation only, result left as a TRLWE lvl1 (a(X) then b(X), 2N words) in row trlwe_out[job] of
+ * d_trlwe (row `job` when trlwe_out is NULL).  Replaces cufhe::GateBootstrappingTLWE2TRLWElvl01NTT(
+ * cuFHETRLWElvl1&, Ctxt&, st) (/root/reference/src/iyokan_cufhe.hpp:634-635: TaskCUFHERAMGateBootstrapping
+ * writes the RAM cell's TRLWE `mem_`).  Same job description as iyk_hip_blind_rotate_batch. */
+int iyk_hip_bootstrap_trlwe_batch(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t arena_slots,
+                                  uint64_t count, const int32_t* ia, const int32_t* ib, const int32_t* sa,
+                                  const int32_t* sb, const uint32_t* off, uint32_t* d_trlwe,
+                                  uint64_t trlwe_slots, const int32_t* trlwe_out);
 
 /* Sample-extract(index 0) + identity key switch of TRLWEs into arena slots.  Replaces
  * cufhe::SampleExtractAndKeySwitch(Ctxt&, cuFHETRLWElvl1&, st) (/root/reference/src/iyokan_cufhe.hpp:601).
  * trlwe_index[g] selects the TRLWE (2N words each) in d_trlwe, out_slot[g] the destination slot. */
-int iyk_hip_sample_extract_keyswitch_batch(iyk_hip_stream* st, const uint32_t* d_trlwe, uint64_t count,
-                                           const int32_t* trlwe_index, const int32_t* out_slot,
-                                           uint32_t* d_arena);
+int iyk_hip_sample_extract_keyswitch_batch(iyk_hip_stream* st, const uint32_t* d_trlwe, uint64_t trlwe_slots,
+                                           uint64_t count, const int32_t* trlwe_index, const int32_t* out_slot,
+                                           uint32_t* d_arena, uint64_t arena_slots);
 
 /* Kernel-only time of the most recent iyk_hip_gate_batch on this stream, from HIP events
  * recorded on the stream around the blind-rotate and key-switch launches (milliseconds).
@@ -180,9 +227,11 @@ int iyk_hip_timing_log_end(iyk_hip_stream* st, uint64_t* batches, double* blind_
  * integers (forced with the environment variable IYK_HIP_NTT=goldilocks at init, or chosen when a
  * parameter set does not meet the FP64 field's exactness bound).  Both give identical ciphertexts.
  *
- * A/B knob for tests and measurements, read at every batch: IYK_HIP_LATENCY_KERNEL = 0 / 1 / 2 forces the
- * wave-per-rotation, the wave-per-level or the two-waves-per-level blind-rotate kernel; unset = chosen by
- * batch size. */
+ * A/B knob for tests and measurements, read at every batch: IYK_HIP_LATENCY_KERNEL = 0 / 1 / 2 / 3 forces the
+ * wave-per-rotation kernel or one of the workgroup-per-rotation kernels (1: wave per level, 2: two waves per
+ * level, 3: wave per (polynomial, level) — the default for narrow frontiers); unset = chosen by batch size
+ * (DESIGN.md section 6).  IYK_HIP_LATENCY_DEFAULT = 1 / 2 / 3 at init changes which of them the size-based
+ * dispatch uses. */
 int iyk_hip_ntt_path(void);
 
 /* Bytes of device memory holding keys on one GPU (NTT-domain BK + padded KSK + tables). */

@@ -1,0 +1,176 @@
+// blind_rotate_lat3.hpp — per-lane phases of the wave-per-(polynomial, level) low-latency blind rotation.
+//
+// Narrow frontiers (CAHP-class netlist levels: a few dozen gates) are bound by the LATENCY of one rotation:
+// n = 636 dependent CMUX steps.  A lone wavefront issues one VALU instruction per ~8 cycles on gfx950, so the
+// time of a step is (instructions on its longest dependent path) x 8 cycles: the way down is to cut that
+// path, i.e. to spread the step over more wavefronts.  Here ONE rotation runs on a workgroup of 2 LV waves:
+//   forward phase   wave (h, v) transforms digit polynomial (h, v) — a whole 1024-point negacyclic NTT on
+//                   64 lanes, 16 points per lane instead of 32 — multiplies it with the two key rows
+//                   BK_i[h LV + v][c], c = 0, 1, and adds both products into a shared NTT-domain sum in LDS
+//                   (ds_add_f64: the addends are exact integers below 2^53, so the order is irrelevant);
+//   inverse phase   waves (c, 0) transform sum_c back and update accumulator polynomial c.
+// Two workgroup barriers per step.  The other waves spend the inverse phase fetching the next step's key rows.
+//
+// 64-lane transform.  Same 32 x 32 four-step structure, tables and renormalisation schedules as the other
+// kernels (fpntt32.hpp), but a column's 32-point DIF is shared by the TWO half-waves: lane (half, t) holds
+// elements 16 half + r, r < 16, of column t.  Stage 0 pairs (j, j + 16) — one element in each half.  Two
+// v_permlane32_swap rounds do it without duplicating work:
+//   swap-in   (a[2m], a[2m+1]) of lanes (0, t) / (1, t)  ->  lane (0, t) holds the pair j = 2m, lane (1, t) the
+//             pair j = 2m + 1  (v_permlane32_swap exchanges the upper half of one register with the lower half
+//             of the other: one instruction per 32-bit word moves both directions at once);
+//   butterfly each lane: sum and twiddled difference of ITS pair (twiddle w^(2m + half) from 8 lane registers);
+//   swap-out  the same exchange again leaves all 16 sums in lane (0, t) and all 16 differences in lane (1, t),
+//             in natural order: exactly the two 16-blocks stages 1..4 work on, in-lane.
+// 32 swap instructions per pass on top of the arithmetic of half a 32-point DIF.  Operations on values are
+// those of ntt32_dif (plus renormalisations where EITHER half's static schedule asks for one), so all
+// magnitudes stay within the bounds proven there and the results are the same integers mod p: bit-identical
+// output.  csrc/emul.cpp runs these functions lane by lane on the CPU against the oracle.
+#pragma once
+#include "blind_rotate_fp.hpp"
+
+namespace iyk {
+namespace fp {
+
+// union of the two half-blocks' renormalisation schedules (a renormalisation never hurts: it is exact mod p
+// and only shrinks magnitudes)
+template <int PASS>
+struct Sched16 {
+    static constexpr const NormSched& S = PASS == PASS1 ? kSched1 : kSched2;
+    static constexpr bool sum0(int m) { return S.sum[0][2 * m] || S.sum[0][2 * m + 1]; }  // stage 0, pair j = 2m + half
+    static constexpr bool dif0() { return S.dif[0][16]; }                                  // only j = 0 has a twiddle-free difference
+    static constexpr bool sum(int s, int a) { return S.sum[s][a] || S.sum[s][16 + a]; }
+    static constexpr bool dif(int s, int b) { return S.dif[s][b] || S.dif[s][16 + b]; }
+};
+
+// stage 0 on the pairs a lane holds after the swap-in: (a[2m], a[2m+1]) = (u, v) of pair j = 2m + half
+// tw0[m] = w32^(2m + half) (balanced; w^0 = 1)
+template <int PASS>
+IYK_HD void dif16_stage0(double (&a)[16], int half, const double (&tw0)[8])
+{
+    typedef Sched16<PASS> U;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const double u = a[2 * m], v = a[2 * m + 1];
+        const double sum = u + v, dif = u - v;
+        a[2 * m] = U::sum0(m) ? norm(sum) : sum;
+        const double tw = mulmod(dif, tw0[m]);
+        if (m == 0) {
+            // pair j = 0 (lower half-wave) has the trivial twiddle: the schedule treats its difference like a sum
+            const double plain = U::dif0() ? norm(dif) : dif;
+            a[1] = half ? tw : plain;
+        }
+        else {
+            a[2 * m + 1] = tw;
+        }
+    }
+}
+
+// stages 1..4 inside a 16-block (the sums or the differences of stage 0), natural in, bit-reversed out:
+// a[q] becomes position 16 half + q of the full 32-point DIF
+template <int PASS>
+IYK_HD void dif16_stages14(double (&a)[16], const double* w)
+{
+    typedef Sched16<PASS> U;
+#pragma unroll
+    for (int s = 1; s < 5; ++s) {
+        const int len = 16 >> s;
+#pragma unroll
+        for (int blk = 0; blk < 16; blk += 2 * len) {
+#pragma unroll
+            for (int j = 0; j < len; ++j) {
+                const int x = blk + j, y = blk + j + len;
+                const double u = a[x], v = a[y];
+                const double sum = u + v, dif = u - v;
+                a[x] = U::sum(s, x) ? norm(sum) : sum;
+                a[y] = (j == 0) ? (U::dif(s, y) ? norm(dif) : dif) : mulmod(dif, w[j << s]);
+            }
+        }
+    }
+}
+
+// DIF output position 16 half + q holds frequency brv5(16 half + q) = 2 brv4(q) + half
+IYK_HD constexpr int brv4(int x) { return ((x & 1) << 3) | ((x & 2) << 1) | ((x & 4) >> 1) | ((x & 8) >> 3); }
+IYK_HD constexpr int freq16(int half, int q) { return 2 * brv4(q) + half; }
+// ... and, read as an inverse transform, index (32 - freq) mod 32
+IYK_HD constexpr int inv16(int half, int q) { return (32 - freq16(half, q)) & 31; }
+
+// forward pass 1, pre: td[r] = ((X^abar - 1) acc_h)[t + 32 (16 half + r)], digit of virtual level v, times
+// zeta^j2 from the twisted-digit table
+template <class D>
+IYK_HD void fwd1_pre16(int half, int t, int v, u32 abar, const u32* acc_h, double (&x)[16], const double* ztab)
+{
+    u32 td[16];
+#if defined(__HIP_DEVICE_COMPILE__)
+    // PRECONDITION (the kernel's LDS map honours it): acc_h is 4 KB aligned, so the wrapped byte address of the
+    // rotated coefficient is one v_and_or (see fwd1_diff in blind_rotate_fp.hpp)
+    typedef const __attribute__((address_space(3))) u32* lds_u32;
+    const u32 acc_base = (u32)(size_t)(lds_u32)acc_h;
+    const u32 base4 = (((u32)t - abar) << 2) + 2048u * (u32)half;
+    const u32* own = acc_h + t + 512 * half;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const u32 idx4 = base4 + 128u * (u32)r;
+        const u32 neg = (u32)((i32)(idx4 << 19) >> 31);       // bit 12 of 4 idx = bit 10 of idx
+        const u32 a = *(lds_u32)(size_t)((idx4 & 0xFFCu) | acc_base);
+        td[r] = (a ^ neg) + ((0u - own[32 * r]) - neg);
+    }
+#else
+    const u32 base = (u32)t - abar;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int j2 = 16 * half + r;
+        const u32 idx = base + 32u * (u32)j2;  // position of the rotated coefficient, mod 2N
+        const u32 neg = 0u - ((idx >> 10) & 1u);
+        const u32 rot = (acc_h[idx & (NTT_N - 1)] ^ neg) - neg;
+        td[r] = rot - acc_h[t + 32 * j2];
+    }
+#endif
+    const double* zt = ztab + 16 * half * ZTAB_DIGITS + ZTAB_DIGITS / 2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = zt[r * ZTAB_DIGITS + D::digit(td[r], v)];
+}
+
+// inter-pass twiddles: forward psi^(j1 (2 k2 + 1)) with j1 = t, k2 = freq16; inverse psi^(-j1 (2 k2 + 1)) / N with
+// k2 = t, j1 = inv16.  Tables in the LDS layout of the other workgroup-per-rotation kernels: twf_t[k2 * 32 + j1],
+// twi_t[j1 * 32 + k2].
+IYK_HD void fwd1_twiddle16(int half, int t, double (&x)[16], const double* twf_t)
+{
+#pragma unroll
+    for (int q = 0; q < 16; ++q) x[q] = mulmod(x[q], twf_t[freq16(half, q) * 32 + t]);
+}
+IYK_HD void inv1_twiddle16(int half, int t, double (&x)[16], const double* twi_t)
+{
+#pragma unroll
+    for (int q = 0; q < 16; ++q) x[q] = mulmod(x[q], twi_t[inv16(half, q) * 32 + t]);
+}
+
+// 32 x 32 transpose through a wave-owned f64 [32][33] matrix: value q goes to row freq16 / inv16, column t;
+// the lane then reads elements 16 half + r of row t
+template <bool INV>
+IYK_HD void xpose16_write(int half, int t, const double (&x)[16], double* xb)
+{
+#pragma unroll
+    for (int q = 0; q < 16; ++q) xb[(INV ? inv16(half, q) : freq16(half, q)) * XB_STRIDE + t] = x[q];
+}
+IYK_HD void xpose16_read(int half, int t, double (&x)[16], const double* xb)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = xb[t * XB_STRIDE + 16 * half + r];
+}
+
+// key rows of digit polynomial `row` for output polynomial c, the 16 frequencies of this lane: element
+// k = t + 32 k1 with k1 = freq16(half, q) sits at (k1 >> 1) * 64 + 2 t + (k1 & 1) = brv4(q) * 64 + 2 t + half
+IYK_HD const double* bk_lane16(const double* bk_step, int row, int c, int half, int t)
+{
+    return bk_step + (size_t)(row * 2 + c) * NTT_N + (size_t)(2 * t + half);
+}
+
+// inverse pass 2', post: zeta^(-j2) (zi16[q] = zeta^(-inv16(half, q)), a lane register), centred lift,
+// low 32 bits; returns the value to add to acc[t + 32 j2]
+IYK_HD u32 inv2_post16(double y, double zi)
+{
+    return to_torus32(norm(mulmod(y, zi)));
+}
+
+}  // namespace fp
+}  // namespace iyk

@@ -9,6 +9,7 @@
 #include "../../include/iyokan_hip_params.h"
 #include "blind_rotate_core.hpp"
 #include "blind_rotate_fp.hpp"
+#include "blind_rotate_lat3.hpp"
 
 using namespace iyk;
 
@@ -279,6 +280,146 @@ void blind_rotate_fp(const iyk_params* p, const u32* lin, const double* bk_ntt, 
     tlwe1[NTT_N] = acc_lds[NTT_N];
 #undef ALL_LANES
 }
+
+// ---------------------------------------------------------------------------------------------
+// Lane-by-lane emulation of kernels.hpp::blind_rotate_fp_lat3_kernel (blind_rotate_lat3.hpp): 2 LV waves per
+// rotation, wave (h, v) = digit polynomial h of level v, 16 points per lane, the two v_permlane32_swap rounds
+// of every pass modelled on the lane arrays, the shared NTT-domain sums as plain additions.
+template <class D>
+void blind_rotate_fp_lat3(const iyk_params* p, const u32* lin, const double* bk_ntt, u32* tlwe1)
+{
+    constexpr int LV = D::LV, W = 2 * LV;
+    const FpTables& T = fptables();
+    const fp::NttConsts& C = T.t.c;
+    std::vector<double> ztab(fp::ZTAB_ENTRIES);
+    for (int e = 0; e < fp::ZTAB_ENTRIES; ++e) ztab[e] = fp::ztab_entry(e, C.zf);
+    std::vector<u32> acc(2 * NTT_N);
+    std::vector<double> sum(2 * NTT_N, 0.0), xb((size_t)W * 32 * XB_STRIDE);
+    struct Lane {
+        double x[16], tw0[8], zi16[16];
+    };
+    std::vector<Lane> R((size_t)W * 64);
+    // v_permlane32_swap on registers (a[2m], a[2m+1]) of one wave: upper half of the first <-> lower half of the second
+    auto swap16 = [&](int wave) {
+        for (int m = 0; m < 8; ++m)
+            for (int l = 0; l < 32; ++l) std::swap(R[wave * 64 + 32 + l].x[2 * m], R[wave * 64 + l].x[2 * m + 1]);
+    };
+    auto trackw = [&](int wave) {
+        for (int lane = 0; lane < 64; ++lane)
+            for (double v : R[wave * 64 + lane].x) {
+                const double a = (v < 0 ? -v : v) / fp::P;
+                if (a > g_fp_maxabs) g_fp_maxabs = a;
+            }
+    };
+#define WAVE_LANES(w) for (int lane = 0; lane < 64; ++lane)
+    auto dif16 = [&](int wave, int pass) {
+        swap16(wave);
+        WAVE_LANES(wave)
+        {
+            Lane& r = R[wave * 64 + lane];
+            if (pass == 1) fp::dif16_stage0<fp::PASS1>(r.x, lane >> 5, r.tw0);
+            else fp::dif16_stage0<fp::PASS2>(r.x, lane >> 5, r.tw0);
+        }
+        trackw(wave);
+        swap16(wave);
+        WAVE_LANES(wave)
+        {
+            Lane& r = R[wave * 64 + lane];
+            if (pass == 1) fp::dif16_stages14<fp::PASS1>(r.x, C.w);
+            else fp::dif16_stages14<fp::PASS2>(r.x, C.w);
+        }
+        trackw(wave);
+    };
+    const u32 bbar = br_modswitch_b(lin[p->n]);
+    for (int wave = 0; wave < W; ++wave) {
+        const int h = wave / LV, v = wave % LV;
+        WAVE_LANES(wave)
+        {
+            const int half = lane >> 5, t = lane & 31;
+            Lane& r = R[wave * 64 + lane];
+            for (int m = 0; m < 8; ++m) r.tw0[m] = C.w[2 * m + half];
+            for (int q = 0; q < 16; ++q) r.zi16[q] = C.zi[fp::inv16(half, q)];
+            if (v == 0)
+                for (int rr = 0; rr < 16; ++rr) {
+                    const int j = t + 32 * (16 * half + rr);
+                    const u32 idx = ((u32)j - bbar) & (2 * NTT_N - 1);
+                    acc[h * NTT_N + j] = h ? ((idx & NTT_N) ? 0u - p->mu : p->mu) : 0u;
+                }
+        }
+    }
+    for (u32 i = 0; i < p->n; ++i) {
+        const u32 ab = br_modswitch_a(lin[i]);
+        const double* bk_step = bk_ntt + (size_t)i * (2 * LV) * 2 * NTT_N;
+        // forward phase (every wave), up to barrier 1
+        for (int wave = 0; wave < W; ++wave) {
+            const int h = wave / LV, v = wave % LV, row = h * LV + v;
+            double* wxb = xb.data() + (size_t)wave * 32 * XB_STRIDE;
+            WAVE_LANES(wave) fp::fwd1_pre16<D>(lane >> 5, lane & 31, v, ab, acc.data() + h * NTT_N, R[wave * 64 + lane].x, ztab.data());
+            dif16(wave, 1);
+            WAVE_LANES(wave)
+            {
+                fp::fwd1_twiddle16(lane >> 5, lane & 31, R[wave * 64 + lane].x, T.twf_t.data());
+                fp::xpose16_write<false>(lane >> 5, lane & 31, R[wave * 64 + lane].x, wxb);
+            }
+            WAVE_LANES(wave) fp::xpose16_read(lane >> 5, lane & 31, R[wave * 64 + lane].x, wxb);
+            dif16(wave, 2);
+            WAVE_LANES(wave)
+            {
+                const int half = lane >> 5, t = lane & 31;
+                const double* b0 = fp::bk_lane16(bk_step, row, 0, half, t);
+                const double* b1 = fp::bk_lane16(bk_step, row, 1, half, t);
+                for (int q = 0; q < 16; ++q) {
+                    double p0 = fp::mulmod(R[wave * 64 + lane].x[q], b0[fp::brv4(q) * 64]);
+                    double p1 = fp::mulmod(R[wave * 64 + lane].x[q], b1[fp::brv4(q) * 64]);
+                    if (LV > 3) {
+                        p0 = fp::norm(p0);
+                        p1 = fp::norm(p1);
+                    }
+                    double* dst = sum.data() + fp::freq16(half, q) * 32 + t;
+                    dst[0] += p0;
+                    dst[NTT_N] += p1;
+                    for (double vv : {dst[0], dst[NTT_N]}) {
+                        const double a = (vv < 0 ? -vv : vv) / fp::P;
+                        if (a > g_fp_maxabs) g_fp_maxabs = a;
+                    }
+                }
+            }
+        }
+        // inverse phase (waves (h, 0)), up to barrier 2
+        for (int h = 0; h < 2; ++h) {
+            const int wave = h * LV;
+            double* wxb = xb.data() + (size_t)wave * 32 * XB_STRIDE;
+            double* sum_c = sum.data() + h * NTT_N;
+            WAVE_LANES(wave)
+            {
+                const int half = lane >> 5, t = lane & 31;
+                for (int rr = 0; rr < 16; ++rr) {
+                    double* src = sum_c + (16 * half + rr) * 32 + t;
+                    R[wave * 64 + lane].x[rr] = fp::norm(*src);
+                    *src = 0.0;
+                }
+            }
+            dif16(wave, 1);
+            WAVE_LANES(wave)
+            {
+                fp::inv1_twiddle16(lane >> 5, lane & 31, R[wave * 64 + lane].x, T.twi_t.data());
+                fp::xpose16_write<true>(lane >> 5, lane & 31, R[wave * 64 + lane].x, wxb);
+            }
+            WAVE_LANES(wave) fp::xpose16_read(lane >> 5, lane & 31, R[wave * 64 + lane].x, wxb);
+            dif16(wave, 2);
+            WAVE_LANES(wave)
+            {
+                const int half = lane >> 5, t = lane & 31;
+                const Lane& r = R[wave * 64 + lane];
+                for (int q = 0; q < 16; ++q) acc[h * NTT_N + t + 32 * fp::inv16(half, q)] += fp::inv2_post16(r.x[q], r.zi16[q]);
+            }
+        }
+    }
+#undef WAVE_LANES
+    tlwe1[0] = acc[0];
+    for (u32 j = 1; j < (u32)NTT_N; ++j) tlwe1[j] = 0u - acc[NTT_N - j];
+    tlwe1[NTT_N] = acc[NTT_N];
+}
 }  // namespace
 
 extern "C" {
@@ -307,6 +448,15 @@ int iyk_emul_blind_rotate_fp(const iyk_params* p, const uint32_t* lin, const dou
     if (p->N != 1024 || p->k != 1) return -1;
     if (p->l == 3 && p->Bgbit == 6) blind_rotate_fp<fp::Decomp<3, 6, 1>>(p, lin, bk_ntt, tlwe1);
     else if (p->l == 2 && p->Bgbit == 10) blind_rotate_fp<fp::Decomp<2, 10, 2>>(p, lin, bk_ntt, tlwe1);
+    else return -1;
+    return 0;
+}
+
+int iyk_emul_blind_rotate_fp_lat3(const iyk_params* p, const uint32_t* lin, const double* bk_ntt, uint32_t* tlwe1)
+{
+    if (p->N != 1024 || p->k != 1) return -1;
+    if (p->l == 3 && p->Bgbit == 6) blind_rotate_fp_lat3<fp::Decomp<3, 6, 1>>(p, lin, bk_ntt, tlwe1);
+    else if (p->l == 2 && p->Bgbit == 10) blind_rotate_fp_lat3<fp::Decomp<2, 10, 2>>(p, lin, bk_ntt, tlwe1);
     else return -1;
     return 0;
 }

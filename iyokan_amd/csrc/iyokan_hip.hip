@@ -3,10 +3,14 @@
 // Host side of the MI355X backend: owns device-resident keys (NTT-domain BK, padded KSK,
 // twiddle tables) per GPU, streams with their (double-buffered) staging buffers, and turns a batch of
 // gate descriptors into a fixed launch sequence: elementwise (NOT/COPY/CONST), modswitch, blind rotation
-// (wave-per-rotation kernel for full rounds of 2048 + 3-wave kernel for the remainder), keyswitch_init +
-// keyswitch.  Chooses the exact-arithmetic field at init (FP64 p = 3*2^48+1097729 where its bound holds,
-// else / on request the 64-bit Goldilocks integers).  Replaces the cuFHE host API used at
-// /root/reference/src/iyokan_cufhe.cpp:530-536,721 and /root/reference/src/iyokan_cufhe.hpp:8-27,249-261.
+// (wave-per-rotation kernel for full rounds of 2048 + a workgroup-per-rotation kernel for the remainder),
+// keyswitch_init + keyswitch.  Chooses the exact-arithmetic field at init (FP64 p = 3*2^48+1097729 where its
+// bound holds, else / on request the 64-bit Goldilocks integers).  Replaces the cuFHE host API used at
+// /root/reference/src/iyokan_cufhe.cpp:530-536,721 and /root/reference/src/iyokan_cufhe.hpp:8-27,249-261,601,634.
+//
+// Robustness rules of this file: nothing throws across extern "C" (IYK_API_BEGIN / IYK_API_END), every HIP
+// call is checked, every slot index is validated against the arena size the caller states, kernel attributes
+// are set once per device inside iyk_hip_init (under its lock), a failed init releases what it allocated.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -14,7 +18,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/iyokan_hip.h"
@@ -39,6 +45,15 @@ int fail(int code, const std::string& msg)
             return fail(IYK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
     } while (0)
 
+// the header promises "never throws": std::vector growth is the only throwing operation in here
+#define IYK_API_BEGIN try {
+#define IYK_API_END                                                                     \
+    }                                                                                   \
+    catch (const std::bad_alloc&) { return fail(IYK_ERR_NOMEM, "out of host memory"); } \
+    catch (...) { return fail(IYK_ERR_STATE, "unexpected C++ exception"); }
+
+constexpr int MAX_GPUS = 64;
+
 struct Device {
     int ordinal = -1;
     u64* bk_ntt = nullptr;   // NTT-domain BK: u64 residues mod 2^64-2^32+1, or doubles mod p = 3*2^48+1097729 (fp path)
@@ -46,17 +61,31 @@ struct Device {
     u64* tw_fwd = nullptr;   // u64 or double tables, same size
     u64* tw_inv = nullptr;
     fp::NttConsts* fpc = nullptr;  // FP path: 32-point twiddles + twists, read by scalar loads
+    void release()
+    {
+        if (ordinal < 0) return;
+        (void)hipSetDevice(ordinal);
+        if (bk_ntt) (void)hipFree(bk_ntt);
+        if (ksk) (void)hipFree(ksk);
+        if (tw_fwd) (void)hipFree(tw_fwd);
+        if (tw_inv) (void)hipFree(tw_inv);
+        if (fpc) (void)hipFree(fpc);
+        bk_ntt = nullptr;
+        ksk = nullptr;
+        tw_fwd = tw_inv = nullptr;
+        fpc = nullptr;
+    }
 };
 
 struct Global {
     std::mutex mu;
-    bool init = false;
+    std::atomic<bool> init{false};
+    bool debug = false;           // IYK_HIP_DEBUG=1 at init: gate_batch also verifies the independence contract
     iyk_params p{};
     u32 ksk_stride = 0;
     bool use_fp = false;          // FP64 path (fp50.hpp) instead of Goldilocks integers
-    int lat_threshold = 1100;      // rotations per batch at or below which the low-latency kernel is used
-    int lat2_threshold = 0;        // ... and at or below which its two-waves-per-level variant is used (0: never —
-                                   // since the one-wave-per-level kernel prefetches its key rows it is the faster one)
+    int lat_threshold = 1100;     // rotations per batch at or below which a workgroup-per-rotation kernel is used
+    int lat_kernel = 3;           // which one: 1 = wave per level, 2 = two waves per level, 3 = wave per (polynomial, level)
     fp::NttConsts fpc{};
     std::vector<Device> devs;
     std::atomic<int> nstreams{0};
@@ -75,8 +104,9 @@ struct iyk_hip_stream {
     char* d_stage = nullptr;
     size_t stage_cap = 0;             // bytes per half
     int stage_sel = 0;
-    hipEvent_t stage_free = nullptr;  // H2D descriptor copy out of half 0 done
+    hipEvent_t stage_free = nullptr;  // work reading half 0 done
     hipEvent_t stage_free1 = nullptr; // ... half 1
+    hipEvent_t xfer = nullptr, xfer2 = nullptr;  // cross-stream hand-offs of iyk_hip_arena_sync_slots
     // blind-rotation outputs (TLWE lvl1), one row per rotation job
     u32* d_rot = nullptr;
     u32* d_abar = nullptr;  // mod-switched rotation inputs, one row of ABAR_STRIDE words per job
@@ -107,9 +137,10 @@ int ensure_stage(iyk_hip_stream* st, size_t bytes)
     if (bytes <= st->stage_cap) return IYK_OK;
     HIP_TRY(hipStreamSynchronize(st->s));
     if (st->h_stage) HIP_TRY(hipHostFree(st->h_stage));
-    if (st->d_stage) HIP_TRY(hipFree(st->d_stage));
     st->h_stage = nullptr;
+    if (st->d_stage) HIP_TRY(hipFree(st->d_stage));
     st->d_stage = nullptr;
+    st->stage_cap = 0;
     size_t cap = (bytes + bytes / 2 + 4096 + 255) & ~(size_t)255;
     HIP_TRY(hipHostMalloc((void**)&st->h_stage, 2 * cap, hipHostMallocDefault));
     HIP_TRY(hipMalloc((void**)&st->d_stage, 2 * cap));
@@ -138,9 +169,10 @@ int ensure_rot(iyk_hip_stream* st, size_t jobs)
     if (jobs <= st->rot_cap) return IYK_OK;
     HIP_TRY(hipStreamSynchronize(st->s));
     if (st->d_rot) HIP_TRY(hipFree(st->d_rot));
-    if (st->d_abar) HIP_TRY(hipFree(st->d_abar));
     st->d_rot = nullptr;
+    if (st->d_abar) HIP_TRY(hipFree(st->d_abar));
     st->d_abar = nullptr;
+    st->rot_cap = 0;
     size_t cap = jobs + jobs / 2 + 64;
     HIP_TRY(hipMalloc((void**)&st->d_rot, cap * (NTT_N + 1) * sizeof(u32)));
     HIP_TRY(hipMalloc((void**)&st->d_abar, cap * ABAR_STRIDE * sizeof(u32)));
@@ -148,113 +180,91 @@ int ensure_rot(iyk_hip_stream* st, size_t jobs)
     return IYK_OK;
 }
 
+// Where a rotation kernel writes job `first + j`: row out_index[first + j] of d_out when an index list is given
+// (TRLWE memories of the CMUX-RAM tasks), else row first + j.
+struct RotOut {
+    u32* base;
+    const int32_t* index;  // device pointer or nullptr
+    int trlwe;
+    u32* at(int first) const { return index ? base : base + (size_t)first * (trlwe ? 2 * NTT_N : NTT_N + 1); }
+    const int32_t* idx(int first) const { return index ? index + first : nullptr; }
+};
+
 template <int L, int BGBIT>
-int launch_br(iyk_hip_stream* st, int njobs, u32* d_tlwe1, int trlwe)
+int launch_br(iyk_hip_stream* st, int njobs, const RotOut& o)
 {
-    static bool attr_set[64] = {};
     const Device& D = G.devs[st->gpu];
-    auto kern = blind_rotate_kernel<L, BGBIT>;
-    if (!attr_set[st->gpu]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)BR_LDS_BYTES));
-        attr_set[st->gpu] = true;
-    }
     dim3 grid((njobs + BR_WAVES - 1) / BR_WAVES), block(64 * BR_WAVES);
-    hipLaunchKernelGGL(kern, grid, block, BR_LDS_BYTES, st->s, (const u32*)st->d_abar, njobs,
-                       (const u64*)D.bk_ntt, (const u64*)D.tw_fwd, (const u64*)D.tw_inv, d_tlwe1, G.p.n, G.p.mu,
-                       ABAR_STRIDE, trlwe);
+    hipLaunchKernelGGL((blind_rotate_kernel<L, BGBIT>), grid, block, BR_LDS_BYTES, st->s, (const u32*)st->d_abar, njobs,
+                       (const u64*)D.bk_ntt, (const u64*)D.tw_fwd, (const u64*)D.tw_inv, o.at(0), G.p.n, G.p.mu,
+                       ABAR_STRIDE, o.trlwe, o.idx(0));
     HIP_TRY(hipGetLastError());
     return IYK_OK;
 }
 
 template <class DC>
-int launch_br_fp(iyk_hip_stream* st, int first, int njobs, u32* d_tlwe1, int trlwe)
+int launch_br_fp(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
 {
-    static bool attr_set[64] = {};
     const Device& D = G.devs[st->gpu];
-    auto kern = blind_rotate_fp_kernel<DC>;
-    if (!attr_set[st->gpu]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)BR_FP_LDS_BYTES));
-        attr_set[st->gpu] = true;
-    }
     dim3 grid((njobs + BR_WAVES - 1) / BR_WAVES), block(64 * BR_WAVES);
-    hipLaunchKernelGGL(kern, grid, block, BR_FP_LDS_BYTES, st->s, (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE,
-                       njobs, (const double*)D.bk_ntt, (const double*)D.tw_fwd, (const double*)D.tw_inv + NTT_N, D.fpc,
-                       d_tlwe1 + (size_t)first * (trlwe ? 2 * NTT_N : NTT_N + 1), G.p.n, G.p.mu, ABAR_STRIDE, trlwe);
-    HIP_TRY(hipGetLastError());
-    return IYK_OK;
-}
-
-// narrow frontiers: one rotation per workgroup of L waves (kernels.hpp, blind_rotate_fp_lat_kernel)
-template <class DC>
-int launch_br_fp_lat(iyk_hip_stream* st, int first, int njobs, u32* d_tlwe1, int trlwe)
-{
-    static bool attr_set[64] = {};
-    const Device& D = G.devs[st->gpu];
-    auto kern = blind_rotate_fp_lat_kernel<DC>;
-    constexpr int L = DC::LV;
-    constexpr size_t lds = br_lat_lds_bytes<L>();
-    if (!attr_set[st->gpu]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
-        attr_set[st->gpu] = true;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3(64 * L), lds, st->s,
+    hipLaunchKernelGGL(blind_rotate_fp_kernel<DC>, grid, block, BR_FP_LDS_BYTES, st->s,
                        (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE, njobs, (const double*)D.bk_ntt,
-                       (const double*)D.tw_fwd, (const double*)D.tw_inv, D.fpc,
-                       d_tlwe1 + (size_t)first * (trlwe ? 2 * NTT_N : NTT_N + 1), G.p.n, G.p.mu, ABAR_STRIDE, trlwe);
+                       (const double*)D.tw_fwd, (const double*)D.tw_inv + NTT_N, D.fpc, o.at(first), G.p.n, G.p.mu,
+                       ABAR_STRIDE, o.trlwe, o.idx(first));
     HIP_TRY(hipGetLastError());
     return IYK_OK;
 }
 
-// narrowest frontiers: one rotation per workgroup of 2 L waves, each wave one half of every 32-point DIF
-// (kernels.hpp, blind_rotate_fp_lat2_kernel)
-template <class DC>
-int launch_br_fp_lat2(iyk_hip_stream* st, int first, int njobs, u32* d_tlwe1, int trlwe)
+// narrow frontiers: one rotation per workgroup (kernels.hpp).  KIND 1: LV waves, wave = gadget level;
+// KIND 2: 2 LV waves, wave = (level, half of every DIF); KIND 3: 2 LV waves, wave = (polynomial, level).
+template <class DC, int KIND>
+int launch_br_fp_wg(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
 {
-    static bool attr_set[64] = {};
     const Device& D = G.devs[st->gpu];
-    auto kern = blind_rotate_fp_lat2_kernel<DC>;
     constexpr int L = DC::LV;
-    constexpr size_t lds = BrLat2Lds<L>::BYTES;
-    if (!attr_set[st->gpu]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
-        attr_set[st->gpu] = true;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3(128 * L), lds, st->s,
-                       (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE, njobs, (const double*)D.bk_ntt,
-                       (const double*)D.tw_fwd, (const double*)D.tw_inv, D.fpc,
-                       d_tlwe1 + (size_t)first * (trlwe ? 2 * NTT_N : NTT_N + 1), G.p.n, G.p.mu, ABAR_STRIDE, trlwe);
+    const u32* abar = (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE;
+    if (KIND == 1)
+        hipLaunchKernelGGL(blind_rotate_fp_lat_kernel<DC>, dim3((unsigned)njobs), dim3(64 * L), br_lat_lds_bytes<L>(), st->s,
+                           abar, njobs, (const double*)D.bk_ntt, (const double*)D.tw_fwd, (const double*)D.tw_inv, D.fpc,
+                           o.at(first), G.p.n, G.p.mu, ABAR_STRIDE, o.trlwe, o.idx(first));
+    else if (KIND == 2)
+        hipLaunchKernelGGL(blind_rotate_fp_lat2_kernel<DC>, dim3((unsigned)njobs), dim3(128 * L), BrLat2Lds<L>::BYTES, st->s,
+                           abar, njobs, (const double*)D.bk_ntt, (const double*)D.tw_fwd, (const double*)D.tw_inv, D.fpc,
+                           o.at(first), G.p.n, G.p.mu, ABAR_STRIDE, o.trlwe, o.idx(first));
+    else
+        hipLaunchKernelGGL(blind_rotate_fp_lat3_kernel<DC>, dim3((unsigned)njobs), dim3(BrLat3<DC>::THREADS), BrLat3<DC>::LDS_BYTES,
+                           st->s, abar, njobs, (const double*)D.bk_ntt, (const double*)D.tw_fwd, (const double*)D.tw_inv, D.fpc,
+                           o.at(first), G.p.n, G.p.mu, ABAR_STRIDE, o.trlwe, o.idx(first));
     HIP_TRY(hipGetLastError());
     return IYK_OK;
 }
-
-// Measured (profiles/r01_sweep_kernels.txt): the wave-per-rotation kernel runs 2048 rotations per 23 ms
-// round; the one-wave-per-level kernel takes 6.3 ms for <= 256 and ~18 ms per 1024; the two-waves-per-level
-// kernel (6.4 ms, 25 ms per 1024) is kept for A/B only.  So: full 2048-rounds on the first, a remainder of
-// up to lat_threshold rotations on the second.
 template <class DC>
-int dispatch_fp(iyk_hip_stream* st, int njobs, u32* d_tlwe1, int trlwe)
+int launch_br_fp_lat_any(iyk_hip_stream* st, int kind, int first, int njobs, const RotOut& o)
+{
+    if (kind == 1) return launch_br_fp_wg<DC, 1>(st, first, njobs, o);
+    if (kind == 2) return launch_br_fp_wg<DC, 2>(st, first, njobs, o);
+    return launch_br_fp_wg<DC, 3>(st, first, njobs, o);
+}
+
+// Dispatch (profiles/*sweep*): full rounds of 2048 rotations (8 per CU on 256 CUs) on the wave-per-rotation
+// kernel, a remainder of up to lat_threshold rotations on a workgroup-per-rotation kernel.
+template <class DC>
+int dispatch_fp(iyk_hip_stream* st, int njobs, const RotOut& o)
 {
     int rc;
-    const char* lat = std::getenv("IYK_HIP_LATENCY_KERNEL");  // "0" / "1" / "2" force one kernel (A/B, tests)
-    if (lat && lat[0] == '2') return launch_br_fp_lat2<DC>(st, 0, njobs, d_tlwe1, trlwe);
-    if (lat && lat[0] == '1') return launch_br_fp_lat<DC>(st, 0, njobs, d_tlwe1, trlwe);
-    if (lat && lat[0] == '0') return launch_br_fp<DC>(st, 0, njobs, d_tlwe1, trlwe);
+    const char* lat = std::getenv("IYK_HIP_LATENCY_KERNEL");  // "0" / "1" / "2" / "3" force one kernel (A/B, tests)
+    if (lat && lat[0] >= '1' && lat[0] <= '3') return launch_br_fp_lat_any<DC>(st, lat[0] - '0', 0, njobs, o);
+    if (lat && lat[0] == '0') return launch_br_fp<DC>(st, 0, njobs, o);
     const int round = 2048;
     const int rem = njobs % round, full = njobs - rem;
-    if (rem > G.lat_threshold) return launch_br_fp<DC>(st, 0, njobs, d_tlwe1, trlwe);
-    if (full && (rc = launch_br_fp<DC>(st, 0, full, d_tlwe1, trlwe))) return rc;
-    if (rem && rem <= G.lat2_threshold) return launch_br_fp_lat2<DC>(st, full, rem, d_tlwe1, trlwe);
-    if (rem) return launch_br_fp_lat<DC>(st, full, rem, d_tlwe1, trlwe);
+    if (rem > G.lat_threshold) return launch_br_fp<DC>(st, 0, njobs, o);
+    if (full && (rc = launch_br_fp<DC>(st, 0, full, o))) return rc;
+    if (rem) return launch_br_fp_lat_any<DC>(st, G.lat_kernel, full, rem, o);
     return IYK_OK;
 }
 
-// mod-switch every job into st->d_abar, then one wavefront per job
-int launch_blind_rotate(iyk_hip_stream* st, const u32* d_arena, const RotJob* d_jobs, int njobs,
-                        u32* d_tlwe1, int trlwe = 0)
+// mod-switch every job into st->d_abar, then the blind-rotation kernel(s)
+int launch_blind_rotate(iyk_hip_stream* st, const u32* d_arena, const RotJob* d_jobs, int njobs, const RotOut& o)
 {
     const iyk_params& p = G.p;
     int rc = ensure_rot(st, (size_t)njobs);
@@ -263,11 +273,11 @@ int launch_blind_rotate(iyk_hip_stream* st, const u32* d_arena, const RotJob* d_
                        ABAR_STRIDE);
     HIP_TRY(hipGetLastError());
     if (G.use_fp) {
-        if (p.l == 3) return dispatch_fp<fp::Decomp<3, 6, 1>>(st, njobs, d_tlwe1, trlwe);
-        return dispatch_fp<fp::Decomp<2, 10, 2>>(st, njobs, d_tlwe1, trlwe);
+        if (p.l == 3) return dispatch_fp<fp::Decomp<3, 6, 1>>(st, njobs, o);
+        return dispatch_fp<fp::Decomp<2, 10, 2>>(st, njobs, o);
     }
-    if (p.l == 3 && p.Bgbit == 6) return launch_br<3, 6>(st, njobs, d_tlwe1, trlwe);
-    if (p.l == 2 && p.Bgbit == 10) return launch_br<2, 10>(st, njobs, d_tlwe1, trlwe);
+    if (p.l == 3 && p.Bgbit == 6) return launch_br<3, 6>(st, njobs, o);
+    if (p.l == 2 && p.Bgbit == 10) return launch_br<2, 10>(st, njobs, o);
     return fail(IYK_ERR_INVALID, "unsupported (l, Bgbit)");
 }
 
@@ -278,13 +288,6 @@ int launch_keyswitch_t(iyk_hip_stream* st, u32* d_arena, const KsJob* d_jobs, in
 {
     const Device& D = G.devs[st->gpu];
     const iyk_params& p = G.p;
-    static bool attr_set[64] = {};
-    auto kern = keyswitch_kernel<T>;
-    if (!attr_set[st->gpu]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    KS_G * NTT_N * 2));
-        attr_set[st->gpu] = true;
-    }
     hipLaunchKernelGGL(keyswitch_init_kernel, dim3((unsigned)njobs), dim3(KS_THREADS), 0, st->s,
                        (const u32*)st->d_rot, d_jobs, d_arena, p.n);
     HIP_TRY(hipGetLastError());
@@ -292,7 +295,7 @@ int launch_keyswitch_t(iyk_hip_stream* st, u32* d_arena, const KsJob* d_jobs, in
     int slices = 1;
     while (slices < 64 && groups * slices < 512) slices *= 2;
     const u32 i_per_slice = (u32)NTT_N / (u32)slices;
-    hipLaunchKernelGGL(kern, dim3((unsigned)groups, (unsigned)slices), dim3(KS_THREADS),
+    hipLaunchKernelGGL(keyswitch_kernel<T>, dim3((unsigned)groups, (unsigned)slices), dim3(KS_THREADS),
                        (size_t)KS_G * i_per_slice * 2, st->s, (const u32*)st->d_rot, d_jobs, njobs,
                        (const u32*)D.ksk, d_arena, p.n, G.ksk_stride, i_per_slice);
     HIP_TRY(hipGetLastError());
@@ -305,6 +308,38 @@ int launch_keyswitch(iyk_hip_stream* st, u32* d_arena, const KsJob* d_jobs, int 
     case 8: return launch_keyswitch_t<8>(st, d_arena, d_jobs, njobs);
     case 5: return launch_keyswitch_t<5>(st, d_arena, d_jobs, njobs);
     default: return fail(IYK_ERR_INVALID, "key-switch kernel is instantiated for t in {5, 7, 8}");
+    }
+}
+
+// Dynamic-LDS limits of every kernel this parameter set can launch, for the CURRENT device.  Called once per
+// device from iyk_hip_init, under its lock (a lazily set static flag per launch site would race between streams
+// living on different host threads).
+template <class K>
+int set_lds(K kern, size_t bytes)
+{
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return IYK_OK;
+}
+template <class DC>
+int set_fp_attrs()
+{
+    int rc;
+    if ((rc = set_lds(blind_rotate_fp_kernel<DC>, BR_FP_LDS_BYTES))) return rc;
+    if ((rc = set_lds(blind_rotate_fp_lat_kernel<DC>, br_lat_lds_bytes<DC::LV>()))) return rc;
+    if ((rc = set_lds(blind_rotate_fp_lat2_kernel<DC>, BrLat2Lds<DC::LV>::BYTES))) return rc;
+    return set_lds(blind_rotate_fp_lat3_kernel<DC>, BrLat3<DC>::LDS_BYTES);
+}
+int set_kernel_attrs(const iyk_params& p, bool use_fp)
+{
+    int rc;
+    if (use_fp) rc = (p.l == 3) ? set_fp_attrs<fp::Decomp<3, 6, 1>>() : set_fp_attrs<fp::Decomp<2, 10, 2>>();
+    else rc = (p.l == 3) ? set_lds(blind_rotate_kernel<3, 6>, BR_LDS_BYTES) : set_lds(blind_rotate_kernel<2, 10>, BR_LDS_BYTES);
+    if (rc) return rc;
+    const size_t ks_lds = (size_t)KS_G * NTT_N * 2;
+    switch (p.t) {
+    case 7: return set_lds(keyswitch_kernel<7>, ks_lds);
+    case 8: return set_lds(keyswitch_kernel<8>, ks_lds);
+    default: return set_lds(keyswitch_kernel<5>, ks_lds);
     }
 }
 
@@ -324,100 +359,74 @@ bool gate_coeffs(int op, u32 mu, int32_t& sa, int32_t& sb, u32& off)
     }
 }
 
-}  // namespace
+inline bool slot_ok(int32_t s, uint64_t slots) { return s >= 0 && (uint64_t)s < slots; }
 
-extern "C" {
-
-const char* iyk_hip_last_error(void) { return g_last_error.c_str(); }
-
-int iyk_hip_is_initialized(void) { return G.init ? 1 : 0; }
-
-int iyk_hip_num_gpus(void) { return G.init ? (int)G.devs.size() : 0; }
-
-int iyk_hip_get_params(iyk_params* out)
+// fresh timing events for this batch when a log is active (so a whole timed region can be summed afterwards)
+int begin_timing(iyk_hip_stream* st)
 {
-    if (!G.init) return fail(IYK_ERR_STATE, "not initialised");
-    if (!out) return fail(IYK_ERR_INVALID, "null out");
-    *out = G.p;
+    if (st->log_on) {
+        hipEvent_t e3[3] = {nullptr, nullptr, nullptr};
+        for (auto& e : e3) {
+            hipError_t err = hipEventCreate(&e);
+            if (err != hipSuccess) {
+                for (auto& d : e3)
+                    if (d) (void)hipEventDestroy(d);
+                return fail(IYK_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(err));
+            }
+        }
+        st->log_events.insert(st->log_events.end(), e3, e3 + 3);
+        st->ev_br0 = e3[0];
+        st->ev_br1 = e3[1];
+        st->ev_ks1 = e3[2];
+    }
+    HIP_TRY(hipEventRecord(st->ev_br0, st->s));
     return IYK_OK;
 }
 
-/* 1 = FP64 field path (p = 3 * 2^48 + 1097729), 0 = Goldilocks integer path */
-int iyk_hip_ntt_path(void) { return G.init ? (G.use_fp ? 1 : 0) : IYK_ERR_STATE; }
-
-int iyk_hip_resident_key_bytes(uint64_t* out)
+void destroy_stream_resources(iyk_hip_stream* st)
 {
-    if (!G.init) return fail(IYK_ERR_STATE, "not initialised");
-    *out = G.key_bytes;
-    return IYK_OK;
-}
-
-int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, const uint32_t* bk_torus,
-                 const uint32_t* ksk)
-{
-    std::lock_guard<std::mutex> lock(G.mu);
-    if (G.init) return fail(IYK_ERR_STATE, "already initialised");
-    if (!params || !bk_torus || !ksk || ngpu < 1) return fail(IYK_ERR_INVALID, "null/invalid argument");
-    const iyk_params& p = *params;
-    if (p.N != (u32)NTT_N || p.k != 1) return fail(IYK_ERR_INVALID, "kernels require N == 1024, k == 1");
-    if (!((p.l == 3 && p.Bgbit == 6) || (p.l == 2 && p.Bgbit == 10)))
-        return fail(IYK_ERR_INVALID, "supported (l, Bgbit): (3, 6) [128-bit], (2, 10) [80-bit]");
-
-    if (p.basebit != 2 || !(p.t == 5 || p.t == 7 || p.t == 8))
-        return fail(IYK_ERR_INVALID, "key-switch kernel requires basebit == 2 and t in {5, 7, 8}");
-    if (((p.n + 1 + 3u) & ~3u) > 3 * KS_THREADS || p.n + 1 <= KS_THREADS)
-        return fail(IYK_ERR_INVALID, "key-switch kernel requires 256 < n + 1 <= 768");
-    int avail = 0;
-    HIP_TRY(hipGetDeviceCount(&avail));
-    if (avail < 1) return fail(IYK_ERR_HIP, "no HIP device visible");
-
-    // Path choice: the FP64 field (p = 3 * 2^48 + 1097729) is exact iff 2 * (k+1) l N (Bg/2) 2^31 < p
-    // (fp50.hpp); true for the 128-bit set, false for the 80-bit one.  IYK_HIP_NTT=goldilocks forces
-    // the 64-bit integer path (kept as the cross-check and for A/B measurements).
-    // (128-bit set: 3 levels of 6-bit digits; 80-bit set: each 10-bit digit split into two 5-bit halves,
-    // 4 virtual levels — blind_rotate_fp.hpp Decomp.)
-    const int split = (p.l == 2 && p.Bgbit == 10) ? 2 : 1;
-    const int LV = (int)p.l * split;
-    const double dmax = split == 1 ? (double)(1u << (p.Bgbit - 1)) : (double)(1u << (p.Bgbit / 2 - 1));
-    const double worst = 2.0 * (p.k + 1) * LV * p.N * dmax * 2147483648.0;
-    const char* force = std::getenv("IYK_HIP_NTT");
-    const bool use_fp = worst < fp::P && !(force && std::string(force) == "goldilocks");
-    std::vector<u64> twf(NTT_N), twi(2 * NTT_N);  // twi: [k2][j1], then the transposed copy [j1][k2]
-    fp::HostTables fpt;
-    if (use_fp) {
-        fp::make_tables(fpt);
-        std::memcpy(twf.data(), fpt.tw_fwd, sizeof(double) * NTT_N);
-        std::memcpy(twi.data(), fpt.tw_inv, sizeof(double) * NTT_N);
+    if (st->h_stage) (void)hipHostFree(st->h_stage);
+    if (st->d_stage) (void)hipFree(st->d_stage);
+    if (st->d_rot) (void)hipFree(st->d_rot);
+    if (st->d_abar) (void)hipFree(st->d_abar);
+    if (st->d_scratch) (void)hipFree(st->d_scratch);
+    for (hipEvent_t e : {st->stage_free, st->stage_free1, st->xfer, st->xfer2})
+        if (e) (void)hipEventDestroy(e);
+    if (st->log_on) {
+        for (hipEvent_t e : st->log_events) (void)hipEventDestroy(e);
     }
     else {
-        ntt_make_tables(twf.data(), twi.data());
+        for (hipEvent_t e : {st->ev_br0, st->ev_br1, st->ev_ks1})
+            if (e) (void)hipEventDestroy(e);
     }
+    if (st->owned && st->s) (void)hipStreamDestroy(st->s);
+}
 
-    for (int k2 = 0; k2 < 32; ++k2)
-        for (int j1 = 0; j1 < 32; ++j1) twi[NTT_N + j1 * 32 + k2] = twi[k2 * 32 + j1];
-
+int init_devices(std::vector<Device>& devs, const int* device_ids, int avail, const iyk_params& p, bool use_fp,
+                 int split, const uint32_t* bk_torus, const std::vector<u32>& ksk_pad, const std::vector<u64>& twf,
+                 const std::vector<u64>& twi, const fp::HostTables& fpt)
+{
     const size_t bk_words = (size_t)iyk_bk_words(&p);
     const size_t polys = bk_words / NTT_N;
-    const u32 nb = (1u << p.basebit) - 1;
-    const size_t ksk_rows = (size_t)p.N * p.t * nb;
-    const u32 stride = (p.n + 1 + 3u) & ~3u;
-    std::vector<u32> ksk_pad(ksk_rows * stride, 0u);
-    for (size_t r = 0; r < ksk_rows; ++r)
-        std::memcpy(&ksk_pad[r * stride], ksk + r * (p.n + 1), sizeof(u32) * (p.n + 1));
-
-    std::vector<Device> devs(ngpu);
-    for (int g = 0; g < ngpu; ++g) {
+    for (size_t g = 0; g < devs.size(); ++g) {
         Device& D = devs[g];
-        D.ordinal = device_ids ? device_ids[g] : g;
-        if (D.ordinal < 0 || D.ordinal >= avail) return fail(IYK_ERR_INVALID, "device ordinal out of range");
+        const int ord = device_ids ? device_ids[g] : (int)g;
+        if (ord < 0 || ord >= avail) return fail(IYK_ERR_INVALID, "device ordinal out of range");
+        D.ordinal = ord;
         HIP_TRY(hipSetDevice(D.ordinal));
+        int rc = set_kernel_attrs(p, use_fp);
+        if (rc) return rc;
         u32* d_bk = nullptr;
-        HIP_TRY(hipMalloc((void**)&d_bk, bk_words * sizeof(u32)));
         HIP_TRY(hipMalloc((void**)&D.bk_ntt, bk_words * sizeof(u64) * (use_fp ? split : 1)));
         HIP_TRY(hipMalloc((void**)&D.ksk, ksk_pad.size() * sizeof(u32)));
         HIP_TRY(hipMalloc((void**)&D.tw_fwd, NTT_N * sizeof(u64)));
         HIP_TRY(hipMalloc((void**)&D.tw_inv, 2 * NTT_N * sizeof(u64)));
         HIP_TRY(hipMalloc((void**)&D.fpc, sizeof(fp::NttConsts)));
+        HIP_TRY(hipMalloc((void**)&d_bk, bk_words * sizeof(u32)));
+        struct Tmp {  // the torus-domain copy is only needed until the forward NTT has run
+            u32* p;
+            ~Tmp() { (void)hipFree(p); }
+        } tmp{d_bk};
         HIP_TRY(hipMemcpy(D.fpc, &fpt.c, sizeof(fp::NttConsts), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_bk, bk_torus, bk_words * sizeof(u32), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(D.ksk, ksk_pad.data(), ksk_pad.size() * sizeof(u32), hipMemcpyHostToDevice));
@@ -432,100 +441,221 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
                                D.tw_fwd, polys);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipFree(d_bk));
     }
-    G.p = p;
-    G.use_fp = use_fp;
-    G.fpc = fpt.c;
-    G.ksk_stride = stride;
-    G.devs = devs;
-    G.key_bytes = bk_words * sizeof(u64) * (use_fp ? split : 1) + ksk_pad.size() * sizeof(u32) + 2 * NTT_N * sizeof(u64);
-    G.init = true;
     return IYK_OK;
 }
 
-int iyk_hip_cleanup(void)
+int stream_new(int gpu_index, void* wrap, bool do_wrap, iyk_hip_stream** out)
 {
-    std::lock_guard<std::mutex> lock(G.mu);
-    if (!G.init) return fail(IYK_ERR_STATE, "not initialised");
-    if (G.nstreams.load() != 0) return fail(IYK_ERR_STATE, "streams still alive");
-    for (Device& D : G.devs) {
-        HIP_TRY(hipSetDevice(D.ordinal));
-        HIP_TRY(hipFree(D.bk_ntt));
-        HIP_TRY(hipFree(D.ksk));
-        HIP_TRY(hipFree(D.tw_fwd));
-        HIP_TRY(hipFree(D.tw_inv));
-        HIP_TRY(hipFree(D.fpc));
-    }
-    G.devs.clear();
-    G.init = false;
-    return IYK_OK;
-}
-
-static int stream_new(int gpu_index, void* wrap, bool do_wrap, iyk_hip_stream** out)
-{
-    if (!G.init) return fail(IYK_ERR_STATE, "not initialised");
+    if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
     if (!out) return fail(IYK_ERR_INVALID, "null out");
     int rc = set_device(gpu_index);
     if (rc) return rc;
     iyk_hip_stream* st = new (std::nothrow) iyk_hip_stream();
     if (!st) return fail(IYK_ERR_NOMEM, "out of host memory");
     st->gpu = gpu_index;
+    hipError_t e = hipSuccess;
+    const char* what = "";
     if (do_wrap) {
         st->s = (hipStream_t)wrap;
         st->owned = false;
     }
     else {
-        hipError_t e = hipStreamCreateWithFlags(&st->s, hipStreamNonBlocking);
-        if (e != hipSuccess) {
-            delete st;
-            return fail(IYK_ERR_HIP, std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(e));
-        }
-        st->owned = true;
+        what = "hipStreamCreateWithFlags";
+        e = hipStreamCreateWithFlags(&st->s, hipStreamNonBlocking);
+        st->owned = (e == hipSuccess);
     }
-    (void)hipEventCreateWithFlags(&st->stage_free, hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&st->stage_free1, hipEventDisableTiming);
-    (void)hipEventCreate(&st->ev_br0);
-    (void)hipEventCreate(&st->ev_br1);
-    (void)hipEventCreate(&st->ev_ks1);
+    hipEvent_t* plain[] = {&st->stage_free, &st->stage_free1, &st->xfer, &st->xfer2};
+    for (hipEvent_t* ev : plain)
+        if (e == hipSuccess) {
+            what = "hipEventCreateWithFlags";
+            e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+        }
+    hipEvent_t* timed[] = {&st->ev_br0, &st->ev_br1, &st->ev_ks1};
+    for (hipEvent_t* ev : timed)
+        if (e == hipSuccess) {
+            what = "hipEventCreate";
+            e = hipEventCreate(ev);
+        }
+    if (e != hipSuccess) {
+        destroy_stream_resources(st);
+        delete st;
+        return fail(IYK_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    }
     G.nstreams.fetch_add(1);
     *out = st;
     return IYK_OK;
 }
 
-int iyk_hip_stream_create(int gpu_index, iyk_hip_stream** out) { return stream_new(gpu_index, nullptr, false, out); }
+int row_copy(iyk_hip_stream* st, void* dst, const void* src, size_t row_words, uint64_t total_rows, uint64_t first,
+             uint64_t count, bool device_is_dst, hipMemcpyKind kind)
+{
+    if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
+    if (!st || !dst || !src) return fail(IYK_ERR_INVALID, "null argument");
+    if (first > total_rows || count > total_rows - first) return fail(IYK_ERR_INVALID, "slot range outside the buffer");
+    if (count == 0) return IYK_OK;
+    int rc = set_device(st->gpu);
+    if (rc) return rc;
+    const size_t off = (size_t)first * row_words;
+    HIP_TRY(hipMemcpyAsync(device_is_dst ? (void*)((u32*)dst + off) : dst,
+                           device_is_dst ? src : (const void*)((const u32*)src + off),
+                           (size_t)count * row_words * sizeof(u32), kind, st->s));
+    return IYK_OK;
+}
+
+int check_slot_list(uint64_t count, const int32_t* slots, uint64_t arena_slots)
+{
+    for (uint64_t g = 0; g < count; ++g)
+        if (!slot_ok(slots[g], arena_slots)) return fail(IYK_ERR_INVALID, "slot index outside the arena");
+    return IYK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* iyk_hip_last_error(void) { return g_last_error.c_str(); }
+
+int iyk_hip_is_initialized(void) { return G.init.load() ? 1 : 0; }
+
+int iyk_hip_num_gpus(void) { return G.init.load() ? (int)G.devs.size() : 0; }
+
+int iyk_hip_get_params(iyk_params* out)
+{
+    if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
+    if (!out) return fail(IYK_ERR_INVALID, "null out");
+    *out = G.p;
+    return IYK_OK;
+}
+
+/* 1 = FP64 field path (p = 3 * 2^48 + 1097729), 0 = Goldilocks integer path */
+int iyk_hip_ntt_path(void) { return G.init.load() ? (G.use_fp ? 1 : 0) : IYK_ERR_STATE; }
+
+int iyk_hip_resident_key_bytes(uint64_t* out)
+{
+    if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
+    if (!out) return fail(IYK_ERR_INVALID, "null out");
+    *out = G.key_bytes;
+    return IYK_OK;
+}
+
+int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, const uint32_t* bk_torus,
+                 const uint32_t* ksk)
+{
+    IYK_API_BEGIN
+    std::lock_guard<std::mutex> lock(G.mu);
+    if (G.init.load()) return fail(IYK_ERR_STATE, "already initialised");
+    if (!params || !bk_torus || !ksk || ngpu < 1) return fail(IYK_ERR_INVALID, "null/invalid argument");
+    if (ngpu > MAX_GPUS) return fail(IYK_ERR_INVALID, "ngpu > 64");
+    const iyk_params& p = *params;
+    if (p.N != (u32)NTT_N || p.k != 1) return fail(IYK_ERR_INVALID, "kernels require N == 1024, k == 1");
+    if (!((p.l == 3 && p.Bgbit == 6) || (p.l == 2 && p.Bgbit == 10)))
+        return fail(IYK_ERR_INVALID, "supported (l, Bgbit): (3, 6) [128-bit], (2, 10) [80-bit]");
+
+    if (p.basebit != 2 || !(p.t == 5 || p.t == 7 || p.t == 8))
+        return fail(IYK_ERR_INVALID, "key-switch kernel requires basebit == 2 and t in {5, 7, 8}");
+    if (((p.n + 1 + 3u) & ~3u) > 3 * KS_THREADS || p.n + 1 <= KS_THREADS)
+        return fail(IYK_ERR_INVALID, "key-switch kernel requires 256 < n + 1 <= 768");
+    int avail = 0;
+    HIP_TRY(hipGetDeviceCount(&avail));
+    if (avail < 1) return fail(IYK_ERR_HIP, "no HIP device visible");
+
+    // Path choice: the FP64 field (p = 3 * 2^48 + 1097729) is exact iff 2 * (k+1) LV N dmax 2^31 < p
+    // (fp50.hpp).  128-bit set: 3 levels of 6-bit digits; 80-bit set: each 10-bit digit split into two 5-bit
+    // halves, 4 virtual levels (blind_rotate_fp.hpp Decomp).  IYK_HIP_NTT=goldilocks forces the 64-bit
+    // integer path (kept as the cross-check and for A/B measurements).
+    const int split = (p.l == 2 && p.Bgbit == 10) ? 2 : 1;
+    const int LV = (int)p.l * split;
+    const double dmax = split == 1 ? (double)(1u << (p.Bgbit - 1)) : (double)(1u << (p.Bgbit / 2 - 1));
+    const double worst = 2.0 * (p.k + 1) * LV * p.N * dmax * 2147483648.0;
+    const char* force = std::getenv("IYK_HIP_NTT");
+    const bool use_fp = worst < fp::P && !(force && std::string(force) == "goldilocks");
+    std::vector<u64> twf(NTT_N), twi(2 * NTT_N);  // twi: [k2][j1], then the transposed copy [j1][k2]
+    fp::HostTables fpt{};
+    if (use_fp) {
+        fp::make_tables(fpt);
+        std::memcpy(twf.data(), fpt.tw_fwd, sizeof(double) * NTT_N);
+        std::memcpy(twi.data(), fpt.tw_inv, sizeof(double) * NTT_N);
+    }
+    else {
+        ntt_make_tables(twf.data(), twi.data());
+    }
+    for (int k2 = 0; k2 < 32; ++k2)
+        for (int j1 = 0; j1 < 32; ++j1) twi[NTT_N + j1 * 32 + k2] = twi[k2 * 32 + j1];
+
+    const size_t bk_words = (size_t)iyk_bk_words(&p);
+    const u32 nb = (1u << p.basebit) - 1;
+    const size_t ksk_rows = (size_t)p.N * p.t * nb;
+    const u32 stride = (p.n + 1 + 3u) & ~3u;
+    std::vector<u32> ksk_pad(ksk_rows * stride, 0u);
+    for (size_t r = 0; r < ksk_rows; ++r)
+        std::memcpy(&ksk_pad[r * stride], ksk + r * (p.n + 1), sizeof(u32) * (p.n + 1));
+
+    std::vector<Device> devs(ngpu);
+    int rc = init_devices(devs, device_ids, avail, p, use_fp, split, bk_torus, ksk_pad, twf, twi, fpt);
+    if (rc) {  // release whatever the loop had allocated before it failed; keep its error text
+        const std::string keep = g_last_error;
+        for (Device& D : devs) D.release();
+        g_last_error = keep;
+        return rc;
+    }
+    const char* dbg = std::getenv("IYK_HIP_DEBUG");
+    const char* lk = std::getenv("IYK_HIP_LATENCY_DEFAULT");  // 1 / 2 / 3: kernel used for narrow frontiers
+    G.debug = dbg && dbg[0] == '1';
+    G.lat_kernel = (lk && lk[0] >= '1' && lk[0] <= '3') ? lk[0] - '0' : 3;
+    G.p = p;
+    G.use_fp = use_fp;
+    G.fpc = fpt.c;
+    G.ksk_stride = stride;
+    G.devs = devs;
+    G.key_bytes = bk_words * sizeof(u64) * (use_fp ? split : 1) + ksk_pad.size() * sizeof(u32) + 2 * NTT_N * sizeof(u64);
+    G.init.store(true);
+    return IYK_OK;
+    IYK_API_END
+}
+
+int iyk_hip_cleanup(void)
+{
+    IYK_API_BEGIN
+    std::lock_guard<std::mutex> lock(G.mu);
+    if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
+    if (G.nstreams.load() != 0) return fail(IYK_ERR_STATE, "streams still alive");
+    for (Device& D : G.devs) D.release();
+    G.devs.clear();
+    G.init.store(false);
+    return IYK_OK;
+    IYK_API_END
+}
+
+int iyk_hip_stream_create(int gpu_index, iyk_hip_stream** out)
+{
+    IYK_API_BEGIN
+    return stream_new(gpu_index, nullptr, false, out);
+    IYK_API_END
+}
 
 int iyk_hip_stream_wrap(int gpu_index, void* hip_stream, iyk_hip_stream** out)
 {
+    IYK_API_BEGIN
     return stream_new(gpu_index, hip_stream, true, out);
+    IYK_API_END
 }
 
 int iyk_hip_stream_destroy(iyk_hip_stream* st)
 {
+    IYK_API_BEGIN
     if (!st) return fail(IYK_ERR_INVALID, "null stream");
     int rc = set_device(st->gpu);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(st->s));
-    if (st->h_stage) (void)hipHostFree(st->h_stage);
-    if (st->d_stage) (void)hipFree(st->d_stage);
-    if (st->d_rot) (void)hipFree(st->d_rot);
-    if (st->d_abar) (void)hipFree(st->d_abar);
-    if (st->d_scratch) (void)hipFree(st->d_scratch);
-    (void)hipEventDestroy(st->stage_free);
-    (void)hipEventDestroy(st->stage_free1);
-    if (st->log_on) {
-        for (hipEvent_t e : st->log_events) (void)hipEventDestroy(e);
-    }
-    else {
-        (void)hipEventDestroy(st->ev_br0);
-        (void)hipEventDestroy(st->ev_br1);
-        (void)hipEventDestroy(st->ev_ks1);
-    }
-    if (st->owned) HIP_TRY(hipStreamDestroy(st->s));
+    destroy_stream_resources(st);
     delete st;
     G.nstreams.fetch_sub(1);
     return IYK_OK;
+    IYK_API_END
 }
+
+int iyk_hip_stream_gpu(iyk_hip_stream* st) { return st ? st->gpu : fail(IYK_ERR_INVALID, "null stream"); }
 
 int iyk_hip_stream_query(iyk_hip_stream* st)
 {
@@ -543,10 +673,12 @@ int iyk_hip_stream_sync(iyk_hip_stream* st)
     return IYK_OK;
 }
 
+/* ---- arenas ----------------------------------------------------------------------------- */
+
 int iyk_hip_arena_alloc(int gpu_index, uint64_t slots, uint32_t** d_arena_out)
 {
-    if (!G.init) return fail(IYK_ERR_STATE, "not initialised");
-    if (!d_arena_out || slots == 0) return fail(IYK_ERR_INVALID, "bad argument");
+    if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
+    if (!d_arena_out || slots == 0 || slots > (1ull << 31)) return fail(IYK_ERR_INVALID, "bad argument");
     int rc = set_device(gpu_index);
     if (rc) return rc;
     HIP_TRY(hipMalloc((void**)d_arena_out, slots * (G.p.n + 1) * sizeof(u32)));
@@ -555,41 +687,164 @@ int iyk_hip_arena_alloc(int gpu_index, uint64_t slots, uint32_t** d_arena_out)
 
 int iyk_hip_arena_free(int gpu_index, uint32_t* d_arena)
 {
-    if (!G.init) return fail(IYK_ERR_STATE, "not initialised");
+    if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
     int rc = set_device(gpu_index);
     if (rc) return rc;
     HIP_TRY(hipFree(d_arena));
     return IYK_OK;
 }
 
-int iyk_hip_arena_upload(iyk_hip_stream* st, uint32_t* d_arena, uint64_t first_slot, uint64_t count,
+int iyk_hip_trlwe_alloc(int gpu_index, uint64_t count, uint32_t** d_trlwe_out)
+{
+    if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
+    if (!d_trlwe_out || count == 0 || count > (1ull << 28)) return fail(IYK_ERR_INVALID, "bad argument");
+    int rc = set_device(gpu_index);
+    if (rc) return rc;
+    HIP_TRY(hipMalloc((void**)d_trlwe_out, count * 2 * NTT_N * sizeof(u32)));
+    return IYK_OK;
+}
+
+int iyk_hip_trlwe_free(int gpu_index, uint32_t* d_trlwe) { return iyk_hip_arena_free(gpu_index, d_trlwe); }
+
+int iyk_hip_arena_upload(iyk_hip_stream* st, uint32_t* d_arena, uint64_t arena_slots, uint64_t first_slot, uint64_t count,
                          const uint32_t* host_tlwe)
 {
-    if (!st || !d_arena || !host_tlwe) return fail(IYK_ERR_INVALID, "null argument");
-    int rc = set_device(st->gpu);
-    if (rc) return rc;
-    const size_t n1 = G.p.n + 1;
-    HIP_TRY(hipMemcpyAsync(d_arena + first_slot * n1, host_tlwe, count * n1 * sizeof(u32),
-                           hipMemcpyHostToDevice, st->s));
-    return IYK_OK;
+    return row_copy(st, d_arena, host_tlwe, (size_t)G.p.n + 1, arena_slots, first_slot, count, true, hipMemcpyHostToDevice);
 }
 
-int iyk_hip_arena_download(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t first_slot, uint64_t count,
-                           uint32_t* host_tlwe)
+int iyk_hip_arena_download(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t arena_slots, uint64_t first_slot,
+                           uint64_t count, uint32_t* host_tlwe)
 {
-    if (!st || !d_arena || !host_tlwe) return fail(IYK_ERR_INVALID, "null argument");
+    return row_copy(st, host_tlwe, d_arena, (size_t)G.p.n + 1, arena_slots, first_slot, count, false, hipMemcpyDeviceToHost);
+}
+
+int iyk_hip_trlwe_upload(iyk_hip_stream* st, uint32_t* d_trlwe, uint64_t trlwe_slots, uint64_t first, uint64_t count,
+                         const uint32_t* host_trlwe)
+{
+    return row_copy(st, d_trlwe, host_trlwe, 2 * NTT_N, trlwe_slots, first, count, true, hipMemcpyHostToDevice);
+}
+
+int iyk_hip_trlwe_download(iyk_hip_stream* st, const uint32_t* d_trlwe, uint64_t trlwe_slots, uint64_t first, uint64_t count,
+                           uint32_t* host_trlwe)
+{
+    return row_copy(st, host_trlwe, d_trlwe, 2 * NTT_N, trlwe_slots, first, count, false, hipMemcpyDeviceToHost);
+}
+
+int iyk_hip_arena_copy(iyk_hip_stream* st, uint32_t* d_dst, uint64_t dst_slots, uint64_t dst_first, const uint32_t* d_src,
+                       uint64_t src_slots, uint64_t src_first, uint64_t count)
+{
+    if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
+    if (!st || !d_dst || !d_src) return fail(IYK_ERR_INVALID, "null argument");
+    if (dst_first > dst_slots || count > dst_slots - dst_first || src_first > src_slots || count > src_slots - src_first)
+        return fail(IYK_ERR_INVALID, "slot range outside the arena");
+    if (count == 0) return IYK_OK;
     int rc = set_device(st->gpu);
     if (rc) return rc;
-    const size_t n1 = G.p.n + 1;
-    HIP_TRY(hipMemcpyAsync(host_tlwe, d_arena + first_slot * n1, count * n1 * sizeof(u32),
-                           hipMemcpyDeviceToHost, st->s));
+    const size_t n1 = (size_t)G.p.n + 1;
+    HIP_TRY(hipMemcpyAsync(d_dst + dst_first * n1, d_src + src_first * n1, count * n1 * sizeof(u32), hipMemcpyDefault, st->s));
     return IYK_OK;
 }
 
-int iyk_hip_gate_batch(iyk_hip_stream* st, uint32_t* d_arena, uint64_t count, const int32_t* ops,
+int iyk_hip_arena_upload_slots(iyk_hip_stream* st, uint32_t* d_arena, uint64_t arena_slots, uint64_t count,
+                               const int32_t* slots, const uint32_t* host_tlwe)
+{
+    IYK_API_BEGIN
+    if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
+    if (!st || !d_arena || !slots || !host_tlwe) return fail(IYK_ERR_INVALID, "null argument");
+    if (count == 0) return IYK_OK;
+    if (count > (1u << 24)) return fail(IYK_ERR_INVALID, "too many slots in one transfer");
+    int rc = check_slot_list(count, slots, arena_slots);
+    if (rc) return rc;
+    if ((rc = set_device(st->gpu))) return rc;
+    const size_t n1 = (size_t)G.p.n + 1;
+    const size_t idx_bytes = (count * sizeof(int32_t) + 15) & ~(size_t)15, row_bytes = count * n1 * sizeof(u32);
+    size_t soff = 0;
+    if ((rc = acquire_stage(st, idx_bytes + row_bytes, &soff))) return rc;
+    std::memcpy(st->h_stage + soff, slots, count * sizeof(int32_t));
+    std::memcpy(st->h_stage + soff + idx_bytes, host_tlwe, row_bytes);  // the caller's buffer is free on return
+    HIP_TRY(hipMemcpyAsync(st->d_stage + soff, st->h_stage + soff, idx_bytes + row_bytes, hipMemcpyHostToDevice, st->s));
+    hipLaunchKernelGGL(scatter_slots_kernel, dim3((unsigned)count), dim3(256), 0, st->s, d_arena,
+                       (const int32_t*)(st->d_stage + soff), (const u32*)(st->d_stage + soff + idx_bytes), G.p.n);
+    HIP_TRY(hipGetLastError());
+    return release_stage(st);
+    IYK_API_END
+}
+
+int iyk_hip_arena_download_slots(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t arena_slots, uint64_t count,
+                                 const int32_t* slots, uint32_t* host_tlwe)
+{
+    IYK_API_BEGIN
+    if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
+    if (!st || !d_arena || !slots || !host_tlwe) return fail(IYK_ERR_INVALID, "null argument");
+    if (count == 0) return IYK_OK;
+    if (count > (1u << 24)) return fail(IYK_ERR_INVALID, "too many slots in one transfer");
+    int rc = check_slot_list(count, slots, arena_slots);
+    if (rc) return rc;
+    if ((rc = set_device(st->gpu))) return rc;
+    const size_t n1 = (size_t)G.p.n + 1;
+    const size_t idx_bytes = (count * sizeof(int32_t) + 15) & ~(size_t)15, row_bytes = count * n1 * sizeof(u32);
+    size_t soff = 0;
+    if ((rc = acquire_stage(st, idx_bytes + row_bytes, &soff))) return rc;
+    std::memcpy(st->h_stage + soff, slots, count * sizeof(int32_t));
+    HIP_TRY(hipMemcpyAsync(st->d_stage + soff, st->h_stage + soff, idx_bytes, hipMemcpyHostToDevice, st->s));
+    hipLaunchKernelGGL(gather_slots_kernel, dim3((unsigned)count), dim3(256), 0, st->s, d_arena,
+                       (const int32_t*)(st->d_stage + soff), (u32*)(st->d_stage + soff + idx_bytes), G.p.n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host_tlwe, st->d_stage + soff + idx_bytes, row_bytes, hipMemcpyDeviceToHost, st->s));
+    return release_stage(st);
+    IYK_API_END
+}
+
+int iyk_hip_arena_sync_slots(iyk_hip_stream* st_src, const uint32_t* d_src, uint64_t src_slots, iyk_hip_stream* st_dst,
+                             uint32_t* d_dst, uint64_t dst_slots, uint64_t count, const int32_t* slots)
+{
+    IYK_API_BEGIN
+    if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
+    if (!st_src || !st_dst || !d_src || !d_dst || !slots) return fail(IYK_ERR_INVALID, "null argument");
+    if (st_src == st_dst) return fail(IYK_ERR_INVALID, "source and destination streams must differ");
+    if (count == 0) return IYK_OK;
+    if (count > (1u << 24)) return fail(IYK_ERR_INVALID, "too many slots in one transfer");
+    int rc = check_slot_list(count, slots, src_slots < dst_slots ? src_slots : dst_slots);
+    if (rc) return rc;
+    const size_t n1 = (size_t)G.p.n + 1;
+    const size_t idx_bytes = (count * sizeof(int32_t) + 15) & ~(size_t)15, row_bytes = count * n1 * sizeof(u32);
+    // source GPU: gather the listed slots into its staging buffer
+    size_t so = 0, dof = 0;
+    if ((rc = set_device(st_src->gpu))) return rc;
+    if ((rc = acquire_stage(st_src, idx_bytes + row_bytes, &so))) return rc;
+    std::memcpy(st_src->h_stage + so, slots, count * sizeof(int32_t));
+    HIP_TRY(hipMemcpyAsync(st_src->d_stage + so, st_src->h_stage + so, idx_bytes, hipMemcpyHostToDevice, st_src->s));
+    hipLaunchKernelGGL(gather_slots_kernel, dim3((unsigned)count), dim3(256), 0, st_src->s, d_src,
+                       (const int32_t*)(st_src->d_stage + so), (u32*)(st_src->d_stage + so + idx_bytes), G.p.n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(st_src->xfer, st_src->s));
+    // destination GPU: wait for the gather, pull the rows over the fabric (xGMI peer copy), scatter
+    if ((rc = set_device(st_dst->gpu))) return rc;
+    if ((rc = acquire_stage(st_dst, idx_bytes + row_bytes, &dof))) return rc;
+    std::memcpy(st_dst->h_stage + dof, slots, count * sizeof(int32_t));
+    HIP_TRY(hipMemcpyAsync(st_dst->d_stage + dof, st_dst->h_stage + dof, idx_bytes, hipMemcpyHostToDevice, st_dst->s));
+    HIP_TRY(hipStreamWaitEvent(st_dst->s, st_src->xfer, 0));
+    HIP_TRY(hipMemcpyAsync(st_dst->d_stage + dof + idx_bytes, st_src->d_stage + so + idx_bytes, row_bytes, hipMemcpyDefault,
+                           st_dst->s));
+    HIP_TRY(hipEventRecord(st_dst->xfer2, st_dst->s));
+    hipLaunchKernelGGL(scatter_slots_kernel, dim3((unsigned)count), dim3(256), 0, st_dst->s, d_dst,
+                       (const int32_t*)(st_dst->d_stage + dof), (const u32*)(st_dst->d_stage + dof + idx_bytes), G.p.n);
+    HIP_TRY(hipGetLastError());
+    if ((rc = release_stage(st_dst))) return rc;
+    // the source staging half is reusable once the peer copy has read it
+    if ((rc = set_device(st_src->gpu))) return rc;
+    HIP_TRY(hipStreamWaitEvent(st_src->s, st_dst->xfer2, 0));
+    return release_stage(st_src);
+    IYK_API_END
+}
+
+/* ---- the hot path ------------------------------------------------------------------------ */
+
+int iyk_hip_gate_batch(iyk_hip_stream* st, uint32_t* d_arena, uint64_t arena_slots, uint64_t count, const int32_t* ops,
                        const int32_t* in0, const int32_t* in1, const int32_t* in2, const int32_t* out)
 {
-    if (!G.init) return fail(IYK_ERR_STATE, "not initialised");
+    IYK_API_BEGIN
+    if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
     if (!st || !d_arena) return fail(IYK_ERR_INVALID, "null argument");
     if (count == 0) return IYK_OK;
     if (!ops || !in0 || !in1 || !in2 || !out) return fail(IYK_ERR_INVALID, "null descriptor array");
@@ -605,23 +860,25 @@ int iyk_hip_gate_batch(iyk_hip_stream* st, uint32_t* d_arena, uint64_t count, co
     ks.reserve(count);
     for (uint64_t g = 0; g < count; ++g) {
         const int op = ops[g];
-        if (out[g] < 0) return fail(IYK_ERR_INVALID, "negative output slot");
+        if (!slot_ok(out[g], arena_slots)) return fail(IYK_ERR_INVALID, "output slot outside the arena");
         int32_t sa, sb;
         u32 off;
         if (gate_coeffs(op, p.mu, sa, sb, off)) {
-            if (in0[g] < 0 || in1[g] < 0) return fail(IYK_ERR_INVALID, "binary gate needs two inputs");
+            if (!slot_ok(in0[g], arena_slots) || !slot_ok(in1[g], arena_slots))
+                return fail(IYK_ERR_INVALID, "binary gate needs two input slots inside the arena");
             ks.push_back(KsJob{(int32_t)rot.size(), -1, 0u, out[g]});
             rot.push_back(RotJob{in0[g], in1[g], sa, sb, off});
         }
         else if (op == IYK_OP_MUX) {
             // HomMUX(cs = in2, c1 = in1, c0 = in0): BR(cs + c1 - mu) + BR(c0 - cs - mu) + (0, mu) -> KS
-            if (in0[g] < 0 || in1[g] < 0 || in2[g] < 0) return fail(IYK_ERR_INVALID, "MUX needs three inputs");
+            if (!slot_ok(in0[g], arena_slots) || !slot_ok(in1[g], arena_slots) || !slot_ok(in2[g], arena_slots))
+                return fail(IYK_ERR_INVALID, "MUX needs three input slots inside the arena");
             ks.push_back(KsJob{(int32_t)rot.size(), (int32_t)rot.size() + 1, p.mu, out[g]});
             rot.push_back(RotJob{in2[g], in1[g], 1, 1, 0u - p.mu});
             rot.push_back(RotJob{in0[g], in2[g], 1, -1, 0u - p.mu});
         }
         else if (op == IYK_OP_NOT || op == IYK_OP_COPY) {
-            if (in0[g] < 0) return fail(IYK_ERR_INVALID, "NOT/COPY needs one input");
+            if (!slot_ok(in0[g], arena_slots)) return fail(IYK_ERR_INVALID, "NOT/COPY needs one input slot inside the arena");
             ew.push_back(EwJob{op, in0[g], out[g]});
         }
         else if (op == IYK_OP_CONSTONE || op == IYK_OP_CONSTZERO) {
@@ -629,6 +886,25 @@ int iyk_hip_gate_batch(iyk_hip_stream* st, uint32_t* d_arena, uint64_t count, co
         }
         else {
             return fail(IYK_ERR_INVALID, "unknown gate op");
+        }
+    }
+    if (G.debug) {
+        // the independence contract (header): output slots are pairwise distinct and no gate reads a slot that
+        // ANOTHER gate of this batch writes.  O(count) with a hash map; only under IYK_HIP_DEBUG=1.
+        std::unordered_map<int32_t, uint64_t> writer;
+        writer.reserve(count * 2);
+        for (uint64_t g = 0; g < count; ++g)
+            if (!writer.emplace(out[g], g).second)
+                return fail(IYK_ERR_INVALID, "debug: two gates of one batch write the same slot");
+        for (uint64_t g = 0; g < count; ++g) {
+            const int op = ops[g];
+            const int nin = op == IYK_OP_MUX ? 3 : op < IYK_OP_MUX ? 2 : (op == IYK_OP_NOT || op == IYK_OP_COPY) ? 1 : 0;
+            const int32_t ins[3] = {in0[g], in1[g], in2[g]};
+            for (int k = 0; k < nin; ++k) {
+                auto it = writer.find(ins[k]);
+                if (it != writer.end() && it->second != g)
+                    return fail(IYK_ERR_INVALID, "debug: a gate reads a slot another gate of the same batch writes");
+            }
         }
     }
 
@@ -649,7 +925,6 @@ int iyk_hip_gate_batch(iyk_hip_stream* st, uint32_t* d_arena, uint64_t count, co
     HIP_TRY(hipMemcpyAsync(ds, hs, total, hipMemcpyHostToDevice, st->s));
     if ((rc = release_stage(st))) return rc;
 
-    const Device& D = G.devs[st->gpu];
     if (!ew.empty()) {
         hipLaunchKernelGGL(elementwise_kernel, dim3((unsigned)ew.size()), dim3(256), 0, st->s, d_arena,
                            (const EwJob*)(ds + ew_off), p.n, p.mu);
@@ -657,16 +932,9 @@ int iyk_hip_gate_batch(iyk_hip_stream* st, uint32_t* d_arena, uint64_t count, co
     }
     st->timing_valid = false;
     if (!rot.empty()) {
-        if (st->log_on) {  // fresh events per batch so a whole timed region can be summed afterwards
-            hipEvent_t e3[3];
-            for (auto& e : e3) HIP_TRY(hipEventCreate(&e));
-            st->log_events.insert(st->log_events.end(), e3, e3 + 3);
-            st->ev_br0 = e3[0];
-            st->ev_br1 = e3[1];
-            st->ev_ks1 = e3[2];
-        }
-        HIP_TRY(hipEventRecord(st->ev_br0, st->s));
-        if ((rc = launch_blind_rotate(st, d_arena, (const RotJob*)ds, (int)rot.size(), st->d_rot))) return rc;
+        if ((rc = begin_timing(st))) return rc;
+        if ((rc = launch_blind_rotate(st, d_arena, (const RotJob*)ds, (int)rot.size(), RotOut{st->d_rot, nullptr, 0})))
+            return rc;
         HIP_TRY(hipEventRecord(st->ev_br1, st->s));
         if ((rc = launch_keyswitch(st, d_arena, (const KsJob*)(ds + ks_off), (int)ks.size()))) return rc;
         HIP_TRY(hipEventRecord(st->ev_ks1, st->s));
@@ -674,12 +942,14 @@ int iyk_hip_gate_batch(iyk_hip_stream* st, uint32_t* d_arena, uint64_t count, co
         st->timing_has_ks = true;
     }
     return IYK_OK;
+    IYK_API_END
 }
 
 int iyk_hip_gate_host(iyk_hip_stream* st, int op, const uint32_t* in0, const uint32_t* in1,
                       const uint32_t* in2, uint32_t* out)
 {
-    if (!G.init) return fail(IYK_ERR_STATE, "not initialised");
+    IYK_API_BEGIN
+    if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
     if (!st || !out) return fail(IYK_ERR_INVALID, "null argument");
     int rc = set_device(st->gpu);
     if (rc) return rc;
@@ -694,62 +964,83 @@ int iyk_hip_gate_host(iyk_hip_stream* st, int op, const uint32_t* in0, const uin
             idx[k] = k + 1;
         }
     const int32_t o = 0, opv = op;
-    if ((rc = iyk_hip_gate_batch(st, st->d_scratch, 1, &opv, &idx[0], &idx[1], &idx[2], &o))) return rc;
+    if ((rc = iyk_hip_gate_batch(st, st->d_scratch, 4, 1, &opv, &idx[0], &idx[1], &idx[2], &o))) return rc;
     HIP_TRY(hipMemcpyAsync(out, st->d_scratch, n1 * sizeof(u32), hipMemcpyDeviceToHost, st->s));
     return IYK_OK;
+    IYK_API_END
 }
 
 // shared body of the two rotation-only entry points
-static int rotate_only(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t count, const int32_t* ia,
+static int rotate_only(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t arena_slots, uint64_t count, const int32_t* ia,
                        const int32_t* ib, const int32_t* sa, const int32_t* sb, const uint32_t* off, uint32_t* d_out,
-                       int trlwe)
+                       int trlwe, uint64_t out_rows, const int32_t* out_index)
 {
-    if (!G.init) return fail(IYK_ERR_STATE, "not initialised");
+    if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
     if (!st || !d_arena || !d_out || !ia || !ib || !sa || !sb || !off) return fail(IYK_ERR_INVALID, "null argument");
     if (count == 0) return IYK_OK;
+    if (count > (1u << 30)) return fail(IYK_ERR_INVALID, "batch too large");
     int rc = set_device(st->gpu);
     if (rc) return rc;
     std::vector<RotJob> rot(count);
-    for (uint64_t g = 0; g < count; ++g) rot[g] = RotJob{ia[g], ib[g], sa[g], sb[g], off[g]};
-    const size_t bytes = rot.size() * sizeof(RotJob);
+    for (uint64_t g = 0; g < count; ++g) {
+        if (!slot_ok(ia[g], arena_slots) || (ib[g] >= 0 && !slot_ok(ib[g], arena_slots)))
+            return fail(IYK_ERR_INVALID, "input slot outside the arena");
+        if (out_index && !slot_ok(out_index[g], out_rows)) return fail(IYK_ERR_INVALID, "output index outside the buffer");
+        rot[g] = RotJob{ia[g], ib[g], sa[g], sb[g], off[g]};
+    }
+    if (!out_index && out_rows && count > out_rows) return fail(IYK_ERR_INVALID, "more jobs than output rows");
+    const size_t bytes = rot.size() * sizeof(RotJob), idx_off = (bytes + 15) & ~(size_t)15;
+    const size_t total = idx_off + (out_index ? count * sizeof(int32_t) : 0);
     size_t soff = 0;
-    if ((rc = acquire_stage(st, bytes, &soff))) return rc;
+    if ((rc = acquire_stage(st, total, &soff))) return rc;
     std::memcpy(st->h_stage + soff, rot.data(), bytes);
-    HIP_TRY(hipMemcpyAsync(st->d_stage + soff, st->h_stage + soff, bytes, hipMemcpyHostToDevice, st->s));
-    if ((rc = release_stage(st))) return rc;
-    HIP_TRY(hipEventRecord(st->ev_br0, st->s));
-    if ((rc = launch_blind_rotate(st, d_arena, (const RotJob*)(st->d_stage + soff), (int)count, d_out, trlwe))) return rc;
+    if (out_index) std::memcpy(st->h_stage + soff + idx_off, out_index, count * sizeof(int32_t));
+    HIP_TRY(hipMemcpyAsync(st->d_stage + soff, st->h_stage + soff, total, hipMemcpyHostToDevice, st->s));
+    if ((rc = begin_timing(st))) return rc;
+    const RotOut o{d_out, out_index ? (const int32_t*)(st->d_stage + soff + idx_off) : nullptr, trlwe};
+    if ((rc = launch_blind_rotate(st, d_arena, (const RotJob*)(st->d_stage + soff), (int)count, o))) return rc;
     HIP_TRY(hipEventRecord(st->ev_br1, st->s));
+    if (st->log_on) HIP_TRY(hipEventRecord(st->ev_ks1, st->s));  // empty key-switch interval: the log's triples stay well formed
+    if ((rc = release_stage(st))) return rc;
     st->timing_valid = true;
     st->timing_has_ks = false;
     return IYK_OK;
 }
 
-int iyk_hip_blind_rotate_batch(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t count, const int32_t* ia,
-                               const int32_t* ib, const int32_t* sa, const int32_t* sb, const uint32_t* off,
-                               uint32_t* d_tlwe1)
+int iyk_hip_blind_rotate_batch(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t arena_slots, uint64_t count,
+                               const int32_t* ia, const int32_t* ib, const int32_t* sa, const int32_t* sb,
+                               const uint32_t* off, uint32_t* d_tlwe1)
 {
-    return rotate_only(st, d_arena, count, ia, ib, sa, sb, off, d_tlwe1, 0);
+    IYK_API_BEGIN
+    return rotate_only(st, d_arena, arena_slots, count, ia, ib, sa, sb, off, d_tlwe1, 0, 0, nullptr);
+    IYK_API_END
 }
 
-int iyk_hip_bootstrap_trlwe_batch(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t count, const int32_t* ia,
-                                  const int32_t* ib, const int32_t* sa, const int32_t* sb, const uint32_t* off,
-                                  uint32_t* d_trlwe)
+int iyk_hip_bootstrap_trlwe_batch(iyk_hip_stream* st, const uint32_t* d_arena, uint64_t arena_slots, uint64_t count,
+                                  const int32_t* ia, const int32_t* ib, const int32_t* sa, const int32_t* sb,
+                                  const uint32_t* off, uint32_t* d_trlwe, uint64_t trlwe_slots, const int32_t* trlwe_out)
 {
-    return rotate_only(st, d_arena, count, ia, ib, sa, sb, off, d_trlwe, 1);
+    IYK_API_BEGIN
+    if (trlwe_slots == 0) return fail(IYK_ERR_INVALID, "trlwe_slots == 0");
+    return rotate_only(st, d_arena, arena_slots, count, ia, ib, sa, sb, off, d_trlwe, 1, trlwe_slots, trlwe_out);
+    IYK_API_END
 }
 
-int iyk_hip_sample_extract_keyswitch_batch(iyk_hip_stream* st, const uint32_t* d_trlwe, uint64_t count,
-                                           const int32_t* trlwe_index, const int32_t* out_slot, uint32_t* d_arena)
+int iyk_hip_sample_extract_keyswitch_batch(iyk_hip_stream* st, const uint32_t* d_trlwe, uint64_t trlwe_slots, uint64_t count,
+                                           const int32_t* trlwe_index, const int32_t* out_slot, uint32_t* d_arena,
+                                           uint64_t arena_slots)
 {
-    if (!G.init) return fail(IYK_ERR_STATE, "not initialised");
+    IYK_API_BEGIN
+    if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
     if (!st || !d_trlwe || !trlwe_index || !out_slot || !d_arena) return fail(IYK_ERR_INVALID, "null argument");
     if (count == 0) return IYK_OK;
+    if (count > (1u << 30)) return fail(IYK_ERR_INVALID, "batch too large");
     int rc = set_device(st->gpu);
     if (rc) return rc;
     std::vector<KsJob> ks(count);
     for (uint64_t g = 0; g < count; ++g) {
-        if (trlwe_index[g] < 0 || out_slot[g] < 0) return fail(IYK_ERR_INVALID, "negative index");
+        if (!slot_ok(trlwe_index[g], trlwe_slots)) return fail(IYK_ERR_INVALID, "TRLWE index outside the buffer");
+        if (!slot_ok(out_slot[g], arena_slots)) return fail(IYK_ERR_INVALID, "output slot outside the arena");
         ks[g] = KsJob{(int32_t)g, -1, 0u, out_slot[g]};
     }
     const size_t ks_bytes = ks.size() * sizeof(KsJob), idx_off = (ks_bytes + 15) & ~(size_t)15;
@@ -760,12 +1051,15 @@ int iyk_hip_sample_extract_keyswitch_batch(iyk_hip_stream* st, const uint32_t* d
     std::memcpy(st->h_stage + soff, ks.data(), ks_bytes);
     std::memcpy(st->h_stage + soff + idx_off, trlwe_index, count * sizeof(int32_t));
     HIP_TRY(hipMemcpyAsync(st->d_stage + soff, st->h_stage + soff, total, hipMemcpyHostToDevice, st->s));
-    if ((rc = release_stage(st))) return rc;
     hipLaunchKernelGGL(sample_extract_kernel, dim3((unsigned)count), dim3(256), 0, st->s, d_trlwe,
                        (const int32_t*)(st->d_stage + soff + idx_off), st->d_rot);
     HIP_TRY(hipGetLastError());
-    return launch_keyswitch(st, d_arena, (const KsJob*)(st->d_stage + soff), (int)count);
+    if ((rc = launch_keyswitch(st, d_arena, (const KsJob*)(st->d_stage + soff), (int)count))) return rc;
+    return release_stage(st);
+    IYK_API_END
 }
+
+/* ---- measurement ------------------------------------------------------------------------- */
 
 int iyk_hip_last_batch_timing(iyk_hip_stream* st, float* blind_rotate_ms, float* keyswitch_ms)
 {
@@ -787,20 +1081,22 @@ int iyk_hip_last_batch_timing(iyk_hip_stream* st, float* blind_rotate_ms, float*
 
 int iyk_hip_timing_log_begin(iyk_hip_stream* st)
 {
+    IYK_API_BEGIN
     if (!st) return fail(IYK_ERR_INVALID, "null stream");
     if (st->log_on) return fail(IYK_ERR_STATE, "timing log already active");
-    (void)hipEventDestroy(st->ev_br0);
-    (void)hipEventDestroy(st->ev_br1);
-    (void)hipEventDestroy(st->ev_ks1);
+    for (hipEvent_t e : {st->ev_br0, st->ev_br1, st->ev_ks1})
+        if (e) (void)hipEventDestroy(e);
     st->ev_br0 = st->ev_br1 = st->ev_ks1 = nullptr;
     st->timing_valid = false;
     st->log_on = true;
     st->log_events.clear();
     return IYK_OK;
+    IYK_API_END
 }
 
 int iyk_hip_timing_log_end(iyk_hip_stream* st, uint64_t* batches, double* blind_rotate_ms, double* keyswitch_ms)
 {
+    IYK_API_BEGIN
     if (!st) return fail(IYK_ERR_INVALID, "null stream");
     if (!st->log_on) return fail(IYK_ERR_STATE, "timing log not active");
     HIP_TRY(hipStreamSynchronize(st->s));
@@ -817,6 +1113,7 @@ int iyk_hip_timing_log_end(iyk_hip_stream* st, uint64_t* batches, double* blind_
     st->log_events.clear();
     st->log_on = false;
     // the stream's standing events were replaced by logged ones: make fresh ones
+    st->ev_br0 = st->ev_br1 = st->ev_ks1 = nullptr;
     HIP_TRY(hipEventCreate(&st->ev_br0));
     HIP_TRY(hipEventCreate(&st->ev_br1));
     HIP_TRY(hipEventCreate(&st->ev_ks1));
@@ -825,6 +1122,7 @@ int iyk_hip_timing_log_end(iyk_hip_stream* st, uint64_t* batches, double* blind_
     if (blind_rotate_ms) *blind_rotate_ms = br;
     if (keyswitch_ms) *keyswitch_ms = ks;
     return IYK_OK;
+    IYK_API_END
 }
 
 }  // extern "C"

@@ -16,6 +16,7 @@
 
 #include "blind_rotate_core.hpp"
 #include "blind_rotate_fp.hpp"
+#include "blind_rotate_lat3.hpp"
 
 namespace iyk {
 
@@ -124,7 +125,8 @@ template <int L, int BGBIT>
 __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_kernel(
     const u32* __restrict__ abar_all, int njobs, const u64* __restrict__ bk_ntt,
     const u64* __restrict__ tw_fwd, const u64* __restrict__ tw_inv, u32* __restrict__ tlwe1_out, u32 n,
-    u32 mu, u32 abar_stride, int trlwe_mode)
+    u32 mu, u32 abar_stride, int trlwe_mode,
+    const int32_t* __restrict__ out_index)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* s_twf = reinterpret_cast<u64*>(smem);            // [k2][j1]
@@ -244,11 +246,11 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_kernel(
     // sample extract at index 0 -> TLWE lvl1: a'[0] = a[0], a'[j] = -a[N-j], b' = b[0]
     if (live) {
         if (trlwe_mode) {  // raw accumulator: TRLWE (a(X), b(X)), 2N words per job
-            u32* out = tlwe1_out + (size_t)job * (2 * NTT_N);
+            u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (2 * NTT_N);
             for (int j = lane; j < 2 * NTT_N; j += 64) out[j] = acc_lds[j];
         }
         else {
-            u32* out = tlwe1_out + (size_t)job * (NTT_N + 1);
+            u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (NTT_N + 1);
             for (int j = lane; j < NTT_N; j += 64) out[j] = (j == 0) ? acc_lds[0] : 0u - acc_lds[NTT_N - j];
             if (lane == 0) out[NTT_N] = acc_lds[NTT_N];
         }
@@ -343,7 +345,8 @@ template <class D>
 __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
     const u32* __restrict__ abar_all, int njobs, const double* __restrict__ bk_ntt,
     const double* __restrict__ tw_fwd, const double* __restrict__ tw_inv_t, const fp::NttConsts* __restrict__ Cp,
-    u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride, int trlwe_mode)
+    u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride, int trlwe_mode,
+    const int32_t* __restrict__ out_index)
 {
     // twist / 32-point twiddle constants are read with scalar loads where they are used: held by value
     // they overflow the SGPR file and come back through v_readlane (a VALU op per 32 bits)
@@ -485,11 +488,11 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
 
     if (live) {
         if (trlwe_mode) {  // raw accumulator: TRLWE (a(X), b(X)), 2N words per job
-            u32* out = tlwe1_out + (size_t)job * (2 * NTT_N);
+            u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (2 * NTT_N);
             for (int j = lane; j < 2 * NTT_N; j += 64) out[j] = acc_lds[j];
         }
         else {
-            u32* out = tlwe1_out + (size_t)job * (NTT_N + 1);
+            u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (NTT_N + 1);
             for (int j = lane; j < NTT_N; j += 64) out[j] = (j == 0) ? acc_lds[0] : 0u - acc_lds[NTT_N - j];
             if (lane == 0) out[NTT_N] = acc_lds[NTT_N];
         }
@@ -514,7 +517,8 @@ template <class D>
 __global__ __launch_bounds__(64 * D::LV) void blind_rotate_fp_lat_kernel(
     const u32* __restrict__ abar_all, int njobs, const double* __restrict__ bk_ntt,
     const double* __restrict__ tw_fwd, const double* __restrict__ tw_inv, const fp::NttConsts* __restrict__ Cp,
-    u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride, int trlwe_mode)
+    u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride, int trlwe_mode,
+    const int32_t* __restrict__ out_index)
 {
     const fp::NttConsts& C = *Cp;
     constexpr int L = D::LV;  // one wavefront per (virtual) gadget level
@@ -641,11 +645,11 @@ __global__ __launch_bounds__(64 * D::LV) void blind_rotate_fp_lat_kernel(
 
     if (wave == 0) {
         if (trlwe_mode) {  // raw accumulator: TRLWE (a(X), b(X)), 2N words per job
-            u32* out = tlwe1_out + (size_t)job * (2 * NTT_N);
+            u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (2 * NTT_N);
             for (int j = lane; j < 2 * NTT_N; j += 64) out[j] = acc_lds[j];
         }
         else {
-            u32* out = tlwe1_out + (size_t)job * (NTT_N + 1);
+            u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (NTT_N + 1);
             for (int j = lane; j < NTT_N; j += 64) out[j] = (j == 0) ? acc_lds[0] : 0u - acc_lds[NTT_N - j];
             if (lane == 0) out[NTT_N] = acc_lds[NTT_N];
         }
@@ -682,7 +686,8 @@ template <class D>
 __global__ __launch_bounds__(128 * D::LV) void blind_rotate_fp_lat2_kernel(
     const u32* __restrict__ abar_all, int njobs, const double* __restrict__ bk_ntt,
     const double* __restrict__ tw_fwd, const double* __restrict__ tw_inv, const fp::NttConsts* __restrict__ Cp,
-    u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride, int trlwe_mode)
+    u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride, int trlwe_mode,
+    const int32_t* __restrict__ out_index)
 {
     const fp::NttConsts& C = *Cp;
     constexpr int L = D::LV;
@@ -811,11 +816,195 @@ __global__ __launch_bounds__(128 * D::LV) void blind_rotate_fp_lat2_kernel(
 
     if (wave == 0) {
         if (trlwe_mode) {  // raw accumulator: TRLWE (a(X), b(X)), 2N words per job
-            u32* out = tlwe1_out + (size_t)job * (2 * NTT_N);
+            u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (2 * NTT_N);
             for (int j = lane; j < 2 * NTT_N; j += 64) out[j] = acc_lds[j];
         }
         else {
-            u32* out = tlwe1_out + (size_t)job * (NTT_N + 1);
+            u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (NTT_N + 1);
+            for (int j = lane; j < NTT_N; j += 64) out[j] = (j == 0) ? acc_lds[0] : 0u - acc_lds[NTT_N - j];
+            if (lane == 0) out[NTT_N] = acc_lds[NTT_N];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Low-latency variant 3: ONE ROTATION PER WORKGROUP of 2 LV wavefronts, wave (h, v) = digit polynomial h of
+// (virtual) gadget level v; 64-lane transforms with 16 points per lane (blind_rotate_lat3.hpp).  Per step:
+//   forward   every wave: digits of ITS polynomial -> NTT -> two key-row products -> ds_add_f64 into the shared
+//             NTT-domain sums [c][k1][k2];  then it issues the NEXT step's key-row loads and waits at barrier 1;
+//   inverse   waves (c, 0): sum_c -> inverse NTT -> accumulator polynomial c (and zero sum_c);  barrier 2.
+// Critical path per step ~ (0.14 k digits + 0.68 k NTT + 0.22 k MAC) + (0.05 k + 0.68 k NTT + 0.18 k post) VALU
+// of a lone wave, against 1.9 k + 1.5 k for the wave-per-level kernel; key-row latency is off the path entirely.
+//
+// LDS (bytes): twiddles fwd + inv 16 K | twisted digits 16 K | accumulator 8 K | sums f64 [2][32][32] 16 K |
+// per wave one f64 [32][33] transpose matrix (8448).
+template <class D>
+struct BrLat3 {
+    static constexpr int LV = D::LV, WAVES = 2 * LV, THREADS = 64 * WAVES;
+    static constexpr size_t XB_DOUBLES = 32 * XB_STRIDE;
+    static constexpr size_t LDS_BYTES = (2 * NTT_N + fp::ZTAB_ENTRIES) * sizeof(double) + 2 * NTT_N * sizeof(u32) +
+                                        2 * NTT_N * sizeof(double) + (size_t)WAVES * XB_DOUBLES * sizeof(double);
+    static_assert(LDS_BYTES <= 160 * 1024, "latency kernel 3 does not fit the CU's LDS");
+};
+
+// the two v_permlane32_swap rounds of a pass exchange (a[2m], a[2m+1]) between the half-waves
+__device__ __forceinline__ void swap16(double (&a)[16])
+{
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const u64 ua = fp::d2u(a[2 * m]), ub = fp::d2u(a[2 * m + 1]);
+        const auto lo = __builtin_amdgcn_permlane32_swap((u32)ua, (u32)ub, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((u32)(ua >> 32), (u32)(ub >> 32), false, false);
+        a[2 * m] = fp::u2d(((u64)hi[0] << 32) | lo[0]);
+        a[2 * m + 1] = fp::u2d(((u64)hi[1] << 32) | lo[1]);
+    }
+}
+template <int PASS>
+__device__ __forceinline__ void dif16(double (&a)[16], int half, const double (&tw0)[8], const double* w)
+{
+    swap16(a);
+    fp::dif16_stage0<PASS>(a, half, tw0);
+    swap16(a);
+    fp::dif16_stages14<PASS>(a, w);
+}
+
+template <class D>
+__global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kernel(
+    const u32* __restrict__ abar_all, int njobs, const double* __restrict__ bk_ntt,
+    const double* __restrict__ tw_fwd, const double* __restrict__ tw_inv, const fp::NttConsts* __restrict__ Cp,
+    u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride, int trlwe_mode,
+    const int32_t* __restrict__ out_index)
+{
+    typedef BrLat3<D> M;
+    constexpr int LV = M::LV, NT = M::THREADS;
+    const fp::NttConsts& C = *Cp;
+    extern __shared__ __attribute__((aligned(4096))) unsigned char smem[];
+    double* s_twf = reinterpret_cast<double*>(smem);                    // [k2][j1]
+    double* s_twi = s_twf + NTT_N;                                      // [j1][k2]
+    double* s_ztab = s_twi + NTT_N;                                     // [j2][digit + 32]
+    u32* acc_lds = reinterpret_cast<u32*>(s_ztab + fp::ZTAB_ENTRIES);   // [2][1024]
+    double* s_sum = reinterpret_cast<double*>(acc_lds + 2 * NTT_N);     // [c][k1][k2]
+    double* s_xb = s_sum + 2 * NTT_N;                                   // [WAVES][32][33]
+
+    for (int e = threadIdx.x; e < NTT_N; e += NT) {
+        const int a = e >> 5, b = e & 31;
+        s_twf[b * 32 + a] = tw_fwd[e];
+        s_twi[b * 32 + a] = tw_inv[e];
+    }
+    for (int e = threadIdx.x; e < fp::ZTAB_ENTRIES; e += NT) s_ztab[e] = fp::ztab_entry(e, C.zf);
+    for (int e = threadIdx.x; e < 2 * NTT_N; e += NT) s_sum[e] = 0.0;
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = wave / LV, v = wave - h * LV;   // digit polynomial h, (virtual) level v
+    const int lane = threadIdx.x & 63;
+    const int half0 = lane >> 5, t0 = lane & 31;
+    const int job = blockIdx.x;
+    const u32* abar = abar_all + (size_t)job * abar_stride;
+    u32* acc_h = acc_lds + h * NTT_N;
+    const int half = half0, t = t0;
+    if (v == 0) {  // initial accumulator (0, X^bbar * sum_j mu X^j): each lane its 16 coefficients
+        const u32 bbar = abar[n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = t + 32 * (16 * half + r);
+            const u32 idx = ((u32)j - bbar) & (2 * NTT_N - 1);
+            acc_h[j] = h ? ((idx & NTT_N) ? 0u - mu : mu) : 0u;
+        }
+    }
+    // lane constants: stage-0 twiddles w^(2m + half); inverse post-twists zeta^(-j2)
+    double tw0[8], zi16[16];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) tw0[m] = C.w[2 * m + half];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) zi16[q] = C.zi[fp::inv16(half, q)];
+    __syncthreads();
+
+    double* xb = s_xb + (size_t)wave * M::XB_DOUBLES;
+    const int row = h * LV + v;
+    double bk0[16], bk1[16];
+    {
+        const double* b0 = fp::bk_lane16(bk_ntt, row, 0, half, t);
+        const double* b1 = fp::bk_lane16(bk_ntt, row, 1, half, t);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            bk0[q] = b0[fp::brv4(q) * 64];
+            bk1[q] = b1[fp::brv4(q) * 64];
+        }
+    }
+
+    u32 ab_next = abar[0];
+    for (u32 i = 0; i < n; ++i) {
+        const u32 ab = ab_next;
+        ab_next = abar[i + 1 < n ? i + 1 : i];
+        double x[16];
+        int t = t0, half = half0;
+        asm volatile("" : "+v"(t), "+v"(half));  // keep lane-dependent address math inside the iteration (no hoisting)
+        // ---- forward: digits -> pass 1 -> twiddle -> transpose -> pass 2 -> two products into the shared sums
+        fp::fwd1_pre16<D>(half, t, v, ab, acc_h, x, s_ztab);
+        dif16<fp::PASS1>(x, half, tw0, C.w);
+        fp::fwd1_twiddle16(half, t, x, s_twf);
+        fp::xpose16_write<false>(half, t, x, xb);
+        lds_sync();
+        fp::xpose16_read(half, t, x, xb);
+        lds_sync();
+        dif16<fp::PASS2>(x, half, tw0, C.w);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            double p0 = fp::mulmod(x[q], bk0[q]), p1 = fp::mulmod(x[q], bk1[q]);
+            if (LV > 3) {  // 2 LV terms of <= 1.34 p would pass 2^53: reduce each first
+                p0 = fp::norm(p0);
+                p1 = fp::norm(p1);
+            }
+            double* dst = s_sum + fp::freq16(half, q) * 32 + t;
+            __hip_atomic_fetch_add(dst, p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(dst + NTT_N, p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        // next step's key rows: in flight during the inverse phase, off the critical path
+        if (i + 1 < n) {
+            const double* bk_step = bk_ntt + (size_t)(i + 1) * (2 * LV) * 2 * NTT_N;
+            const double* b0 = fp::bk_lane16(bk_step, row, 0, half, t);
+            const double* b1 = fp::bk_lane16(bk_step, row, 1, half, t);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                bk0[q] = b0[fp::brv4(q) * 64];
+                bk1[q] = b1[fp::brv4(q) * 64];
+            }
+        }
+        wg_barrier_lds();  // all 2 (k+1) LV products are in the sums
+        // ---- inverse of sum_h -> accumulator polynomial h (waves (h, 0))
+        if (v == 0) {
+            asm volatile("" : "+v"(t), "+v"(half));
+            double* sum_c = s_sum + h * NTT_N;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                double* src = sum_c + (16 * half + r) * 32 + t;
+                x[r] = *src;
+                *src = 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = fp::norm(x[r]);
+            dif16<fp::PASS1>(x, half, tw0, C.w);
+            fp::inv1_twiddle16(half, t, x, s_twi);
+            fp::xpose16_write<true>(half, t, x, xb);
+            lds_sync();
+            fp::xpose16_read(half, t, x, xb);
+            lds_sync();
+            dif16<fp::PASS2>(x, half, tw0, C.w);
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                __hip_atomic_fetch_add(acc_h + t + 32 * fp::inv16(half, q), fp::inv2_post16(x[q], zi16[q]), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        wg_barrier_lds();  // accumulator of step i is complete before anyone derives step i+1's digits
+    }
+
+    if (wave == 0) {
+        if (trlwe_mode) {  // raw accumulator: TRLWE (a(X), b(X)), 2N words per job
+            u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (2 * NTT_N);
+            for (int j = lane; j < 2 * NTT_N; j += 64) out[j] = acc_lds[j];
+        }
+        else {
+            u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (NTT_N + 1);
             for (int j = lane; j < NTT_N; j += 64) out[j] = (j == 0) ? acc_lds[0] : 0u - acc_lds[NTT_N - j];
             if (lane == 0) out[NTT_N] = acc_lds[NTT_N];
         }
@@ -946,6 +1135,27 @@ __global__ __launch_bounds__(256) void elementwise_kernel(u32* __restrict__ aren
         }
         out[i] = v;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Bulk host I/O and multi-GPU exchange of non-contiguous arena slots: rows[j] <-> arena[slots[j]].
+// One workgroup per ciphertext.  (Mem::set/get of many INPUT / OUTPUT / RAM cells in one transfer instead of
+// one synchronous 2.5 KB copy per cell; the reference copies per ciphertext, /root/reference/src/iyokan_cufhe.hpp:80-88.)
+__global__ __launch_bounds__(256) void gather_slots_kernel(const u32* __restrict__ arena, const int32_t* __restrict__ slots,
+                                                           u32* __restrict__ rows, u32 n)
+{
+    const size_t n1 = (size_t)n + 1;
+    const u32* in = arena + (size_t)slots[blockIdx.x] * n1;
+    u32* out = rows + (size_t)blockIdx.x * n1;
+    for (u32 i = threadIdx.x; i <= n; i += 256) out[i] = in[i];
+}
+__global__ __launch_bounds__(256) void scatter_slots_kernel(u32* __restrict__ arena, const int32_t* __restrict__ slots,
+                                                            const u32* __restrict__ rows, u32 n)
+{
+    const size_t n1 = (size_t)n + 1;
+    const u32* in = rows + (size_t)blockIdx.x * n1;
+    u32* out = arena + (size_t)slots[blockIdx.x] * n1;
+    for (u32 i = threadIdx.x; i <= n; i += 256) out[i] = in[i];
 }
 
 }  // namespace iyk

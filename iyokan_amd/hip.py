@@ -30,6 +30,9 @@ EXPORTS = [
     "iyk_hip_blind_rotate_batch", "iyk_hip_last_batch_timing", "iyk_hip_resident_key_bytes",
     "iyk_hip_timing_log_begin", "iyk_hip_timing_log_end", "iyk_hip_ntt_path",
     "iyk_hip_bootstrap_trlwe_batch", "iyk_hip_sample_extract_keyswitch_batch",
+    "iyk_hip_stream_gpu", "iyk_hip_arena_upload_slots", "iyk_hip_arena_download_slots", "iyk_hip_arena_copy",
+    "iyk_hip_arena_sync_slots", "iyk_hip_trlwe_alloc", "iyk_hip_trlwe_free", "iyk_hip_trlwe_upload",
+    "iyk_hip_trlwe_download",
 ]
 
 
@@ -55,17 +58,26 @@ def lib():
         L.iyk_hip_get_params.argtypes = [ctypes.POINTER(IykParams)]
         L.iyk_hip_stream_create.argtypes = [ctypes.c_int, ctypes.POINTER(_vp)]
         L.iyk_hip_stream_wrap.argtypes = [ctypes.c_int, _vp, ctypes.POINTER(_vp)]
-        for f in ("iyk_hip_stream_destroy", "iyk_hip_stream_query", "iyk_hip_stream_sync"):
+        for f in ("iyk_hip_stream_destroy", "iyk_hip_stream_query", "iyk_hip_stream_sync", "iyk_hip_stream_gpu"):
             getattr(L, f).argtypes = [_vp]
-        L.iyk_hip_arena_alloc.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(_vp)]
+        u64 = ctypes.c_uint64
+        L.iyk_hip_arena_alloc.argtypes = [ctypes.c_int, u64, ctypes.POINTER(_vp)]
         L.iyk_hip_arena_free.argtypes = [ctypes.c_int, _vp]
-        L.iyk_hip_arena_upload.argtypes = [_vp, _vp, ctypes.c_uint64, ctypes.c_uint64, _u32p]
-        L.iyk_hip_arena_download.argtypes = [_vp, _vp, ctypes.c_uint64, ctypes.c_uint64, _u32p]
-        L.iyk_hip_gate_batch.argtypes = [_vp, _vp, ctypes.c_uint64, _i32p, _i32p, _i32p, _i32p, _i32p]
+        L.iyk_hip_arena_upload.argtypes = [_vp, _vp, u64, u64, u64, _u32p]
+        L.iyk_hip_arena_download.argtypes = [_vp, _vp, u64, u64, u64, _u32p]
+        L.iyk_hip_arena_upload_slots.argtypes = [_vp, _vp, u64, u64, _i32p, _u32p]
+        L.iyk_hip_arena_download_slots.argtypes = [_vp, _vp, u64, u64, _i32p, _u32p]
+        L.iyk_hip_arena_copy.argtypes = [_vp, _vp, u64, u64, _vp, u64, u64, u64]
+        L.iyk_hip_arena_sync_slots.argtypes = [_vp, _vp, u64, _vp, _vp, u64, u64, _i32p]
+        L.iyk_hip_trlwe_alloc.argtypes = [ctypes.c_int, u64, ctypes.POINTER(_vp)]
+        L.iyk_hip_trlwe_free.argtypes = [ctypes.c_int, _vp]
+        L.iyk_hip_trlwe_upload.argtypes = [_vp, _vp, u64, u64, u64, _u32p]
+        L.iyk_hip_trlwe_download.argtypes = [_vp, _vp, u64, u64, u64, _u32p]
+        L.iyk_hip_gate_batch.argtypes = [_vp, _vp, u64, u64, _i32p, _i32p, _i32p, _i32p, _i32p]
         L.iyk_hip_gate_host.argtypes = [_vp, ctypes.c_int, _u32p, _u32p, _u32p, _u32p]
-        L.iyk_hip_blind_rotate_batch.argtypes = [_vp, _vp, ctypes.c_uint64, _i32p, _i32p, _i32p, _i32p, _u32p, _vp]
-        L.iyk_hip_bootstrap_trlwe_batch.argtypes = [_vp, _vp, ctypes.c_uint64, _i32p, _i32p, _i32p, _i32p, _u32p, _vp]
-        L.iyk_hip_sample_extract_keyswitch_batch.argtypes = [_vp, _vp, ctypes.c_uint64, _i32p, _i32p, _vp]
+        L.iyk_hip_blind_rotate_batch.argtypes = [_vp, _vp, u64, u64, _i32p, _i32p, _i32p, _i32p, _u32p, _vp]
+        L.iyk_hip_bootstrap_trlwe_batch.argtypes = [_vp, _vp, u64, u64, _i32p, _i32p, _i32p, _i32p, _u32p, _vp, u64, _i32p]
+        L.iyk_hip_sample_extract_keyswitch_batch.argtypes = [_vp, _vp, u64, u64, _i32p, _i32p, _vp, u64]
         L.iyk_hip_last_batch_timing.argtypes = [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
         L.iyk_hip_resident_key_bytes.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
         L.iyk_hip_timing_log_begin.argtypes = [_vp]
@@ -177,18 +189,45 @@ class Stream:
 
     def upload(self, arena, first_slot, host):
         host = np.ascontiguousarray(host, dtype=np.uint32).reshape(-1, arena.n1)
-        assert first_slot + host.shape[0] <= arena.slots
-        _check(lib().iyk_hip_arena_upload(self.h, arena.ptr, first_slot, host.shape[0],
+        _check(lib().iyk_hip_arena_upload(self.h, arena.ptr, arena.slots, first_slot, host.shape[0],
                                           host.ctypes.data_as(_u32p)), "iyk_hip_arena_upload")
         self.sync()  # host buffer is pageable: finish before it can be garbage collected
 
     def download(self, arena, first_slot, count):
-        assert first_slot + count <= arena.slots
         out = np.zeros((count, arena.n1), dtype=np.uint32)
-        _check(lib().iyk_hip_arena_download(self.h, arena.ptr, first_slot, count,
+        _check(lib().iyk_hip_arena_download(self.h, arena.ptr, arena.slots, first_slot, count,
                                             out.ctypes.data_as(_u32p)), "iyk_hip_arena_download")
         self.sync()
         return out
+
+    def upload_slots(self, arena, slots, host):
+        """Mem::set of many cells in one transfer: host row j -> arena slot slots[j]."""
+        slots = _i32(slots)
+        host = np.ascontiguousarray(host, dtype=np.uint32).reshape(len(slots), arena.n1)
+        _check(lib().iyk_hip_arena_upload_slots(self.h, arena.ptr, arena.slots, len(slots), slots.ctypes.data_as(_i32p),
+                                                host.ctypes.data_as(_u32p)), "iyk_hip_arena_upload_slots")
+
+    def download_slots(self, arena, slots):
+        """Mem::get of many cells in one transfer."""
+        slots = _i32(slots)
+        out = np.zeros((len(slots), arena.n1), dtype=np.uint32)
+        _check(lib().iyk_hip_arena_download_slots(self.h, arena.ptr, arena.slots, len(slots),
+                                                  slots.ctypes.data_as(_i32p), out.ctypes.data_as(_u32p)),
+               "iyk_hip_arena_download_slots")
+        self.sync()
+        return out
+
+    def arena_copy(self, dst, dst_first, src, src_first, count):
+        _check(lib().iyk_hip_arena_copy(self.h, dst.ptr, dst.slots, dst_first, src.ptr, src.slots, src_first, count),
+               "iyk_hip_arena_copy")
+
+    def sync_slots_to(self, src_arena, dst_stream, dst_arena, slots):
+        """Level-boundary exchange between in-process GPU replicas: listed slots of src_arena (this stream's GPU)
+        -> same slots of dst_arena (dst_stream's GPU), ordered by events on both streams."""
+        slots = _i32(slots)
+        _check(lib().iyk_hip_arena_sync_slots(self.h, src_arena.ptr, src_arena.slots, dst_stream.h, dst_arena.ptr,
+                                              dst_arena.slots, len(slots), slots.ctypes.data_as(_i32p)),
+               "iyk_hip_arena_sync_slots")
 
     def gate_batch(self, arena, ops, in0, in1, in2, out):
         """`len(ops)` independent gates on arena slots; asynchronous (poll query() / sync())."""
@@ -196,7 +235,7 @@ class Stream:
         n = len(ops)
         assert len(in0) == len(in1) == len(in2) == len(out) == n
         p = lambda a: a.ctypes.data_as(_i32p)
-        _check(lib().iyk_hip_gate_batch(self.h, arena.ptr, n, p(ops), p(in0), p(in1), p(in2), p(out)),
+        _check(lib().iyk_hip_gate_batch(self.h, arena.ptr, arena.slots, n, p(ops), p(in0), p(in1), p(in2), p(out)),
                "iyk_hip_gate_batch")
 
     def gate_host(self, op, in0=None, in1=None, in2=None):
@@ -215,25 +254,31 @@ class Stream:
         ia, ib, sa, sb = map(_i32, (ia, ib, sa, sb))
         off = np.ascontiguousarray(off, dtype=np.uint32)
         p = lambda a: a.ctypes.data_as(_i32p)
-        _check(lib().iyk_hip_blind_rotate_batch(self.h, arena.ptr, len(ia), p(ia), p(ib), p(sa), p(sb),
+        _check(lib().iyk_hip_blind_rotate_batch(self.h, arena.ptr, arena.slots, len(ia), p(ia), p(ib), p(sa), p(sb),
                                                 off.ctypes.data_as(_u32p), _vp(int(d_tlwe1_ptr))),
                "iyk_hip_blind_rotate_batch")
 
-    def bootstrap_trlwe_batch(self, arena, ia, ib, sa, sb, off, d_trlwe_ptr):
-        """GateBootstrappingTLWE2TRLWElvl01NTT shape: rotation only, TRLWE (2N words) per job."""
+    def bootstrap_trlwe_batch(self, arena, ia, ib, sa, sb, off, d_trlwe_ptr, trlwe_slots=None, trlwe_out=None):
+        """GateBootstrappingTLWE2TRLWElvl01NTT shape: rotation only, TRLWE (2N words) per job, written to row
+        trlwe_out[job] of the TRLWE buffer (row `job` when trlwe_out is None)."""
         ia, ib, sa, sb = map(_i32, (ia, ib, sa, sb))
         off = np.ascontiguousarray(off, dtype=np.uint32)
         p = lambda a: a.ctypes.data_as(_i32p)
-        _check(lib().iyk_hip_bootstrap_trlwe_batch(self.h, arena.ptr, len(ia), p(ia), p(ib), p(sa), p(sb),
-                                                   off.ctypes.data_as(_u32p), _vp(int(d_trlwe_ptr))),
+        to = None if trlwe_out is None else _i32(trlwe_out)
+        _check(lib().iyk_hip_bootstrap_trlwe_batch(self.h, arena.ptr, arena.slots, len(ia), p(ia), p(ib), p(sa), p(sb),
+                                                   off.ctypes.data_as(_u32p), _vp(int(d_trlwe_ptr)),
+                                                   len(ia) if trlwe_slots is None else int(trlwe_slots),
+                                                   None if to is None else p(to)),
                "iyk_hip_bootstrap_trlwe_batch")
 
-    def sample_extract_keyswitch_batch(self, d_trlwe_ptr, trlwe_index, out_slot, arena):
+    def sample_extract_keyswitch_batch(self, d_trlwe_ptr, trlwe_index, out_slot, arena, trlwe_slots=None):
         """SampleExtractAndKeySwitch shape: TRLWE -> TLWE lvl0 into arena slots."""
         ti, os_ = _i32(trlwe_index), _i32(out_slot)
         p = lambda a: a.ctypes.data_as(_i32p)
-        _check(lib().iyk_hip_sample_extract_keyswitch_batch(self.h, _vp(int(d_trlwe_ptr)), len(ti), p(ti), p(os_),
-                                                            arena.ptr), "iyk_hip_sample_extract_keyswitch_batch")
+        nt = (int(ti.max()) + 1 if len(ti) else 0) if trlwe_slots is None else int(trlwe_slots)
+        _check(lib().iyk_hip_sample_extract_keyswitch_batch(self.h, _vp(int(d_trlwe_ptr)), nt, len(ti), p(ti), p(os_),
+                                                            arena.ptr, arena.slots),
+               "iyk_hip_sample_extract_keyswitch_batch")
 
     def last_batch_timing(self):
         """(blind_rotate_ms, keyswitch_ms) of the most recent batch, from HIP events on this stream."""

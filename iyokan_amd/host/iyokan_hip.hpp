@@ -95,9 +95,9 @@ class HIPArena {
             // device -> host -> device keeps the C ABI minimal; growth only happens while building
             std::vector<uint32_t> tmp(used_ * (p_.n + 1));
             if (used_) {
-                hipCheck(iyk_hip_arena_download(io_, d_, 0, used_, tmp.data()), "arena_download");
+                hipCheck(iyk_hip_arena_download(io_, d_, cap_, 0, used_, tmp.data()), "arena_download");
                 io_.sync();
-                hipCheck(iyk_hip_arena_upload(io_, nd, 0, used_, tmp.data()), "arena_upload");
+                hipCheck(iyk_hip_arena_upload(io_, nd, ncap, 0, used_, tmp.data()), "arena_upload");
                 io_.sync();
             }
             hipCheck(iyk_hip_arena_free(0, d_), "iyk_hip_arena_free");
@@ -114,6 +114,7 @@ public:
     }
     const iyk_params& params() const { return p_; }
     uint32_t* device() const { return d_; }
+    uint64_t slots() const { return cap_; }
     Slot alloc()
     {
         if (used_ + 1 > cap_) grow(used_ + 1);
@@ -122,13 +123,13 @@ public:
     void set(Slot s, const TLWELvl0& v)
     {
         if (v.size() != p_.n + 1) die("HIPArena::set: wrong ciphertext size");
-        hipCheck(iyk_hip_arena_upload(io_, d_, (uint64_t)s, 1, v.data()), "arena_upload");
+        hipCheck(iyk_hip_arena_upload(io_, d_, cap_, (uint64_t)s, 1, v.data()), "arena_upload");
         io_.sync();
     }
     TLWELvl0 get(Slot s)
     {
         TLWELvl0 v(p_.n + 1);
-        hipCheck(iyk_hip_arena_download(io_, d_, (uint64_t)s, 1, v.data()), "arena_download");
+        hipCheck(iyk_hip_arena_download(io_, d_, cap_, (uint64_t)s, 1, v.data()), "arena_download");
         io_.sync();
         return v;
     }
@@ -151,7 +152,7 @@ struct HIPWorkerInfo {
     void flush()
     {
         if (ops.empty()) return;
-        hipCheck(iyk_hip_gate_batch(*stream, arena->device(), ops.size(), ops.data(), in0.data(), in1.data(),
+        hipCheck(iyk_hip_gate_batch(*stream, arena->device(), arena->slots(), ops.size(), ops.data(), in0.data(), in1.data(),
                                     in2.data(), out.data()),
                  "iyk_hip_gate_batch");
         ops.clear(); in0.clear(); in1.clear(); in2.clear(); out.clear();
@@ -305,9 +306,9 @@ public:
             b.push(IYK_OP_COPY, d.shadow, -1, -1, d.slot);
         });
         if (!a.ops.empty()) {
-            hipCheck(iyk_hip_gate_batch(st_, f_.arena.device(), a.ops.size(), a.ops.data(), a.in0.data(), a.in1.data(),
+            hipCheck(iyk_hip_gate_batch(st_, f_.arena.device(), f_.arena.slots(), a.ops.size(), a.ops.data(), a.in0.data(), a.in1.data(),
                                         a.in2.data(), a.out.data()), "tick latch");
-            hipCheck(iyk_hip_gate_batch(st_, f_.arena.device(), b.ops.size(), b.ops.data(), b.in0.data(), b.in1.data(),
+            hipCheck(iyk_hip_gate_batch(st_, f_.arena.device(), f_.arena.slots(), b.ops.size(), b.ops.data(), b.in0.data(), b.in1.data(),
                                         b.in2.data(), b.out.data()), "tick commit");
             st_.sync();
         }

@@ -181,10 +181,17 @@ void orc_negacyclic_ntt(u32 N, const i32* d, const u32* b, u32* res)
 }
 
 /* ------------------------------------------------------------ oracle context */
+/* second restatement, FP64 field (tfhe_oracle_fp.c); mode 2 of orc_blind_rotate / orc_gate */
+struct orc_fp_ctx;
+struct orc_fp_ctx* orc_fp_new(const iyk_params* p, const u32* bk);
+void orc_fp_free(struct orc_fp_ctx* c);
+void orc_fp_blind_rotate(const struct orc_fp_ctx* c, const u32* tlwe0, u32* acc);
+
 typedef struct orc_ctx {
     iyk_params p;
     u32 logN;
     orc_ntt* ntt;
+    struct orc_fp_ctx* fp; /* NULL when the parameter set does not meet the FP64 field's exactness bound */
     const u32* bk;   /* torus domain, borrowed: [n][(k+1)l][k+1][N] */
     const u32* ksk;  /* borrowed: [kN][t][2^basebit-1][n+1] */
     u64* bk_ntt;     /* owned, same indexing, oracle's own (bit-reversed) NTT order */
@@ -208,13 +215,18 @@ orc_ctx* orc_new(const iyk_params* p, const u32* bk, const u32* ksk)
         for (u32 i = 0; i < p->N; ++i) dst[i] = src[i];
         ntt_fwd(c->ntt, dst);
     }
+    c->fp = orc_fp_new(p, bk);
     return c;
 }
+
+/* 1 when mode 2 (FP64-field restatement) is available for this parameter set */
+int orc_has_fp(const orc_ctx* c) { return c->fp != NULL; }
 
 void orc_free(orc_ctx* c)
 {
     if (!c) return;
     ntt_free(c->ntt);
+    orc_fp_free(c->fp);
     free(c->bk_ntt);
     free(c);
 }
@@ -266,10 +278,18 @@ static void mul_by_xai(u32 N, const u32* in, u32 a, u32* out)
 }
 
 /* blind rotation of a lvl0 TLWE with the all-mu test vector; acc = [k+1][N] torus32.
- * schoolbook != 0 uses uint32 schoolbook products against the torus-domain BK. */
+ * schoolbook (= mode): 0 Goldilocks NTT products, 1 uint32 schoolbook products against the torus-domain BK,
+ * 2 the FP64-field restatement of tfhe_oracle_fp.c (falls back to 0 where its exactness bound fails). */
 void orc_blind_rotate(const orc_ctx* c, const u32* tlwe0, u32* acc, int schoolbook)
 {
     const iyk_params* p = &c->p;
+    if (schoolbook == 2) {
+        if (c->fp) {
+            orc_fp_blind_rotate(c->fp, tlwe0, acc);
+            return;
+        }
+        schoolbook = 0;
+    }
     const u32 N = p->N, k1 = p->k + 1, rows = k1 * p->l;
     const u32 shift = 32 - 1 - c->logN;
     u32* tmp = (u32*)malloc(sizeof(u32) * k1 * N);
@@ -400,8 +420,15 @@ void orc_gate(const orc_ctx* c, int op, const u32* in0, const u32* in1, const u3
 
 /* Batch over independent gates: arena addressing identical to the C-ABI
  * (iyk_hip_gate_batch): ciphertext slot s lives at arena + s*(n+1). */
+void orc_gate_batch_mode(const orc_ctx* c, u32 count, const i32* ops, const i32* in0, const i32* in1,
+                         const i32* in2, const i32* outs, u32* arena, int nthreads, int mode);
 void orc_gate_batch(const orc_ctx* c, u32 count, const i32* ops, const i32* in0, const i32* in1,
                     const i32* in2, const i32* outs, u32* arena, int nthreads)
+{
+    orc_gate_batch_mode(c, count, ops, in0, in1, in2, outs, arena, nthreads, 0);
+}
+void orc_gate_batch_mode(const orc_ctx* c, u32 count, const i32* ops, const i32* in0, const i32* in1,
+                         const i32* in2, const i32* outs, u32* arena, int nthreads, int mode)
 {
     const size_t n1 = c->p.n + 1;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
@@ -409,7 +436,7 @@ void orc_gate_batch(const orc_ctx* c, u32 count, const i32* ops, const i32* in0,
         const u32* a = in0[g] >= 0 ? arena + (size_t)in0[g] * n1 : NULL;
         const u32* b = in1[g] >= 0 ? arena + (size_t)in1[g] * n1 : NULL;
         const u32* s = in2[g] >= 0 ? arena + (size_t)in2[g] * n1 : NULL;
-        orc_gate(c, ops[g], a, b, s, arena + (size_t)outs[g] * n1, 0);
+        orc_gate(c, ops[g], a, b, s, arena + (size_t)outs[g] * n1, mode);
     }
 }
 

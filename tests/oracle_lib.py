@@ -24,6 +24,9 @@ def lib():
         L.orc_free.argtypes = [ctypes.c_void_p]
         L.orc_gate.argtypes = [ctypes.c_void_p, ctypes.c_int, _u32p, _u32p, _u32p, _u32p, ctypes.c_int]
         L.orc_gate_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint32, _i32p, _i32p, _i32p, _i32p, _i32p, _u32p, ctypes.c_int]
+        L.orc_gate_batch_mode.argtypes = [ctypes.c_void_p, ctypes.c_uint32, _i32p, _i32p, _i32p, _i32p, _i32p, _u32p,
+                                          ctypes.c_int, ctypes.c_int]
+        L.orc_has_fp.argtypes = [ctypes.c_void_p]
         L.orc_blind_rotate.argtypes = [ctypes.c_void_p, _u32p, _u32p, ctypes.c_int]
         L.orc_sample_extract0.argtypes = [ctypes.c_void_p, _u32p, _u32p]
         L.orc_keyswitch.argtypes = [ctypes.c_void_p, _u32p, _u32p]
@@ -59,20 +62,28 @@ class Oracle:
         lib().orc_gate(self.ctx, int(op), _p(args[0]), _p(args[1]), _p(args[2]), _p(out), int(schoolbook))
         return out
 
-    def gate_batch(self, ops, in0, in1, in2, out, arena, nthreads=1):
-        """Same addressing as iyk_hip_gate_batch; arena (slots, n+1) uint32 is updated in place."""
+    MODES = {"goldilocks": 0, "schoolbook": 1, "fp": 2}
+
+    def has_fp(self):
+        """True when the FP64-field restatement (oracle/tfhe_oracle_fp.c) is exact for this parameter set."""
+        return bool(lib().orc_has_fp(self.ctx))
+
+    def gate_batch(self, ops, in0, in1, in2, out, arena, nthreads=1, mode="goldilocks"):
+        """Same addressing as iyk_hip_gate_batch; arena (slots, n+1) uint32 is updated in place.
+        mode: which of the oracle's exact product implementations runs the blind rotation."""
         conv = lambda a: np.ascontiguousarray(a, dtype=np.int32)
         ops, in0, in1, in2, out = map(conv, (ops, in0, in1, in2, out))
         assert arena.dtype == np.uint32 and arena.flags["C_CONTIGUOUS"]
         ip = lambda a: a.ctypes.data_as(_i32p)
-        lib().orc_gate_batch(self.ctx, len(ops), ip(ops), ip(in0), ip(in1), ip(in2), ip(out), _p(arena), nthreads)
+        lib().orc_gate_batch_mode(self.ctx, len(ops), ip(ops), ip(in0), ip(in1), ip(in2), ip(out), _p(arena), nthreads,
+                                  self.MODES[mode])
         return arena
 
-    def bootstrap_lvl1(self, lin, schoolbook=False):
+    def bootstrap_lvl1(self, lin, schoolbook=False, mode=None):
         """blind rotate + sample extract(0): lvl0 TLWE -> lvl1 TLWE (N+1 words)."""
         lin = np.ascontiguousarray(lin, dtype=np.uint32)
         acc = np.zeros((self.p.k + 1) * self.p.N, dtype=np.uint32)
-        lib().orc_blind_rotate(self.ctx, _p(lin), _p(acc), int(schoolbook))
+        lib().orc_blind_rotate(self.ctx, _p(lin), _p(acc), int(schoolbook) if mode is None else self.MODES[mode])
         t1 = np.zeros(self.p.N + 1, dtype=np.uint32)
         lib().orc_sample_extract0(self.ctx, _p(acc), _p(t1))
         return t1

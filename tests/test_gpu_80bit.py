@@ -10,10 +10,10 @@ from iyokan_amd.params import OPS, PLAIN
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("path,kernel", [("fp50", "0"), ("fp50", "1"), ("fp50", "2"), ("goldilocks", None)])
+@pytest.mark.parametrize("path,kernel", [("fp50", "0"), ("fp50", "1"), ("fp50", "2"), ("fp50", "3"), ("goldilocks", None)])
 def test_80bit_gates_bit_exact(path, kernel, keys80, oracle80, monkeypatch):
     """Both exact-arithmetic paths at the 80-bit set: FP64 field with split digits (default; each of its
-    three rotation kernels forced in turn) and the 64-bit integer field (IYK_HIP_NTT=goldilocks)."""
+    four rotation kernels forced in turn) and the 64-bit integer field (IYK_HIP_NTT=goldilocks)."""
     from iyokan_amd import hip
 
     if kernel is None:
@@ -59,3 +59,37 @@ def test_80bit_gates_bit_exact(path, kernel, keys80, oracle80, monkeypatch):
     oracle80.gate_batch(ops, in0, in1, in2, out, ref, nthreads=os.cpu_count() or 1)
     assert np.array_equal(got, ref)
     assert list(client.decrypt_bits(keys80, got[16:])) == want
+
+
+def test_80bit_full_size_flat_nand_property(keys80, oracle80):
+    """BASELINE config #5 shape at full size: 65 536 independent NANDs at the 80-bit set; every output decrypts to
+    the NAND of its plaintexts, and a 32-gate sample is bit-equal to the oracle."""
+    from iyokan_amd import hip
+
+    hip.initialize(keys80, device_ids=(0,))
+    try:
+        st = hip.Stream(0)
+        p = keys80.params
+        G, nin = 65536, 2048
+        rng = np.random.default_rng(12)
+        bits = rng.integers(0, 2, size=nin).astype(np.uint8)
+        ia = rng.integers(0, nin, size=G).astype(np.int32)
+        ib = rng.integers(0, nin, size=G).astype(np.int32)
+        enc = client.encrypt_bits(keys80, bits, seed=6)
+        arena = hip.Arena(nin + G)
+        st.upload(arena, 0, enc)
+        st.gate_batch(arena, np.full(G, OPS["NAND"], dtype=np.int32), ia, ib, np.full(G, -1, dtype=np.int32),
+                      np.arange(nin, nin + G, dtype=np.int32))
+        st.sync()
+        got = st.download(arena, nin, G)
+        arena.free()
+        st.destroy()
+    finally:
+        hip.cleanup()
+    assert np.array_equal(client.decrypt_bits(keys80, got), 1 - (bits[ia] & bits[ib]))
+    sample = rng.choice(G, size=32, replace=False)
+    ref = np.zeros((nin + 32, p.n + 1), dtype=np.uint32)
+    ref[:nin] = enc
+    oracle80.gate_batch([OPS["NAND"]] * 32, ia[sample], ib[sample], [-1] * 32, list(range(nin, nin + 32)), ref,
+                        nthreads=os.cpu_count() or 1)
+    assert np.array_equal(got[sample], ref[nin:])

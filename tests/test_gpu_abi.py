@@ -78,7 +78,7 @@ def test_trlwe_bootstrap_then_extract_keyswitch(gpu, keys128, oracle128):
     st.upload(arena, 0, cts)
     trlwe = torch.zeros((1, 2 * p.N), dtype=torch.int32, device="cuda")
     st.bootstrap_trlwe_batch(arena, [0], [1], [-1], [-1], [np.uint32(p.mu)], trlwe.data_ptr())
-    st.sample_extract_keyswitch_batch(trlwe.data_ptr(), [0], [2], arena)
+    st.sample_extract_keyswitch_batch(trlwe.data_ptr(), [0], [2], arena, trlwe_slots=1)
     st.gate_batch(arena, [OPS["NAND"]], [0], [1], [-1], [3])
     st.sync()
     got = st.download(arena, 2, 2)
@@ -125,15 +125,75 @@ def test_error_codes(gpu, keys128):
     i32 = lambda *v: np.array(v, dtype=np.int32)
     with pytest.raises(gpu.IykHipError, match="unknown gate op"):
         st.gate_batch(arena, i32(99), i32(0), i32(1), i32(-1), i32(2))
-    with pytest.raises(gpu.IykHipError, match="MUX needs three inputs"):
+    with pytest.raises(gpu.IykHipError, match="MUX needs three input slots"):
         st.gate_batch(arena, i32(OPS["MUX"]), i32(0), i32(1), i32(-1), i32(2))
-    with pytest.raises(gpu.IykHipError, match="negative output slot"):
+    with pytest.raises(gpu.IykHipError, match="output slot outside the arena"):
         st.gate_batch(arena, i32(OPS["NAND"]), i32(0), i32(1), i32(-1), i32(-1))
-    assert L.iyk_hip_gate_batch(None, ctypes.c_void_p(arena.ptr), 1, None, None, None, None, None) == -1
+    # every index is checked against the arena size the caller states: no out-of-bounds device access
+    with pytest.raises(gpu.IykHipError, match="output slot outside the arena"):
+        st.gate_batch(arena, i32(OPS["NAND"]), i32(0), i32(1), i32(-1), i32(4))
+    with pytest.raises(gpu.IykHipError, match="two input slots inside the arena"):
+        st.gate_batch(arena, i32(OPS["NAND"]), i32(0), i32(4), i32(-1), i32(2))
+    with pytest.raises(gpu.IykHipError, match="NOT/COPY needs one input slot"):
+        st.gate_batch(arena, i32(OPS["NOT"]), i32(17), i32(-1), i32(-1), i32(2))
+    with pytest.raises(gpu.IykHipError, match="outside the buffer"):
+        st.download(arena, 3, 2)
+    with pytest.raises(gpu.IykHipError, match="slot index outside the arena"):
+        st.download_slots(arena, [0, 4])
+    with pytest.raises(gpu.IykHipError, match="input slot outside the arena"):
+        import torch
+        out = torch.zeros((1, keys128.params.N + 1), dtype=torch.int32, device="cuda")
+        st.blind_rotate_batch(arena, [-1], [-1], [1], [0], [np.uint32(0)], out.data_ptr())
+    assert L.iyk_hip_gate_batch(None, ctypes.c_void_p(arena.ptr), 4, 1, None, None, None, None, None) == -1
     assert L.iyk_hip_init(1, None, ctypes.byref(keys128.params), None, None) == -2       # already initialised
     assert L.iyk_hip_cleanup() == -2 and b"streams still alive" in L.iyk_hip_last_error()
     h = ctypes.c_void_p()
     assert L.iyk_hip_stream_create(7, ctypes.byref(h)) == -1                               # gpu_index out of range
     assert gpu.resident_key_bytes() > 100e6 and gpu.ntt_path() in ("fp50", "goldilocks")
+    assert L.iyk_hip_stream_gpu(st.h) == 0
+    arena.free()
+    st.destroy()
+
+
+def test_bulk_slot_io_and_arena_copy(gpu, keys128):
+    """upload_slots / download_slots (Mem::set/get of many cells in one transfer) and the device-side copy."""
+    st = gpu.Stream(0)
+    p = keys128.params
+    rng = np.random.default_rng(5)
+    host = rng.integers(0, 2**32, size=(300, p.n + 1), dtype=np.uint64).astype(np.uint32)
+    arena = gpu.Arena(1000)
+    slots = rng.permutation(1000)[:300]
+    st.upload_slots(arena, slots, host)
+    assert np.array_equal(st.download_slots(arena, slots), host)
+    order = rng.permutation(300)
+    assert np.array_equal(st.download_slots(arena, slots[order]), host[order])
+    lo = int(np.argmin(slots))
+    assert np.array_equal(st.download(arena, int(slots[lo]), 1)[0], host[lo])
+    other = gpu.Arena(400)
+    st.arena_copy(other, 100, arena, 0, 300)
+    assert np.array_equal(st.download(other, 100, 300), st.download(arena, 0, 300))
+    for a in (arena, other):
+        a.free()
+    st.destroy()
+
+
+def test_timing_log_covers_rotation_only_calls(gpu, keys128):
+    """after timing_log_begin the rotation-only entry points must still work (they create their own events)."""
+    import torch
+
+    st = gpu.Stream(0)
+    p = keys128.params
+    cts = client.encrypt_bits(keys128, [1, 0], seed=93)
+    arena = gpu.Arena(3)
+    st.upload(arena, 0, cts)
+    out = torch.zeros((1, p.N + 1), dtype=torch.int32, device="cuda")
+    st.timing_log_begin()
+    st.blind_rotate_batch(arena, [0], [1], [-1], [-1], [np.uint32(p.mu)], out.data_ptr())
+    st.gate_batch(arena, [OPS["NAND"]], [0], [1], [-1], [2])
+    nb, br_ms, ks_ms = st.timing_log_end()
+    assert nb == 2 and br_ms > 0 and ks_ms > 0
+    st.gate_batch(arena, [OPS["NAND"]], [0], [1], [-1], [2])   # standing events were re-created
+    st.sync()
+    assert st.last_batch_timing()[0] > 0
     arena.free()
     st.destroy()

@@ -241,9 +241,9 @@ def test_full_size_flat_nand_property(gpu128, keys128, oracle128):
 
 
 def test_all_rotation_kernels_agree(gpu128, keys128, oracle128):
-    """The wave-per-rotation kernel, the wave-per-level and the two-waves-per-level low-latency kernels
-    (IYK_HIP_LATENCY_KERNEL=0/1/2 forces one; default picks by batch size) must produce identical
-    ciphertexts, equal to the oracle."""
+    """The wave-per-rotation kernel and the three workgroup-per-rotation kernels (wave per level, two waves per
+    level, wave per (polynomial, level); IYK_HIP_LATENCY_KERNEL=0/1/2/3 forces one, default picks by batch
+    size) must produce identical ciphertexts, equal to the oracle."""
     hip, st = gpu128
     p = keys128.params
     rng = np.random.default_rng(41)
@@ -258,7 +258,7 @@ def test_all_rotation_kernels_agree(gpu128, keys128, oracle128):
     results = {}
     old = os.environ.get("IYK_HIP_LATENCY_KERNEL")
     try:
-        for mode in ("0", "1", "2"):
+        for mode in ("0", "1", "2", "3"):
             os.environ["IYK_HIP_LATENCY_KERNEL"] = mode
             results[mode] = _run(hip, st, host, ops, in0, in1, in2, out)
     finally:
@@ -268,6 +268,7 @@ def test_all_rotation_kernels_agree(gpu128, keys128, oracle128):
             os.environ["IYK_HIP_LATENCY_KERNEL"] = old
     assert np.array_equal(results["0"], results["1"])
     assert np.array_equal(results["0"], results["2"])
+    assert np.array_equal(results["0"], results["3"])
     ref = host.copy()
     oracle128.gate_batch(ops, in0, in1, in2, out, ref, nthreads=os.cpu_count() or 1)
     assert np.array_equal(results["0"], ref)
@@ -332,3 +333,26 @@ def test_mid_size_batch_uses_both_kernels(gpu128, keys128, rem):
                np.arange(nin, nin + ng, dtype=np.int32))
     assert np.array_equal(got[:nin], enc)
     assert np.array_equal(client.decrypt_bits(keys128, got[nin:]), bits[ia] ^ bits[ib])
+
+
+def test_dispatch_split_bit_exact_vs_oracle(gpu128, keys128, oracle128):
+    """2048 + 150 rotations: the full round runs on the wave-per-rotation kernel, the remainder on the
+    workgroup-per-rotation kernel with a non-zero job offset (`first`).  64 gates from EACH side of the split
+    are compared word for word with the oracle (the other tests of the split only decrypt)."""
+    hip, st = gpu128
+    p = keys128.params
+    rng = np.random.default_rng(4321)
+    nin, ng = 300, 2048 + 150
+    bits = rng.integers(0, 2, size=nin).astype(np.uint8)
+    ia = rng.integers(0, nin, size=ng).astype(np.int32)
+    ib = rng.integers(0, nin, size=ng).astype(np.int32)
+    ops = rng.choice([OPS["NAND"], OPS["ANDNOT"], OPS["XNOR"]], size=ng).astype(np.int32)
+    host = np.zeros((nin + ng, p.n + 1), dtype=np.uint32)
+    host[:nin] = client.encrypt_bits(keys128, bits, seed=79)
+    got = _run(hip, st, host, ops, ia, ib, np.full(ng, -1, dtype=np.int32), np.arange(nin, nin + ng, dtype=np.int32))
+    sample = np.concatenate([rng.choice(2048, size=64, replace=False), 2048 + rng.choice(150, size=64, replace=False)])
+    ref = np.zeros((nin + len(sample), p.n + 1), dtype=np.uint32)
+    ref[:nin] = host[:nin]
+    oracle128.gate_batch(ops[sample], ia[sample], ib[sample], [-1] * len(sample),
+                         list(range(nin, nin + len(sample))), ref, nthreads=os.cpu_count() or 1)
+    assert np.array_equal(got[nin + sample], ref[nin:])

@@ -1,0 +1,81 @@
+"""GPU: IYK_HIP_DEBUG=1 verifies the gate_batch independence contract (own library lifetime: the flag is read at
+iyk_hip_init, so this module initialises the library itself; named zz to run after the module-scoped fixtures of
+the other GPU test files have been torn down)."""
+import os
+
+import numpy as np
+import pytest
+
+from iyokan_amd import client
+from iyokan_amd.params import OPS
+
+pytestmark = pytest.mark.gpu
+
+
+def test_debug_mode_checks_independence(keys128, oracle128, monkeypatch):
+    from iyokan_amd import hip
+
+    monkeypatch.setenv("IYK_HIP_DEBUG", "1")
+    hip.initialize(keys128, device_ids=(0,))
+    try:
+        st = hip.Stream(0)
+        arena = hip.Arena(8)
+        cts = client.encrypt_bits(keys128, [1, 0, 1], seed=17)
+        st.upload(arena, 0, cts)
+        nand = OPS["NAND"]
+        with pytest.raises(hip.IykHipError, match="two gates of one batch write the same slot"):
+            st.gate_batch(arena, [nand, nand], [0, 1], [1, 2], [-1, -1], [4, 4])
+        with pytest.raises(hip.IykHipError, match="reads a slot another gate of the same batch writes"):
+            st.gate_batch(arena, [nand, nand], [0, 4], [1, 2], [-1, -1], [4, 5])
+        # writing over one's OWN input stays legal, and a legal batch still computes the right thing
+        st.gate_batch(arena, [nand, OPS["NOT"]], [0, 2], [1, -1], [-1, -1], [0, 2])
+        st.sync()
+        got = st.download(arena, 0, 3)
+        assert np.array_equal(got[0], oracle128.gate(nand, cts[0], cts[1]))
+        assert np.array_equal(got[2], (np.uint32(0) - cts[2]).astype(np.uint32))
+        arena.free()
+        st.destroy()
+    finally:
+        hip.cleanup()
+
+
+def test_two_gpu_replicas_on_one_device(keys128, oracle128):
+    """In-process multi-GPU shape (cufhe::SetGPUNum): ngpu = 2 with both indices mapped to device 0 (a 1-GPU box
+    cannot offer two ordinals; key replicas, per-GPU streams and the gather -> peer copy -> scatter exchange of
+    iyk_hip_arena_sync_slots are exactly the N-GPU code path).  A frontier is dealt to the two replicas, each
+    computes its half, the halves are exchanged, and both arenas must then equal the oracle's."""
+    from iyokan_amd import hip
+
+    hip.initialize(keys128, device_ids=(0, 0))
+    try:
+        assert hip.lib().iyk_hip_num_gpus() == 2
+        p = keys128.params
+        rng = np.random.default_rng(8)
+        nin, ng = 32, 40
+        bits = rng.integers(0, 2, size=nin).astype(np.uint8)
+        host = np.zeros((nin + ng, p.n + 1), dtype=np.uint32)
+        host[:nin] = client.encrypt_bits(keys128, bits, seed=23)
+        ops = rng.choice([OPS["NAND"], OPS["XOR"], OPS["MUX"]], size=ng).astype(np.int32)
+        in0, in1, in2 = (rng.integers(0, nin, size=ng).astype(np.int32) for _ in range(3))
+        in2 = np.where(ops == OPS["MUX"], in2, -1).astype(np.int32)
+        out = np.arange(nin, nin + ng, dtype=np.int32)
+        streams = [hip.Stream(g) for g in range(2)]
+        arenas = [hip.Arena(nin + ng, gpu_index=g) for g in range(2)]
+        for st, ar in zip(streams, arenas):
+            st.upload(ar, 0, host)
+        mine = [np.arange(g, ng, 2) for g in range(2)]
+        for g in range(2):
+            sel = mine[g]
+            streams[g].gate_batch(arenas[g], ops[sel], in0[sel], in1[sel], in2[sel], out[sel])
+        for g in range(2):
+            streams[g].sync_slots_to(arenas[g], streams[1 - g], arenas[1 - g], out[mine[g]])
+        got = [st.download(ar, 0, nin + ng) for st, ar in zip(streams, arenas)]
+        ref = host.copy()
+        oracle128.gate_batch(ops, in0, in1, in2, out, ref, nthreads=os.cpu_count() or 1)
+        assert np.array_equal(got[0], ref) and np.array_equal(got[1], ref)
+        for ar in arenas:
+            ar.free()
+        for st in streams:
+            st.destroy()
+    finally:
+        hip.cleanup()

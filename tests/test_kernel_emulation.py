@@ -59,5 +59,11 @@ def test_emulated_fp64_path_bit_exact(which, request):
         got = np.zeros(p.N + 1, dtype=np.uint32)
         assert em.iyk_emul_blind_rotate_fp(ctypes.byref(p), lin.ctypes.data_as(u32p), bk.ctypes.data_as(dp),
                                            got.ctypes.data_as(u32p)) == 0
-        assert np.array_equal(oracle128.bootstrap_lvl1(lin), got)
+        ref = oracle128.bootstrap_lvl1(lin)
+        assert np.array_equal(ref, got)
+        # wave-per-(polynomial, level) low-latency kernel: 16 points per lane, permlane32 exchanges, shared sums
+        got3 = np.zeros(p.N + 1, dtype=np.uint32)
+        assert em.iyk_emul_blind_rotate_fp_lat3(ctypes.byref(p), lin.ctypes.data_as(u32p), bk.ctypes.data_as(dp),
+                                                got3.ctypes.data_as(u32p)) == 0
+        assert np.array_equal(ref, got3)
     assert em.iyk_emul_fp_max_magnitude() < 0.95 * 2.0 ** 53 / 844424931229697

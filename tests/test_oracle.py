@@ -89,3 +89,42 @@ def test_gate_batch_addressing(keys128, oracle128):
     oracle128.gate_batch([OPS["NAND"], OPS["MUX"], OPS["NOT"], OPS["COPY"]], [0, 0, 3, 1], [1, 1, -1, -1],
                          [-1, 2, -1, -1], [4, 5, 6, 7], arena, nthreads=4)
     assert list(client.decrypt_bits(keys128, arena[4:])) == [1, 1, 1, 1]
+
+
+def test_fp_restatement_equals_goldilocks_restatement(keys128, oracle128, keys80, oracle80):
+    """oracle/tfhe_oracle_fp.c (FP64-field products, the faster CPU baseline of bench.py) against
+    oracle/tfhe_oracle.c (Goldilocks products): same words for every gate kind on fresh and on bootstrapped
+    inputs; unavailable (falls back) where its exactness bound fails (80-bit set)."""
+    import os
+
+    import numpy as np
+
+    from iyokan_amd import client
+    from iyokan_amd.params import OPS
+
+    assert oracle128.has_fp() and not oracle80.has_fp()
+    p = keys128.params
+    rng = np.random.default_rng(77)
+    nin = 12
+    bits = rng.integers(0, 2, size=nin).astype(np.uint8)
+    kinds = ["AND", "NAND", "ANDNOT", "OR", "NOR", "ORNOT", "XOR", "XNOR", "MUX", "MUX", "NOT"]
+    ops = [OPS[k] for k in kinds]
+    in0 = [int(v) for v in rng.integers(0, nin, size=len(kinds))]
+    in1 = [int(v) if k != "NOT" else -1 for v, k in zip(rng.integers(0, nin, size=len(kinds)), kinds)]
+    in2 = [int(v) if k == "MUX" else -1 for v, k in zip(rng.integers(0, nin, size=len(kinds)), kinds)]
+    out = list(range(nin, nin + len(kinds)))
+    a = np.zeros((nin + 2 * len(kinds), p.n + 1), dtype=np.uint32)
+    a[:nin] = client.encrypt_bits(keys128, bits, seed=123)
+    b = a.copy()
+    nt = os.cpu_count() or 1
+    oracle128.gate_batch(ops, in0, in1, in2, out, a, nthreads=nt, mode="goldilocks")
+    oracle128.gate_batch(ops, in0, in1, in2, out, b, nthreads=nt, mode="fp")
+    assert np.array_equal(a, b)
+    # second level: inputs are bootstrapped ciphertexts
+    out2 = [o + len(kinds) for o in out]
+    in0b = [nin + (i * 5) % len(kinds) for i in range(len(kinds))]
+    in1b = [nin + (i * 3 + 1) % len(kinds) if k != "NOT" else -1 for i, k in enumerate(kinds)]
+    in2b = [nin + (i * 7 + 2) % len(kinds) if k == "MUX" else -1 for i, k in enumerate(kinds)]
+    oracle128.gate_batch(ops, in0b, in1b, in2b, out2, a, nthreads=nt, mode="goldilocks")
+    oracle128.gate_batch(ops, in0b, in1b, in2b, out2, b, nthreads=nt, mode="fp")
+    assert np.array_equal(a, b)

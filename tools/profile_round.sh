@@ -1,38 +1,47 @@
 #!/bin/bash
 # One-shot profile of the headline workload on the GPU box (run through gpurun):
 #   bash tools/profile_round.sh <tag>
-# writes gpurun_out/<tag>_bench.json, <tag>_kernel_trace.txt, <tag>_pmc.txt, <tag>_traffic.json
-# (copy the ones to keep into profiles/).  Counters are collected in their own --pmc passes, never
-# together with trace domains.
-tag=${1:-rXX}
+# writes gpurun_out/<tag>_bench.json, <tag>_kernel_trace.txt, <tag>_pmc.txt, <tag>_counters.json
+# (copy the ones to keep into profiles/; bench.py reads profiles/r02_counters.json).  Counters are collected
+# in their own --pmc passes, never together with trace domains.
+tag=${1:-r02}
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
 mkdir -p gpurun_out
 if [ -z "$PMC_ONLY" ]; then
-timeout 300 python bench.py 2>/dev/null | tail -1 > gpurun_out/${tag}_bench.json
+timeout 600 python bench.py 2>/dev/null | tail -1 > gpurun_out/${tag}_bench.json
 rm -rf /tmp/prof_kt && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python bench.py --cpu-sample 0 > /tmp/kt.log 2>&1
 python tools/rocprof_summary.py $(find /tmp/prof_kt -name "*.db" | head -1) > gpurun_out/${tag}_kernel_trace.txt
 fi
 {
-  echo "# rocprofv3 --pmc passes, 65536 NAND / launch (bench.py --steps 1 --warmup 0); KiB units (gfx950: double FETCH_SIZE)"
-  for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+  echo "# rocprofv3 --pmc passes, 65536 NAND / launch (bench.py --steps 1 --warmup 0); FETCH/WRITE in KiB (gfx950: double FETCH_SIZE)"
+  for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD" \
+             "GRBM_GUI_ACTIVE" "SQ_BUSY_CYCLES SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
     rm -rf /tmp/prof_pmc; timeout 300 rocprofv3 --pmc $grp -d /tmp/prof_pmc -o pmc -- python bench.py --steps 1 --warmup 0 --cpu-sample 0 > /tmp/pmc.log 2>&1
     db=$(find /tmp/prof_pmc -name "*.db" 2>/dev/null | head -1)
-    if [ -n "$db" ]; then python tools/rocprof_summary.py $db --pmc | grep -v "^#\|^ *[0-9]\|^ calls"; else echo "# pass failed: $grp"; tail -5 /tmp/pmc.log | sed 's/^/#   /'; fi
+    if [ -n "$db" ]; then
+      python tools/rocprof_summary.py $db --pmc | grep -v "^#\|^ calls" | grep "blind_rotate\|keyswitch_kernel\|^ *[0-9]" | grep -v "copyBuffer\|at::native"
+    else echo "# pass failed: $grp"; tail -5 /tmp/pmc.log | sed 's/^/#   /'; fi
   done
 } > gpurun_out/${tag}_pmc.txt
 python - "$tag" <<'PY'
 import json, re, sys
 tag = sys.argv[1]
-vals = {}
+vals, durs = {}, []
 for line in open(f"gpurun_out/{tag}_pmc.txt"):
     m = re.match(r"(\w+)\s+([\d.]+)\s+n=\d+\s+(.*)", line)
     if m and "blind_rotate" in m.group(3):
         vals[m.group(1)] = float(m.group(2))
+    m = re.match(r"\s*(\d+)\s+(\d+)\s+(\d+)\s+[\d.]+\s+(.*)", line)   # calls total_ns avg_ns pct kernel
+    if m and "blind_rotate" in m.group(4):
+        durs.append(float(m.group(3)))
 if "FETCH_SIZE" in vals:
     out = {
-        "_doc": "HBM traffic of the dominant kernel from separate rocprofv3 --pmc passes: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 "
-                "per launch; the factor 2 is the gfx950 FETCH_SIZE correction prescribed by MI355X_MICROARCH.md (HBM section). "
-                "bench.py copies traffic_bytes_per_launch into roofline.traffic when the workload matches.",
+        "_doc": "Counters of the dominant kernel from separate rocprofv3 --pmc passes (tools/profile_round.sh), one "
+                "65536-NAND launch.  traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes: the factor 2 is the gfx950 "
+                "FETCH_SIZE correction prescribed by MI355X_MICROARCH.md (HBM section).  valu_insts_per_launch = "
+                "SQ_INSTS_VALU (wave-instructions, deterministic for a given kernel build and workload).  "
+                "sustained_clock_ghz = GRBM_GUI_ACTIVE / 8 XCDs / kernel duration of that pass.  bench.py reads this "
+                "file for roofline.traffic and roofline.valu when the workload matches.",
         "kernel": "blind_rotate_fp_kernel<Decomp<3,6,1>>",
         "workload": {"gates_per_launch": 65536, "params": "128bit", "op": "NAND"},
         "FETCH_SIZE_KiB": vals["FETCH_SIZE"], "WRITE_SIZE_KiB": vals.get("WRITE_SIZE", 0.0),
@@ -40,7 +49,19 @@ if "FETCH_SIZE" in vals:
     }
     if "TCC_HIT_sum" in vals and "TCC_MISS_sum" in vals:
         out["l2_hit_rate"] = round(vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"]), 4)
-    json.dump(out, open(f"gpurun_out/{tag}_traffic.json", "w"), indent=1)
+    for k_src, k_dst in (("SQ_INSTS_VALU", "valu_insts_per_launch"), ("SQ_INSTS_LDS", "lds_insts_per_launch"),
+                         ("SQ_INSTS_SALU", "salu_insts_per_launch"), ("SQ_INSTS_VMEM_RD", "vmem_rd_insts_per_launch"),
+                         ("GRBM_GUI_ACTIVE", "GRBM_GUI_ACTIVE"), ("SQ_BUSY_CYCLES", "SQ_BUSY_CYCLES"),
+                         ("SQ_WAVES", "SQ_WAVES")):
+        if k_src in vals:
+            out[k_dst] = vals[k_src]
+    if durs:
+        out["pmc_pass_avg_launch_ns"] = sum(durs) / len(durs)
+        if "GRBM_GUI_ACTIVE" in vals:
+            clk = vals["GRBM_GUI_ACTIVE"] / 8.0 / (sum(durs) / len(durs))
+            if 0.5 < clk < 3.0:
+                out["sustained_clock_ghz"] = round(clk, 3)
+    json.dump(out, open(f"gpurun_out/{tag}_counters.json", "w"), indent=1)
     print(out)
 PY
 cat gpurun_out/${tag}_kernel_trace.txt | head -12
