@@ -2,6 +2,11 @@
 
 Mirrors what `iyokan-packet genkey|genevalkey|enc|dec` does for the reference
 (/root/reference/src/iyokan-packet.cpp:144-178); used to make synthetic, non-trivial inputs.
+
+Randomness: `seed=None` (the default) draws keys / masks / noise from a ChaCha20 stream keyed with fresh
+getrandom(2) entropy for every call — two encryptions never share a mask.  An explicit integer `seed` selects
+a seeded, NON-cryptographic generator: reproducible fixtures for tests and benchmarks only (the same seed
+reproduces the same masks, so never encrypt two messages meant to stay secret with one seed).
 """
 import ctypes
 import os
@@ -22,8 +27,9 @@ def _lib():
         if not os.path.exists(path):
             raise RuntimeError(f"{path} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
         lib = ctypes.CDLL(path)
-        lib.iyk_client_keygen.argtypes = [ctypes.POINTER(IykParams), ctypes.c_uint64, _u32p, _u32p, _u32p, _u32p]
-        lib.iyk_client_encrypt_bits.argtypes = [ctypes.POINTER(IykParams), _u32p, ctypes.c_uint64, _u8p, ctypes.c_uint64, _u32p]
+        lib.iyk_client_keygen.argtypes = [ctypes.POINTER(IykParams), ctypes.c_uint64, ctypes.c_int, _u32p, _u32p, _u32p, _u32p]
+        lib.iyk_client_encrypt_bits.argtypes = [ctypes.POINTER(IykParams), _u32p, ctypes.c_uint64, ctypes.c_int, _u8p,
+                                                ctypes.c_uint64, _u32p]
         lib.iyk_client_decrypt_bits.argtypes = [ctypes.POINTER(IykParams), _u32p, _u32p, ctypes.c_uint64, _u8p]
         lib.iyk_client_phases.argtypes = [ctypes.POINTER(IykParams), _u32p, _u32p, ctypes.c_uint64, _u32p]
         lib.iyk_client_trivial.argtypes = [ctypes.POINTER(IykParams), ctypes.c_int, _u32p]
@@ -42,22 +48,25 @@ class KeySet:
         self.params, self.s0, self.s1, self.bk, self.ksk = params, s0, s1, bk, ksk
 
 
-def keygen(params: IykParams, seed: int = 1) -> KeySet:
+def keygen(params: IykParams, seed=None) -> KeySet:
+    """SecretKey + EvalKey material.  seed=None: OS entropy (CSPRNG); an int: reproducible fixture keys."""
     s0 = np.zeros(params.n, dtype=np.uint32)
     s1 = np.zeros(params.N, dtype=np.uint32)
     bk = np.zeros(params.bk_words, dtype=np.uint32)
     ksk = np.zeros(params.ksk_words, dtype=np.uint32)
-    rc = _lib().iyk_client_keygen(ctypes.byref(params), seed, _p32(s0), _p32(s1), _p32(bk), _p32(ksk))
+    rc = _lib().iyk_client_keygen(ctypes.byref(params), 0 if seed is None else int(seed), int(seed is not None),
+                                  _p32(s0), _p32(s1), _p32(bk), _p32(ksk))
     if rc != 0:
         raise RuntimeError(f"iyk_client_keygen failed: {rc}")
     return KeySet(params, s0, s1, bk, ksk)
 
 
-def encrypt_bits(keys: KeySet, bits, seed: int = 2) -> np.ndarray:
+def encrypt_bits(keys: KeySet, bits, seed=None) -> np.ndarray:
+    """bootsSymEncrypt of a bit vector.  seed=None: fresh OS-keyed stream per call; an int: reproducible fixture."""
     bits = np.ascontiguousarray(np.asarray(bits, dtype=np.uint8).ravel())
     out = np.zeros((bits.size, keys.params.n + 1), dtype=np.uint32)
-    _lib().iyk_client_encrypt_bits(ctypes.byref(keys.params), _p32(keys.s0), seed,
-                                   bits.ctypes.data_as(_u8p), bits.size, _p32(out))
+    _lib().iyk_client_encrypt_bits(ctypes.byref(keys.params), _p32(keys.s0), 0 if seed is None else int(seed),
+                                   int(seed is not None), bits.ctypes.data_as(_u8p), bits.size, _p32(out))
     return out
 
 

@@ -26,20 +26,45 @@
 // magnitudes stay within the bounds proven there and the results are the same integers mod p: bit-identical
 // output.  csrc/emul.cpp runs these functions lane by lane on the CPU against the oracle.
 #pragma once
+#include <type_traits>
+#include <utility>
+
 #include "blind_rotate_fp.hpp"
 
 namespace iyk {
 namespace fp {
 
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}), so that the
+// renormalisation decisions below are `if constexpr` on the static schedule (left to the optimiser, stage 0's
+// table look-ups survived as run-time byte loads from constant memory: 8 global loads on the critical path per pass)
+template <class F, int... I>
+IYK_HD void static_for_impl(F&& f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+IYK_HD void static_for(F&& f)
+{
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
 // union of the two half-blocks' renormalisation schedules (a renormalisation never hurts: it is exact mod p
 // and only shrinks magnitudes)
 template <int PASS>
 struct Sched16 {
-    static constexpr const NormSched& S = PASS == PASS1 ? kSched1 : kSched2;
-    static constexpr bool sum0(int m) { return S.sum[0][2 * m] || S.sum[0][2 * m + 1]; }  // stage 0, pair j = 2m + half
-    static constexpr bool dif0() { return S.dif[0][16]; }                                  // only j = 0 has a twiddle-free difference
-    static constexpr bool sum(int s, int a) { return S.sum[s][a] || S.sum[s][16 + a]; }
-    static constexpr bool dif(int s, int b) { return S.dif[s][b] || S.dif[s][16 + b]; }
+    static constexpr bool sum0(int m)  // stage 0, pair j = 2m + half
+    {
+        return PASS == PASS1 ? (kSched1.sum[0][2 * m] || kSched1.sum[0][2 * m + 1]) : (kSched2.sum[0][2 * m] || kSched2.sum[0][2 * m + 1]);
+    }
+    static constexpr bool dif0() { return PASS == PASS1 ? kSched1.dif[0][16] : kSched2.dif[0][16]; }  // only j = 0 has a twiddle-free difference
+    static constexpr bool sum(int s, int a)
+    {
+        return PASS == PASS1 ? (kSched1.sum[s][a] || kSched1.sum[s][16 + a]) : (kSched2.sum[s][a] || kSched2.sum[s][16 + a]);
+    }
+    static constexpr bool dif(int s, int b)
+    {
+        return PASS == PASS1 ? (kSched1.dif[s][b] || kSched1.dif[s][16 + b]) : (kSched2.dif[s][b] || kSched2.dif[s][16 + b]);
+    }
 };
 
 // stage 0 on the pairs a lane holds after the swap-in: (a[2m], a[2m+1]) = (u, v) of pair j = 2m + half
@@ -48,44 +73,55 @@ template <int PASS>
 IYK_HD void dif16_stage0(double (&a)[16], int half, const double (&tw0)[8])
 {
     typedef Sched16<PASS> U;
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
+    static_for<8>([&](auto M) {
+        constexpr int m = decltype(M)::value;
+        constexpr bool nsum = U::sum0(m), ndif = U::dif0();
         const double u = a[2 * m], v = a[2 * m + 1];
         const double sum = u + v, dif = u - v;
-        a[2 * m] = U::sum0(m) ? norm(sum) : sum;
+        if constexpr (nsum) a[2 * m] = norm(sum);
+        else a[2 * m] = sum;
         const double tw = mulmod(dif, tw0[m]);
-        if (m == 0) {
+        if constexpr (m == 0) {
             // pair j = 0 (lower half-wave) has the trivial twiddle: the schedule treats its difference like a sum
-            const double plain = U::dif0() ? norm(dif) : dif;
+            double plain = dif;
+            if constexpr (ndif) plain = norm(dif);
             a[1] = half ? tw : plain;
         }
         else {
             a[2 * m + 1] = tw;
         }
-    }
+    });
 }
 
 // stages 1..4 inside a 16-block (the sums or the differences of stage 0), natural in, bit-reversed out:
 // a[q] becomes position 16 half + q of the full 32-point DIF
+template <int PASS, int S_, int X, int Y, int J>
+IYK_HD void dif16_bfly(double (&a)[16], const double* w)
+{
+    typedef Sched16<PASS> U;
+    constexpr bool nsum = U::sum(S_, X), ndif = U::dif(S_, Y);
+    const double u = a[X], v = a[Y];
+    const double sum = u + v, dif = u - v;
+    if constexpr (nsum) a[X] = norm(sum);
+    else a[X] = sum;
+    if constexpr (J == 0) {
+        if constexpr (ndif) a[Y] = norm(dif);
+        else a[Y] = dif;
+    }
+    else {
+        a[Y] = mulmod(dif, w[J << S_]);
+    }
+}
 template <int PASS>
 IYK_HD void dif16_stages14(double (&a)[16], const double* w)
 {
-    typedef Sched16<PASS> U;
-#pragma unroll
-    for (int s = 1; s < 5; ++s) {
-        const int len = 16 >> s;
-#pragma unroll
-        for (int blk = 0; blk < 16; blk += 2 * len) {
-#pragma unroll
-            for (int j = 0; j < len; ++j) {
-                const int x = blk + j, y = blk + j + len;
-                const double u = a[x], v = a[y];
-                const double sum = u + v, dif = u - v;
-                a[x] = U::sum(s, x) ? norm(sum) : sum;
-                a[y] = (j == 0) ? (U::dif(s, y) ? norm(dif) : dif) : mulmod(dif, w[j << s]);
-            }
-        }
-    }
+    // 4 stages x 8 butterflies; butterfly b of stage s: len = 16 >> s, block = b / len, j = b % len
+    static_for<32>([&](auto B) {
+        constexpr int idx = decltype(B)::value;
+        constexpr int s = 1 + idx / 8, b = idx % 8;
+        constexpr int len = 16 >> s, blk = (b / len) * 2 * len, j = b % len;
+        dif16_bfly<PASS, s, blk + j, blk + j + len, j>(a, w);
+    });
 }
 
 // DIF output position 16 half + q holds frequency brv5(16 half + q) = 2 brv4(q) + half

@@ -259,7 +259,9 @@ int dispatch_fp(iyk_hip_stream* st, int njobs, const RotOut& o)
     const int rem = njobs % round, full = njobs - rem;
     if (rem > G.lat_threshold) return launch_br_fp<DC>(st, 0, njobs, o);
     if (full && (rc = launch_br_fp<DC>(st, 0, full, o))) return rc;
-    if (rem) return launch_br_fp_lat_any<DC>(st, G.lat_kernel, full, rem, o);
+    // one workgroup per CU: the widest-split kernel (lat_kernel, default 3) wins while every rotation has a CU of its
+    // own (<= 256); above that two rotations share a CU and the 3-wave kernel (two workgroups per CU fit) is faster
+    if (rem) return launch_br_fp_lat_any<DC>(st, rem <= 256 ? G.lat_kernel : 1, full, rem, o);
     return IYK_OK;
 }
 

@@ -868,6 +868,19 @@ __device__ __forceinline__ void dif16(double (&a)[16], int half, const double (&
     fp::dif16_stages14<PASS>(a, w);
 }
 
+// Phase stamps for tools/ubench/lat3_trace.hip only (compiled with -DIYK_LAT3_TRACE=<step>): s_memtime at the phase
+// boundaries of ONE step, written per wave to the buffer passed in place of out_index.  Not part of the product build.
+#ifdef IYK_LAT3_TRACE
+#define IYK_TRACE_DECL unsigned long long trace_[16] = {}
+#define IYK_TRACE(k)                                                                                      \
+    do {                                                                                                  \
+        if (i == (u32)(IYK_LAT3_TRACE)) trace_[k] = __builtin_readcyclecounter();                         \
+    } while (0)
+#else
+#define IYK_TRACE_DECL
+#define IYK_TRACE(k)
+#endif
+
 template <class D>
 __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kernel(
     const u32* __restrict__ abar_all, int njobs, const double* __restrict__ bk_ntt,
@@ -932,6 +945,7 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
         }
     }
 
+    IYK_TRACE_DECL;
     u32 ab_next = abar[0];
     for (u32 i = 0; i < n; ++i) {
         const u32 ab = ab_next;
@@ -939,15 +953,20 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
         double x[16];
         int t = t0, half = half0;
         asm volatile("" : "+v"(t), "+v"(half));  // keep lane-dependent address math inside the iteration (no hoisting)
+        IYK_TRACE(0);
         // ---- forward: digits -> pass 1 -> twiddle -> transpose -> pass 2 -> two products into the shared sums
         fp::fwd1_pre16<D>(half, t, v, ab, acc_h, x, s_ztab);
+        IYK_TRACE(1);
         dif16<fp::PASS1>(x, half, tw0, C.w);
         fp::fwd1_twiddle16(half, t, x, s_twf);
+        IYK_TRACE(2);
         fp::xpose16_write<false>(half, t, x, xb);
         lds_sync();
         fp::xpose16_read(half, t, x, xb);
         lds_sync();
+        IYK_TRACE(3);
         dif16<fp::PASS2>(x, half, tw0, C.w);
+        IYK_TRACE(4);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             double p0 = fp::mulmod(x[q], bk0[q]), p1 = fp::mulmod(x[q], bk1[q]);
@@ -970,7 +989,9 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
                 bk1[q] = b1[fp::brv4(q) * 64];
             }
         }
+        IYK_TRACE(5);
         wg_barrier_lds();  // all 2 (k+1) LV products are in the sums
+        IYK_TRACE(6);
         // ---- inverse of sum_h -> accumulator polynomial h (waves (h, 0))
         if (v == 0) {
             asm volatile("" : "+v"(t), "+v"(half));
@@ -983,20 +1004,33 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = fp::norm(x[r]);
+            IYK_TRACE(7);
             dif16<fp::PASS1>(x, half, tw0, C.w);
             fp::inv1_twiddle16(half, t, x, s_twi);
+            IYK_TRACE(8);
             fp::xpose16_write<true>(half, t, x, xb);
             lds_sync();
             fp::xpose16_read(half, t, x, xb);
             lds_sync();
+            IYK_TRACE(9);
             dif16<fp::PASS2>(x, half, tw0, C.w);
+            IYK_TRACE(10);
 #pragma unroll
             for (int q = 0; q < 16; ++q)
                 __hip_atomic_fetch_add(acc_h + t + 32 * fp::inv16(half, q), fp::inv2_post16(x[q], zi16[q]), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WAVEFRONT);
+            IYK_TRACE(11);
         }
         wg_barrier_lds();  // accumulator of step i is complete before anyone derives step i+1's digits
+        IYK_TRACE(12);
     }
+#ifdef IYK_LAT3_TRACE
+    if (lane == 0 && blockIdx.x == 0) {
+        unsigned long long* tr = reinterpret_cast<unsigned long long*>(const_cast<int32_t*>(out_index)) + wave * 16;
+        for (int k = 0; k < 16; ++k) tr[k] = trace_[k];
+    }
+    out_index = nullptr;
+#endif
 
     if (wave == 0) {
         if (trlwe_mode) {  // raw accumulator: TRLWE (a(X), b(X)), 2N words per job

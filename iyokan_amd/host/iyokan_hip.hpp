@@ -6,22 +6,29 @@
 //   TaskHIPGate{Mem,DFF,WIRE} <- TaskCUFHEGate{Mem,DFF,WIRE}   :70-205
 //   TaskHIPGate (12 kinds)    <- DEFINE_TASK_GATE(...)         :207-261
 //   HIPNetworkBuilder    <- CUFHENetworkBuilder       :264-288
-//   HIPWorker            <- CUFHEWorker               :290-312
-//   HIPNetworkRunner     <- CUFHENetworkRunner        :666-753   (GPU half; no CPU bridge)
+//   HIPWorker            <- CUFHEWorker               :290-312   (one batching worker drives ALL GPUs)
+//   TaskHIP2TFHEpp / TaskTFHEpp2HIP      <- TaskCUFHE2TFHEpp / TaskTFHEpp2CUFHE  :314-356  (host <-> device bridges)
+//   TaskHIPRAMSEIAndKS                   <- TaskCUFHERAMSEIAndKS                 :592-627
+//   TaskHIPRAMGateBootstrapping          <- TaskCUFHERAMGateBootstrapping        :629-661
+//   HIPNetworkRunner     <- CUFHENetworkRunner        :666-753   (GPU half; the TFHEpp CPU runner stays upstream's)
 //   processAllGates(HIPNetwork&, ...)  <- /root/reference/src/iyokan_cufhe.cpp:854-878
-//   initializeHIP / cleanupHIP         <- CUFHEFrontend::initializeCUFHE :530-536, CleanUp :721
+//   initializeHIP / cleanupHIP         <- CUFHEFrontend::initializeCUFHE :530-536 (SetGPUNum + Initialize), CleanUp :721
 //   trivial / decrypt helpers          <- /root/reference/src/tfhepp_cufhe_wrapper.hpp:24-37
 //
 // What is different BY DESIGN (MI355X-first):
-//  * Ciphertexts are device-resident.  A task's output is a slot of one arena in HBM; only
-//    Mem::set/get (INPUT / OUTPUT / RAM / ROM cells) cross PCIe.  The reference copies both
-//    inputs host->device and the output device->host for every single gate (:217-222,238-241).
-//  * One BATCHING worker replaces hundreds of one-gate workers: HIPWorker::update() drains the
-//    whole ready frontier into ONE iyk_hip_gate_batch (a handful of kernel launches) and propagates the
-//    frontier when its stream goes idle.  The reference issues one fused kernel per gate on
-//    800 streams and polls each with StreamQuery.
+//  * Ciphertexts are device-resident.  A task's output is a slot of an arena in HBM; only Mem::set/get (INPUT /
+//    OUTPUT / RAM / ROM cells) cross PCIe, in bulk (HIPArena::setMany / getMany: one transfer for all cells).  The
+//    reference copies both inputs host->device and the output device->host for every single gate (:217-222,238-241).
+//  * One BATCHING worker replaces hundreds of one-gate workers: HIPWorker::update() drains the whole ready frontier
+//    into ONE iyk_hip_gate_batch per GPU (a handful of kernel launches) and propagates the frontier when the streams
+//    go idle.  The reference issues one fused kernel per gate on 800 streams and polls each with StreamQuery.
+//  * Multi-GPU (cufhe::SetGPUNum, --num-gpu): every GPU holds a replica of the arena; a frontier's bootstrapped gates
+//    are dealt round-robin (2-rotation MUXes first), NOT / COPY / CONST are computed redundantly everywhere, and each
+//    GPU's outputs go to the other replicas device-to-device (iyk_hip_arena_sync_slots over xGMI) at the level
+//    boundary.  The reference round-robins its streams over the GPUs and bounces every ciphertext through the host.
 //  * Status codes: every C-ABI failure is mapped to die() = the reference's error::die.
 #pragma once
+#include <algorithm>
 #include <cstring>
 
 #include "../../include/iyokan_hip.h"
@@ -31,16 +38,19 @@ namespace iyk {
 namespace host {
 
 using TLWELvl0 = std::vector<uint32_t>;  // n+1 words, TFHEpp::TLWE<lvl0param> layout
+using TRLWELvl1 = std::vector<uint32_t>; // 2N words: a(X) then b(X), TFHEpp::TRLWE<lvl1param> layout
 
 inline void hipCheck(int rc, const char* what)
 {
     if (rc < 0) die(std::string(what) + ": " + iyk_hip_last_error());
 }
 
-// cufhe::SetGPUNum + cufhe::Initialize(ek): bk = ek.getbk<lvl01param>(), ksk = ek.getiksk<lvl10param>()
-inline void initializeHIP(const iyk_params& p, const uint32_t* bk_torus, const uint32_t* ksk, int device = 0)
+// cufhe::SetGPUNum(numGPU) + cufhe::Initialize(ek): bk = ek.getbk<lvl01param>(), ksk = ek.getiksk<lvl10param>().
+// device_ids: HIP ordinals of the numGPU devices (nullptr = 0 .. numGPU-1).
+inline void initializeHIP(const iyk_params& p, const uint32_t* bk_torus, const uint32_t* ksk, int numGPU = 1,
+                          const int* device_ids = nullptr)
 {
-    hipCheck(iyk_hip_init(1, &device, &p, bk_torus, ksk), "iyk_hip_init");
+    hipCheck(iyk_hip_init(numGPU, device_ids, &p, bk_torus, ksk), "iyk_hip_init");
 }
 inline void cleanupHIP() { hipCheck(iyk_hip_cleanup(), "iyk_hip_cleanup"); }
 
@@ -50,18 +60,20 @@ inline TLWELvl0 trivialTLWELvl0(const iyk_params& p, int bit)  // setTLWELvl0Tri
     c[p.n] = bit ? p.mu : 0u - p.mu;
     return c;
 }
-inline int decryptTLWELvl0(const iyk_params& p, const TLWELvl0& c, const uint32_t* s0)  // sign of the phase
+inline int decryptTLWELvl0(const iyk_params& p, const uint32_t* c, const uint32_t* s0)  // sign of the phase
 {
     uint32_t ph = c[p.n];
     for (uint32_t i = 0; i < p.n; ++i) ph -= c[i] * s0[i];
     return (int32_t)ph > 0;
 }
+inline int decryptTLWELvl0(const iyk_params& p, const TLWELvl0& c, const uint32_t* s0) { return decryptTLWELvl0(p, c.data(), s0); }
 
 class HIPStream {
     iyk_hip_stream* st_ = nullptr;
+    int gpu_ = 0;
 
 public:
-    explicit HIPStream(int gpu_index = 0) { hipCheck(iyk_hip_stream_create(gpu_index, &st_), "iyk_hip_stream_create"); }
+    explicit HIPStream(int gpu_index = 0) : gpu_(gpu_index) { hipCheck(iyk_hip_stream_create(gpu_index, &st_), "iyk_hip_stream_create"); }
     ~HIPStream()
     {
         if (st_) iyk_hip_stream_destroy(st_);
@@ -69,6 +81,7 @@ public:
     HIPStream(const HIPStream&) = delete;
     HIPStream& operator=(const HIPStream&) = delete;
     operator iyk_hip_stream*() const { return st_; }
+    int gpu() const { return gpu_; }
     bool query() const
     {
         int rc = iyk_hip_stream_query(st_);
@@ -78,69 +91,164 @@ public:
     void sync() const { hipCheck(iyk_hip_stream_sync(st_), "iyk_hip_stream_sync"); }
 };
 
-// Device-resident value store of one network: a growable arena of TLWE lvl0 slots.
+// Device-resident value store of one network: a growable arena of TLWE lvl0 slots, replicated on every GPU the
+// library was initialised with.  Host I/O is bulk: setMany / getMany move any list of slots in one transfer.
 class HIPArena {
     iyk_params p_{};
-    uint32_t* d_ = nullptr;
+    int ngpu_ = 1;
+    std::vector<uint32_t*> d_;  // one replica per GPU
     size_t cap_ = 0, used_ = 0;
-    HIPStream io_;  // stream for set/get/grow copies
+    std::vector<std::unique_ptr<HIPStream>> io_;  // per-GPU stream for set / get / grow copies
 
     void grow(size_t want)
     {
         size_t ncap = cap_ ? cap_ : 1024;
         while (ncap < want) ncap *= 2;
-        uint32_t* nd = nullptr;
-        hipCheck(iyk_hip_arena_alloc(0, ncap, &nd), "iyk_hip_arena_alloc");
-        if (d_) {
-            // device -> host -> device keeps the C ABI minimal; growth only happens while building
-            std::vector<uint32_t> tmp(used_ * (p_.n + 1));
-            if (used_) {
-                hipCheck(iyk_hip_arena_download(io_, d_, cap_, 0, used_, tmp.data()), "arena_download");
-                io_.sync();
-                hipCheck(iyk_hip_arena_upload(io_, nd, ncap, 0, used_, tmp.data()), "arena_upload");
-                io_.sync();
+        for (int g = 0; g < ngpu_; ++g) {
+            uint32_t* nd = nullptr;
+            hipCheck(iyk_hip_arena_alloc(g, ncap, &nd), "iyk_hip_arena_alloc");
+            if (d_[g]) {
+                if (used_) {  // device-to-device, no host bounce
+                    hipCheck(iyk_hip_arena_copy(*io_[g], nd, ncap, 0, d_[g], cap_, 0, used_), "iyk_hip_arena_copy");
+                    io_[g]->sync();
+                }
+                hipCheck(iyk_hip_arena_free(g, d_[g]), "iyk_hip_arena_free");
             }
-            hipCheck(iyk_hip_arena_free(0, d_), "iyk_hip_arena_free");
+            d_[g] = nd;
         }
-        d_ = nd;
         cap_ = ncap;
     }
 
 public:
-    HIPArena() { hipCheck(iyk_hip_get_params(&p_), "iyk_hip_get_params"); }
+    HIPArena()
+    {
+        hipCheck(iyk_hip_get_params(&p_), "iyk_hip_get_params");
+        ngpu_ = iyk_hip_num_gpus();
+        d_.assign(ngpu_, nullptr);
+        for (int g = 0; g < ngpu_; ++g) io_.emplace_back(new HIPStream(g));
+    }
     ~HIPArena()
     {
-        if (d_) iyk_hip_arena_free(0, d_);
+        for (int g = 0; g < ngpu_; ++g)
+            if (d_[g]) iyk_hip_arena_free(g, d_[g]);
     }
+    HIPArena(const HIPArena&) = delete;
+    HIPArena& operator=(const HIPArena&) = delete;
     const iyk_params& params() const { return p_; }
-    uint32_t* device() const { return d_; }
+    int numGPUs() const { return ngpu_; }
+    uint32_t* device(int gpu = 0) const { return d_[gpu]; }
     uint64_t slots() const { return cap_; }
+    size_t used() const { return used_; }
     Slot alloc()
     {
         if (used_ + 1 > cap_) grow(used_ + 1);
         return (Slot)used_++;
     }
+    // rows: slots.size() ciphertexts of n+1 words each, row j -> slot slots[j], on every replica
+    void setMany(const std::vector<Slot>& slots, const uint32_t* rows)
+    {
+        if (slots.empty()) return;
+        for (int g = 0; g < ngpu_; ++g)
+            hipCheck(iyk_hip_arena_upload_slots(*io_[g], d_[g], cap_, slots.size(), slots.data(), rows), "arena_upload_slots");
+        for (int g = 0; g < ngpu_; ++g) io_[g]->sync();
+    }
+    std::vector<uint32_t> getMany(const std::vector<Slot>& slots, int gpu = 0)
+    {
+        std::vector<uint32_t> rows(slots.size() * (size_t)(p_.n + 1));
+        if (slots.empty()) return rows;
+        hipCheck(iyk_hip_arena_download_slots(*io_[gpu], d_[gpu], cap_, slots.size(), slots.data(), rows.data()),
+                 "arena_download_slots");
+        io_[gpu]->sync();
+        return rows;
+    }
+    // trivial 0 / 1 into many slots without host traffic (TaskCUFHEGateDFF's initial value, :108-133)
+    void fillTrivial(const std::vector<Slot>& slots, int bit)
+    {
+        if (slots.empty()) return;
+        const std::vector<int32_t> ops(slots.size(), bit ? IYK_OP_CONSTONE : IYK_OP_CONSTZERO), none(slots.size(), -1);
+        for (int g = 0; g < ngpu_; ++g)
+            hipCheck(iyk_hip_gate_batch(*io_[g], d_[g], cap_, slots.size(), ops.data(), none.data(), none.data(), none.data(),
+                                        slots.data()), "fillTrivial");
+        for (int g = 0; g < ngpu_; ++g) io_[g]->sync();
+    }
     void set(Slot s, const TLWELvl0& v)
     {
         if (v.size() != p_.n + 1) die("HIPArena::set: wrong ciphertext size");
-        hipCheck(iyk_hip_arena_upload(io_, d_, cap_, (uint64_t)s, 1, v.data()), "arena_upload");
+        setMany({s}, v.data());
+    }
+    TLWELvl0 get(Slot s) { return getMany({s}); }
+    // whole-arena image (snapshot / resume)
+    std::vector<uint32_t> image(int gpu = 0)
+    {
+        std::vector<uint32_t> rows(used_ * (size_t)(p_.n + 1));
+        if (used_) {
+            hipCheck(iyk_hip_arena_download(*io_[gpu], d_[gpu], cap_, 0, used_, rows.data()), "arena_download");
+            io_[gpu]->sync();
+        }
+        return rows;
+    }
+    void restore(const std::vector<uint32_t>& rows)
+    {
+        if (rows.size() != used_ * (size_t)(p_.n + 1)) die("HIPArena::restore: image does not match this network");
+        for (int g = 0; g < ngpu_; ++g) {
+            hipCheck(iyk_hip_arena_upload(*io_[g], d_[g], cap_, 0, used_, rows.data()), "arena_upload");
+            io_[g]->sync();
+        }
+    }
+};
+
+// TRLWE lvl1 values of the CMUX memories (cufhe::cuFHETRLWElvl1): a device buffer on GPU 0, addressed by index.
+class HIPTRLWEStore {
+    iyk_params p_{};
+    uint32_t* d_ = nullptr;
+    size_t cap_ = 0, used_ = 0;
+    HIPStream io_{0};
+
+public:
+    explicit HIPTRLWEStore(size_t capacity) : cap_(capacity)
+    {
+        hipCheck(iyk_hip_get_params(&p_), "iyk_hip_get_params");
+        hipCheck(iyk_hip_trlwe_alloc(0, capacity, &d_), "iyk_hip_trlwe_alloc");
+    }
+    ~HIPTRLWEStore()
+    {
+        if (d_) iyk_hip_trlwe_free(0, d_);
+    }
+    HIPTRLWEStore(const HIPTRLWEStore&) = delete;
+    HIPTRLWEStore& operator=(const HIPTRLWEStore&) = delete;
+    int alloc()
+    {
+        if (used_ >= cap_) die("HIPTRLWEStore: capacity exhausted");
+        return (int)used_++;
+    }
+    uint32_t* device() const { return d_; }
+    uint64_t slots() const { return cap_; }
+    size_t words() const { return 2 * (size_t)p_.N; }
+    void set(int index, const TRLWELvl1& v)
+    {
+        if (v.size() != words()) die("HIPTRLWEStore::set: wrong TRLWE size");
+        hipCheck(iyk_hip_trlwe_upload(io_, d_, cap_, (uint64_t)index, 1, v.data()), "iyk_hip_trlwe_upload");
         io_.sync();
     }
-    TLWELvl0 get(Slot s)
+    TRLWELvl1 get(int index)
     {
-        TLWELvl0 v(p_.n + 1);
-        hipCheck(iyk_hip_arena_download(io_, d_, cap_, (uint64_t)s, 1, v.data()), "arena_download");
+        TRLWELvl1 v(words());
+        hipCheck(iyk_hip_trlwe_download(io_, d_, cap_, (uint64_t)index, 1, v.data()), "iyk_hip_trlwe_download");
         io_.sync();
         return v;
     }
 };
 
-// Worker-owned scratch: the stream and the batch being assembled (cf. CUFHEWorkerInfo's
-// stream + 10 scratch Ctxt; here gates append descriptors instead of copying ciphertexts).
+// Worker-owned scratch of ONE GPU: its stream and the batches being assembled (cf. CUFHEWorkerInfo's stream + 10
+// scratch Ctxt; here tasks append descriptors instead of copying ciphertexts).
 struct HIPWorkerInfo {
     std::shared_ptr<HIPStream> stream;
     HIPArena* arena = nullptr;
-    std::vector<int32_t> ops, in0, in1, in2, out;
+    int gpu = 0;
+    std::vector<int32_t> ops, in0, in1, in2, out;        // iyk_hip_gate_batch
+    std::vector<int32_t> seiTrlwe, seiOut;                // iyk_hip_sample_extract_keyswitch_batch
+    std::vector<int32_t> gbIn, gbTrlweOut;                // iyk_hip_bootstrap_trlwe_batch
+    HIPTRLWEStore* trlwe = nullptr;
     void push(int op, Slot a, Slot b, Slot c, Slot o)
     {
         ops.push_back(op);
@@ -149,13 +257,38 @@ struct HIPWorkerInfo {
         in2.push_back(c);
         out.push_back(o);
     }
+    void pushSEIAndKS(HIPTRLWEStore* st, int trlweIndex, Slot o)
+    {
+        trlwe = st;
+        seiTrlwe.push_back(trlweIndex);
+        seiOut.push_back(o);
+    }
+    void pushGateBootstrapping(HIPTRLWEStore* st, Slot in, int trlweIndex)
+    {
+        trlwe = st;
+        gbIn.push_back(in);
+        gbTrlweOut.push_back(trlweIndex);
+    }
+    bool empty() const { return ops.empty() && seiTrlwe.empty() && gbIn.empty(); }
     void flush()
     {
-        if (ops.empty()) return;
-        hipCheck(iyk_hip_gate_batch(*stream, arena->device(), arena->slots(), ops.size(), ops.data(), in0.data(), in1.data(),
-                                    in2.data(), out.data()),
-                 "iyk_hip_gate_batch");
+        uint32_t* d = arena->device(gpu);
+        if (!ops.empty())
+            hipCheck(iyk_hip_gate_batch(*stream, d, arena->slots(), ops.size(), ops.data(), in0.data(), in1.data(), in2.data(),
+                                        out.data()), "iyk_hip_gate_batch");
+        if (!seiTrlwe.empty())  // cufhe::SampleExtractAndKeySwitch, one launch sequence for all of them
+            hipCheck(iyk_hip_sample_extract_keyswitch_batch(*stream, trlwe->device(), trlwe->slots(), seiTrlwe.size(),
+                                                            seiTrlwe.data(), seiOut.data(), d, arena->slots()),
+                     "iyk_hip_sample_extract_keyswitch_batch");
+        if (!gbIn.empty()) {    // cufhe::GateBootstrappingTLWE2TRLWElvl01NTT(mem, in): rotation of the input as it is
+            const std::vector<int32_t> none(gbIn.size(), -1), one(gbIn.size(), 1), zero(gbIn.size(), 0);
+            const std::vector<uint32_t> off(gbIn.size(), 0u);
+            hipCheck(iyk_hip_bootstrap_trlwe_batch(*stream, d, arena->slots(), gbIn.size(), gbIn.data(), none.data(), one.data(),
+                                                   zero.data(), off.data(), trlwe->device(), trlwe->slots(), gbTrlweOut.data()),
+                     "iyk_hip_bootstrap_trlwe_batch");
+        }
         ops.clear(); in0.clear(); in1.clear(); in2.clear(); out.clear();
+        seiTrlwe.clear(); seiOut.clear(); gbIn.clear(); gbTrlweOut.clear();
     }
 };
 
@@ -168,6 +301,9 @@ protected:
 public:
     TaskHIPGate(GateKind k, size_t nin, HIPArena* arena) : Task<HIPWorkerInfo>(k, nin), arena_(arena) {}
     bool hasFinished() const override { return !started_on_ || started_on_->query(); }  // cufhe::StreamQuery
+    // blind rotations this task costs (frontier dealing) and whether every GPU replica computes it redundantly
+    virtual int rotations() const { return kind == GateKind::MUX ? 2 : (int)kind < (int)GateKind::MUX ? 1 : 0; }
+    virtual bool gpu0Only() const { return false; }
 
 protected:
     void startAsyncImpl(HIPWorkerInfo& wi) override
@@ -202,6 +338,10 @@ protected:
         if (getInputSize() == 1) wi.push(IYK_OP_COPY, inputSlots[0], -1, -1, slot);
     }
 };
+// The TLWE bridges between a TFHEpp (CPU) network and the GPU network are host <-> device copies of one value:
+// exactly an externally driven WIRE (host -> device: set) and a WIRE read back (device -> host: get).
+using TaskTFHEpp2HIP = TaskHIPGateWIRE;  // TaskTFHEpp2CUFHE :336-356
+using TaskHIP2TFHEpp = TaskHIPGateWIRE;  // TaskCUFHE2TFHEpp :314-334
 
 // DFF: always ready, always finished; the clock edge is a device-side copy done in two
 // batches by HIPNetworkRunner::tick (TaskCUFHEGateDFF :98-161).
@@ -211,12 +351,78 @@ class TaskHIPGateDFF : public TaskHIPGateMem {
 public:
     Slot shadow = -1;  // staging slot for the two-phase latch
     TaskHIPGateDFF(int initValue, HIPArena* arena) : TaskHIPGateMem(GateKind::DFF, 1, arena), initialValue_(initValue) {}
-    void setInitialValue() { arena_->set(slot, trivialTLWELvl0(arena_->params(), initialValue_)); }
+    int initialValue() const { return initialValue_; }
+    void setInitialValue() { arena_->fillTrivial({slot}, initialValue_); }
     bool areInputsReady() const override { return true; }
     bool hasFinished() const override { return true; }
+    int rotations() const override { return 0; }
 
 protected:
     void startAsyncImpl(HIPWorkerInfo&) override {}
+};
+
+// ---- CMUX-memory pieces that run on the GPU in the reference (the CMUX tree itself is TFHEpp CPU work) --------------
+// TRLWE produced on the host (CMUX tree result) -> TRLWE store; edge-less source like an INPUT wire.
+class TaskTFHEpp2HIPTRLWE : public TaskHIPGate {
+    HIPTRLWEStore* store_;
+
+public:
+    int trlweIndex;
+    TaskTFHEpp2HIPTRLWE(HIPTRLWEStore* store, HIPArena* arena)
+        : TaskHIPGate(GateKind::WIRE, 0, arena), store_(store), trlweIndex(store->alloc())
+    {
+    }
+    void set(const TRLWELvl1& v) { store_->set(trlweIndex, v); }
+    int rotations() const override { return 0; }
+    bool gpu0Only() const override { return true; }
+
+protected:
+    void startAsyncImpl(HIPWorkerInfo& wi) override { started_on_ = wi.stream; }
+};
+
+// cufhe::SampleExtractAndKeySwitch(output, input TRLWE, stream): TRLWE -> TLWE lvl0 in this task's slot.  Its one
+// dependency edge comes from the task that produces the TRLWE (a TaskTFHEpp2HIPTRLWE or a TaskHIPRAMGateBootstrapping).
+class TaskHIPRAMSEIAndKS : public TaskHIPGateMem {
+    HIPTRLWEStore* store_;
+    int trlweIndex_;
+
+public:
+    TaskHIPRAMSEIAndKS(HIPTRLWEStore* store, int trlweIndex, HIPArena* arena)
+        : TaskHIPGateMem(GateKind::RAM_SEI_KS, 1, arena), store_(store), trlweIndex_(trlweIndex)
+    {
+    }
+    int rotations() const override { return 0; }
+    bool gpu0Only() const override { return true; }  // the TRLWE store lives on GPU 0; the result is exchanged like a gate's
+
+protected:
+    void startAsyncImpl(HIPWorkerInfo& wi) override
+    {
+        started_on_ = wi.stream;
+        wi.pushSEIAndKS(store_, trlweIndex_, slot);
+    }
+};
+
+// cufhe::GateBootstrappingTLWE2TRLWElvl01NTT(mem, input, stream): blind rotation of the input TLWE, result left as a
+// TRLWE in the RAM cell `mem` of the store (the write path of the CMUX RAM).
+class TaskHIPRAMGateBootstrapping : public TaskHIPGate {
+    HIPTRLWEStore* store_;
+
+public:
+    int trlweIndex;  // = mem_
+    TaskHIPRAMGateBootstrapping(HIPTRLWEStore* store, int memIndex, HIPArena* arena)
+        : TaskHIPGate(GateKind::RAM_GB, 1, arena), store_(store), trlweIndex(memIndex)
+    {
+    }
+    TRLWELvl1 getTRLWE() const { return store_->get(trlweIndex); }  // device -> host for the CPU-side CMUXes
+    int rotations() const override { return 1; }
+    bool gpu0Only() const override { return true; }
+
+protected:
+    void startAsyncImpl(HIPWorkerInfo& wi) override
+    {
+        started_on_ = wi.stream;
+        wi.pushGateBootstrapping(store_, inputSlots.at(0), trlweIndex);
+    }
 };
 
 struct HIPFactory {
@@ -242,30 +448,65 @@ struct HIPFactory {
 using HIPNetworkBuilder = NetworkBuilder<HIPWorkerInfo, HIPFactory>;
 using HIPNetwork = TaskNetwork<HIPWorkerInfo>;
 
-// The batching worker.  update(): (1) drain the ready frontier into one batch and launch it,
-// (2) when the stream is idle, propagate every node of that frontier.
+// The batching worker.  update(): (1) drain the ready frontier, deal it to the GPUs, launch one batch per GPU and
+// enqueue the device-to-device exchange of every GPU's outputs; (2) when all streams are idle, propagate every
+// node of that frontier.
 class HIPWorker : public Worker<HIPWorkerInfo> {
-    HIPWorkerInfo wi_;
+    std::vector<HIPWorkerInfo> wi_;  // one per GPU
     std::vector<int> inflight_;
 
 public:
-    HIPWorker(ReadyQueue<HIPWorkerInfo>& q, size_t& numFinished, HIPArena* arena, int gpu_index = 0) : Worker(q, numFinished)
+    HIPWorker(ReadyQueue<HIPWorkerInfo>& q, size_t& numFinished, HIPArena* arena) : Worker(q, numFinished)
     {
-        wi_.stream = std::make_shared<HIPStream>(gpu_index);
-        wi_.arena = arena;
+        wi_.resize(arena->numGPUs());
+        for (int g = 0; g < arena->numGPUs(); ++g) {
+            wi_[g].stream = std::make_shared<HIPStream>(g);
+            wi_[g].arena = arena;
+            wi_[g].gpu = g;
+        }
     }
     void update() override
     {
         auto& net = readyQueue_.net();
+        const int G = (int)wi_.size();
         if (inflight_.empty() && !readyQueue_.empty()) {
-            while (!readyQueue_.empty()) {
-                const int id = readyQueue_.pop();
-                net.node(id).startAsync(wi_);
+            std::vector<int> frontier;
+            while (!readyQueue_.empty()) frontier.push_back(readyQueue_.pop());
+            // 2-rotation gates first so that the rotation counts of the GPUs differ by at most one gate
+            std::stable_sort(frontier.begin(), frontier.end(), [&](int a, int b) {
+                return static_cast<TaskHIPGate&>(net.node(a)).rotations() > static_cast<TaskHIPGate&>(net.node(b)).rotations();
+            });
+            std::vector<std::vector<int32_t>> produced(G);  // slots each GPU alone has written
+            int next = 0;
+            for (int id : frontier) {
+                auto& t = static_cast<TaskHIPGate&>(net.node(id));
+                if (t.gpu0Only()) {
+                    t.startAsync(wi_[0]);
+                    if (t.kind == GateKind::RAM_SEI_KS) produced[0].push_back(t.slot);
+                }
+                else if (t.rotations() > 0) {
+                    t.startAsync(wi_[next]);
+                    produced[next].push_back(t.slot);
+                    next = (next + 1) % G;
+                }
+                else {
+                    for (int g = G - 1; g >= 0; --g) t.startAsync(wi_[g]);  // cheap: every replica computes it (last: GPU 0's stream)
+                }
                 inflight_.push_back(id);
             }
-            wi_.flush();
+            for (int g = 0; g < G; ++g) wi_[g].flush();
+            for (int g = 0; g < G && G > 1; ++g)
+                for (int o = 0; o < G; ++o)
+                    if (o != g && !produced[g].empty())
+                        hipCheck(iyk_hip_arena_sync_slots(*wi_[g].stream, wi_[g].arena->device(g), wi_[g].arena->slots(), *wi_[o].stream,
+                                                          wi_[o].arena->device(o), wi_[o].arena->slots(), produced[g].size(),
+                                                          produced[g].data()),
+                                 "iyk_hip_arena_sync_slots");
         }
-        if (!inflight_.empty() && wi_.stream->query()) {
+        if (!inflight_.empty()) {
+            bool idle = true;
+            for (auto& w : wi_) idle = idle && w.stream->query();
+            if (!idle) return;
             for (int id : inflight_) {
                 net.node(id).onBeforePropagate();
                 net.propagate(id, readyQueue_);
@@ -277,40 +518,50 @@ public:
     bool isWorking() const override { return !inflight_.empty(); }
 
 protected:
-    HIPWorkerInfo& getWorkerInfo() override { return wi_; }
+    HIPWorkerInfo& getWorkerInfo() override { return wi_[0]; }
 };
 
+// numWorkers is accepted for signature parity with the reference and ignored: ONE batching worker drives every GPU
 inline void processAllGates(HIPNetwork& net, HIPFactory& f, int numWorkers = 1)
 {
-    processAllGatesWith<HIPWorkerInfo, HIPWorker>(net, numWorkers, &f.arena, 0);
+    (void)numWorkers;
+    processAllGatesWith<HIPWorkerInfo, HIPWorker>(net, 1, &f.arena);
 }
 
 // Per-clock driver: run() = one combinational evaluation, tick() = clock edge.
 class HIPNetworkRunner {
     HIPNetwork& net_;
     HIPFactory& f_;
-    HIPStream st_;
+    std::vector<std::unique_ptr<HIPStream>> st_;
+    std::vector<int32_t> latchIn_, latchShadow_, latchOut_;  // every DFF: D, shadow, Q
 
 public:
-    HIPNetworkRunner(HIPNetwork& net, HIPFactory& f) : net_(net), f_(f) {}
-    void run(int numWorkers = 1) { processAllGates(net_, f_, numWorkers); }
-    void tick()
+    HIPNetworkRunner(HIPNetwork& net, HIPFactory& f) : net_(net), f_(f)
     {
-        // two-phase latch on the device: D -> shadow for every DFF, then shadow -> Q
-        HIPWorkerInfo a, b;
-        a.arena = b.arena = &f_.arena;
+        for (int g = 0; g < f.arena.numGPUs(); ++g) st_.emplace_back(new HIPStream(g));
         net_.forEachNode([&](Task<HIPWorkerInfo>& t) {
             if (t.kind != GateKind::DFF) return;
             auto& d = static_cast<TaskHIPGateDFF&>(t);
-            a.push(IYK_OP_COPY, d.inputSlots.at(0), -1, -1, d.shadow);
-            b.push(IYK_OP_COPY, d.shadow, -1, -1, d.slot);
+            latchIn_.push_back(d.inputSlots.at(0));
+            latchShadow_.push_back(d.shadow);
+            latchOut_.push_back(d.slot);
         });
-        if (!a.ops.empty()) {
-            hipCheck(iyk_hip_gate_batch(st_, f_.arena.device(), f_.arena.slots(), a.ops.size(), a.ops.data(), a.in0.data(), a.in1.data(),
-                                        a.in2.data(), a.out.data()), "tick latch");
-            hipCheck(iyk_hip_gate_batch(st_, f_.arena.device(), f_.arena.slots(), b.ops.size(), b.ops.data(), b.in0.data(), b.in1.data(),
-                                        b.in2.data(), b.out.data()), "tick commit");
-            st_.sync();
+    }
+    void run(int numWorkers = 1) { processAllGates(net_, f_, numWorkers); }
+    void tick()
+    {
+        // two-phase latch on every replica: D -> shadow for every DFF, then shadow -> Q (shift registers latch old values)
+        if (!latchIn_.empty()) {
+            const size_t n = latchIn_.size();
+            const std::vector<int32_t> ops(n, IYK_OP_COPY), none(n, -1);
+            for (size_t g = 0; g < st_.size(); ++g) {
+                uint32_t* d = f_.arena.device((int)g);
+                hipCheck(iyk_hip_gate_batch(*st_[g], d, f_.arena.slots(), n, ops.data(), latchIn_.data(), none.data(), none.data(),
+                                            latchShadow_.data()), "tick latch");
+                hipCheck(iyk_hip_gate_batch(*st_[g], d, f_.arena.slots(), n, ops.data(), latchShadow_.data(), none.data(), none.data(),
+                                            latchOut_.data()), "tick commit");
+            }
+            for (auto& s : st_) s->sync();
         }
         net_.tick();
     }

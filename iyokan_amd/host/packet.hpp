@@ -1,0 +1,460 @@
+// packet.hpp — Iyokan's request / result packets on the host side of the HIP backend.
+//
+//   PlainPacket   named bit vectors `bits`, RAM / ROM images, optional cycle count
+//                 (/root/reference/src/packet.hpp:193-206)
+//   TFHEPacket    the same, encrypted: bits / ramInTLWE / romInTLWE as TLWE lvl0 vectors, ram / rom as TRLWE lvl1
+//                 vectors for the CMUX memories (/root/reference/src/packet.hpp:208-223)
+// and their two wire formats:
+//   TOML          `iyokan-packet toml2packet / packet2toml` (/root/reference/src/iyokan-packet.cpp:28-142,191-233)
+//   binary        cereal::PortableBinary{Output,Input}Archive, readFromArchive / writeToArchive
+//                 (/root/reference/src/packet.hpp:287-344)
+//
+// cereal is not available in this container, so the binary reader / writer below restate its PortableBinary
+// encoding for exactly the types these packets contain [recollection of cereal 1.3's published rules; the
+// reference tree holds no binary fixture to pin them against — tests round-trip self-written archives and
+// hand-assembled byte strings]:
+//   archive            1 byte: 1 = payload is little-endian (the writer's default), then the object
+//   struct             its serialize() arguments, in order, no framing
+//   bool, Bit          1 byte (enum class Bit : bool is saved as its underlying type)
+//   int32 / uint32 / uint64   raw little-endian bytes
+//   size tag           uint64
+//   std::string        size tag + bytes
+//   std::vector<T>     size tag + elements (one block of raw bytes when T is arithmetic)
+//   std::array<T, N>   N elements, no size tag (TLWE lvl0 = array<u32, n+1>; TRLWE lvl1 = array<array<u32, N>, 2>)
+//   std::unordered_map<K, V>   size tag + (key, value) pairs in iteration order
+//   std::optional<T>   1 byte `nullopt` flag (1 = empty), then T when present
+// The TLWE / TRLWE array lengths are not in the stream: they come from the parameter set (compile-time in
+// upstream, iyk_params here), which is why every reader takes the params.
+//
+// Key material: TFHEpp serialises SecretKey / EvalKey with its own serialize() members, whose layout this
+// repository cannot pin; upstream code loads them through TFHEpp and hands the raw arrays
+// (`ek.getbk<lvl01param>()`, `ek.getiksk<lvl10param>()`) to iyk_hip_init.  For this
+// repository's own tools the same container rules carry a plain `KeyArchive` (params + s0 + s1 + bk + ksk).
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <istream>
+#include <map>
+#include <optional>
+#include <ostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/iyokan_hip_params.h"
+#include "engine.hpp"
+#include "toml.hpp"
+
+namespace iyk {
+namespace host {
+
+using Bit = uint8_t;  // 0 / 1
+using TLWEVec = std::vector<uint32_t>;  // count * (n+1) words, row-major
+
+struct PlainPacket {
+    std::map<std::string, std::vector<Bit>> ram, rom, bits;
+    std::optional<int> numCycles;
+    bool operator==(const PlainPacket& o) const { return ram == o.ram && rom == o.rom && bits == o.bits && numCycles == o.numCycles; }
+};
+
+struct TFHEPacket {
+    std::map<std::string, std::vector<uint32_t>> ram, rom;              // TRLWE lvl1: count * 2N words
+    std::map<std::string, TLWEVec> ramInTLWE, romInTLWE, bits;         // TLWE lvl0: count * (n+1) words
+    std::optional<int> numCycles;
+    bool operator==(const TFHEPacket& o) const
+    {
+        return ram == o.ram && rom == o.rom && ramInTLWE == o.ramInTLWE && romInTLWE == o.romInTLWE && bits == o.bits &&
+               numCycles == o.numCycles;
+    }
+};
+
+struct KeyArchive {  // this repository's own key container (not TFHEpp's)
+    iyk_params params{};
+    std::vector<uint32_t> s0, s1, bk, ksk;  // s0 / s1 empty in an evaluation-key archive
+};
+
+// ---- TOML form --------------------------------------------------------------------------------------------
+// doToml2Packet (/root/reference/src/iyokan-packet.cpp:191-233): `size` bits, filled from `bytes` lsb first;
+// missing bytes read as 0, surplus bytes are ignored, only the low 8 bits of a byte count.
+inline std::vector<Bit> bitsFromBytes(const std::vector<toml::Value>& bytes, size_t size)
+{
+    std::vector<Bit> out(size, 0);
+    for (size_t i = 0; i < size; ++i) {
+        const size_t byte = i / 8;
+        if (byte >= bytes.size()) break;
+        out[i] = (Bit)(((uint64_t)bytes[byte].asInt() & 0xFF) >> (i % 8) & 1u);
+    }
+    return out;
+}
+inline std::vector<uint8_t> bytesFromBits(const std::vector<Bit>& bits)
+{
+    std::vector<uint8_t> out((bits.size() + 7) / 8, 0);
+    for (size_t i = 0; i < bits.size(); ++i) out[i / 8] |= (uint8_t)((bits[i] & 1u) << (i % 8));
+    return out;
+}
+
+inline PlainPacket plainPacketFromTOML(const std::string& text)
+{
+    const toml::Value root = toml::parse(text);
+    PlainPacket pkt;
+    if (const toml::Value* c = root.find("cycles")) {
+        if (c->asInt() >= 0) pkt.numCycles = (int)c->asInt();
+    }
+    auto load = [&](const char* kind, std::map<std::string, std::vector<Bit>>& dst) {
+        for (const toml::Value& e : root.tables(kind)) {
+            const std::string& name = e.at("name").asString();
+            const int64_t size = e.at("size").asInt();
+            if (size < 0) die(std::string("Invalid packet: negative size of ") + kind + " " + name);
+            if (!dst.emplace(name, bitsFromBytes(e.at("bytes").asArray(), (size_t)size)).second)
+                die(std::string("Invalid packet: duplicate ") + kind + " entry " + name);
+        }
+    };
+    load("ram", pkt.ram);
+    load("rom", pkt.rom);
+    load("bits", pkt.bits);
+    return pkt;
+}
+inline std::string readTextFile(const std::string& path)
+{
+    std::ifstream ifs(path, std::ios::binary);
+    if (!ifs) die("Can't open the file to read from; Maybe not found?: " + path);
+    std::ostringstream ss;
+    ss << ifs.rdbuf();
+    return ss.str();
+}
+inline PlainPacket plainPacketFromTOMLFile(const std::string& path) { return plainPacketFromTOML(readTextFile(path)); }
+
+// doPacket2Toml shape (/root/reference/src/iyokan-packet.cpp:96-142)
+inline std::string plainPacketToTOML(const PlainPacket& pkt)
+{
+    std::ostringstream os;
+    if (pkt.numCycles) os << "cycles = " << *pkt.numCycles << "\n";
+    auto dump = [&](const char* kind, const std::map<std::string, std::vector<Bit>>& src) {
+        for (auto& kv : src) {
+            os << "[[" << kind << "]]\nname = \"" << kv.first << "\"\nsize = " << kv.second.size() << "\nbytes = [";
+            const auto bytes = bytesFromBits(kv.second);
+            for (size_t i = 0; i < bytes.size(); ++i) os << (i ? ", " : "") << (int)bytes[i];
+            os << "]\n";
+        }
+    };
+    dump("rom", pkt.rom);
+    dump("ram", pkt.ram);
+    dump("bits", pkt.bits);
+    return os.str();
+}
+
+// toml2packet(got) == toml2packet(expected) of the reference's test driver (/root/reference/test.rb:34-68):
+// the same named entries with the same (size, zero-padded bytes), and the same cycle count
+inline bool samePacketContent(const PlainPacket& a, const PlainPacket& b, std::string* why = nullptr)
+{
+    auto cmp = [&](const char* kind, const std::map<std::string, std::vector<Bit>>& x, const std::map<std::string, std::vector<Bit>>& y) {
+        for (auto& kv : x) {
+            auto it = y.find(kv.first);
+            if (it == y.end() || it->second != kv.second) {
+                if (why) *why += std::string(kind) + "." + kv.first + " differs; ";
+                return false;
+            }
+        }
+        if (x.size() != y.size()) {
+            if (why) *why += std::string(kind) + ": different entry sets; ";
+            return false;
+        }
+        return true;
+    };
+    bool ok = cmp("bits", a.bits, b.bits);
+    ok = cmp("ram", a.ram, b.ram) && ok;
+    ok = cmp("rom", a.rom, b.rom) && ok;
+    if (a.numCycles.value_or(-1) != b.numCycles.value_or(-1)) {
+        if (why) *why += "cycles differ; ";
+        ok = false;
+    }
+    return ok;
+}
+
+// ---- cereal PortableBinary form ---------------------------------------------------------------------------
+namespace cereal_pb {
+
+class Writer {
+    std::ostream& os_;
+
+public:
+    explicit Writer(std::ostream& os) : os_(os) { u8(1); }  // payload is little-endian
+    void raw(const void* p, size_t n) { os_.write(static_cast<const char*>(p), (std::streamsize)n); }
+    void u8(uint8_t v) { raw(&v, 1); }
+    void u32(uint32_t v) { raw(&v, 4); }  // host is little-endian (x86-64): no swap
+    void i32(int32_t v) { raw(&v, 4); }
+    void u64(uint64_t v) { raw(&v, 8); }
+    void f64(double v) { raw(&v, 8); }
+    void str(const std::string& s)
+    {
+        u64(s.size());
+        raw(s.data(), s.size());
+    }
+    void optInt(const std::optional<int>& o)
+    {
+        u8(o ? 0 : 1);  // "nullopt" flag
+        if (o) i32(*o);
+    }
+    void bitMap(const std::map<std::string, std::vector<Bit>>& m)
+    {
+        u64(m.size());
+        for (auto& kv : m) {
+            str(kv.first);
+            u64(kv.second.size());
+            for (Bit b : kv.second) u8(b ? 1 : 0);
+        }
+    }
+    // vector of fixed-size word arrays (TLWE / TRLWE): element count, then the raw words
+    void arrayMap(const std::map<std::string, std::vector<uint32_t>>& m, size_t words)
+    {
+        u64(m.size());
+        for (auto& kv : m) {
+            if (kv.second.size() % words) die("packet entry " + kv.first + " is not a whole number of ciphertexts");
+            str(kv.first);
+            u64(kv.second.size() / words);
+            raw(kv.second.data(), kv.second.size() * sizeof(uint32_t));
+        }
+    }
+    void u32vec(const std::vector<uint32_t>& v)
+    {
+        u64(v.size());
+        raw(v.data(), v.size() * sizeof(uint32_t));
+    }
+};
+
+class Reader {
+    std::istream& is_;
+    bool swap_ = false;  // archive written big-endian
+
+    [[noreturn]] void bad(const char* what) { die(std::string("Invalid archive: ") + what); }
+
+public:
+    explicit Reader(std::istream& is) : is_(is)
+    {
+        const uint8_t little = u8();
+        if (little > 1) bad("bad endianness flag");
+        swap_ = little == 0;
+    }
+    void raw(void* p, size_t n)
+    {
+        is_.read(static_cast<char*>(p), (std::streamsize)n);
+        if ((size_t)is_.gcount() != n) bad("truncated");
+    }
+    template <class T>
+    T scalar()
+    {
+        unsigned char b[sizeof(T)];
+        raw(b, sizeof(T));
+        if (swap_)
+            for (size_t i = 0; i < sizeof(T) / 2; ++i) std::swap(b[i], b[sizeof(T) - 1 - i]);
+        T v;
+        std::memcpy(&v, b, sizeof(T));
+        return v;
+    }
+    uint8_t u8()
+    {
+        uint8_t v;
+        raw(&v, 1);
+        return v;
+    }
+    uint32_t u32() { return scalar<uint32_t>(); }
+    int32_t i32() { return scalar<int32_t>(); }
+    uint64_t u64() { return scalar<uint64_t>(); }
+    double f64() { return scalar<double>(); }
+    uint64_t size(uint64_t limit)
+    {
+        const uint64_t n = u64();
+        if (n > limit) bad("implausible size tag");
+        return n;
+    }
+    std::string str()
+    {
+        std::string s((size_t)size(1u << 20), '\0');
+        if (!s.empty()) raw(&s[0], s.size());
+        return s;
+    }
+    std::optional<int> optInt()
+    {
+        const uint8_t nullopt = u8();
+        if (nullopt > 1) bad("bad optional flag");
+        if (nullopt) return std::nullopt;
+        return (int)i32();
+    }
+    void words(std::vector<uint32_t>& v, size_t n)
+    {
+        v.resize(n);
+        if (n) raw(v.data(), n * sizeof(uint32_t));
+        if (swap_)
+            for (auto& w : v) w = __builtin_bswap32(w);
+    }
+    void bitMap(std::map<std::string, std::vector<Bit>>& m)
+    {
+        const uint64_t n = size(1u << 20);
+        for (uint64_t e = 0; e < n; ++e) {
+            std::string key = str();
+            std::vector<Bit> v((size_t)size(1ull << 32));
+            if (!v.empty()) raw(v.data(), v.size());
+            for (Bit& b : v)
+                if (b > 1) bad("Bit value out of range");
+            if (!m.emplace(std::move(key), std::move(v)).second) bad("duplicate key");
+        }
+    }
+    void arrayMap(std::map<std::string, std::vector<uint32_t>>& m, size_t wordsPer)
+    {
+        const uint64_t n = size(1u << 20);
+        for (uint64_t e = 0; e < n; ++e) {
+            std::string key = str();
+            const uint64_t count = size((1ull << 34) / wordsPer);
+            std::vector<uint32_t> v;
+            words(v, (size_t)count * wordsPer);
+            if (!m.emplace(std::move(key), std::move(v)).second) bad("duplicate key");
+        }
+    }
+    void u32vec(std::vector<uint32_t>& v, uint64_t limit) { words(v, (size_t)size(limit)); }
+    void expectEnd()
+    {
+        char c;
+        is_.read(&c, 1);
+        if (is_.gcount() != 0) bad("trailing bytes");
+    }
+};
+
+}  // namespace cereal_pb
+
+// writeToArchive / readFromArchive for the packet types (/root/reference/src/packet.hpp:287-344)
+inline void writeToArchive(std::ostream& os, const PlainPacket& p)
+{
+    cereal_pb::Writer w(os);
+    w.bitMap(p.ram);  // serialize(): ar(ram, rom, bits, numCycles)
+    w.bitMap(p.rom);
+    w.bitMap(p.bits);
+    w.optInt(p.numCycles);
+}
+inline void readFromArchive(PlainPacket& p, std::istream& is)
+{
+    cereal_pb::Reader r(is);
+    p = PlainPacket{};
+    r.bitMap(p.ram);
+    r.bitMap(p.rom);
+    r.bitMap(p.bits);
+    p.numCycles = r.optInt();
+    r.expectEnd();
+}
+inline void writeToArchive(std::ostream& os, const TFHEPacket& p, const iyk_params& prm)
+{
+    cereal_pb::Writer w(os);
+    const size_t trlwe = (size_t)(prm.k + 1) * prm.N, tlwe = (size_t)prm.n + 1;
+    w.arrayMap(p.ram, trlwe);  // serialize(): ar(ram, ramInTLWE, rom, romInTLWE, bits, numCycles)
+    w.arrayMap(p.ramInTLWE, tlwe);
+    w.arrayMap(p.rom, trlwe);
+    w.arrayMap(p.romInTLWE, tlwe);
+    w.arrayMap(p.bits, tlwe);
+    w.optInt(p.numCycles);
+}
+inline void readFromArchive(TFHEPacket& p, std::istream& is, const iyk_params& prm)
+{
+    cereal_pb::Reader r(is);
+    const size_t trlwe = (size_t)(prm.k + 1) * prm.N, tlwe = (size_t)prm.n + 1;
+    p = TFHEPacket{};
+    r.arrayMap(p.ram, trlwe);
+    r.arrayMap(p.ramInTLWE, tlwe);
+    r.arrayMap(p.rom, trlwe);
+    r.arrayMap(p.romInTLWE, tlwe);
+    r.arrayMap(p.bits, tlwe);
+    p.numCycles = r.optInt();
+    r.expectEnd();
+}
+inline void writeToArchive(std::ostream& os, const KeyArchive& k)
+{
+    cereal_pb::Writer w(os);
+    const iyk_params& p = k.params;
+    for (uint32_t v : {p.n, p.N, p.k, p.l, p.Bgbit, p.t, p.basebit, p.mu}) w.u32(v);
+    w.f64(p.alpha0);
+    w.f64(p.alpha1);
+    w.u32vec(k.s0);
+    w.u32vec(k.s1);
+    w.u32vec(k.bk);
+    w.u32vec(k.ksk);
+}
+inline void readFromArchive(KeyArchive& k, std::istream& is)
+{
+    cereal_pb::Reader r(is);
+    iyk_params& p = k.params;
+    for (uint32_t* v : {&p.n, &p.N, &p.k, &p.l, &p.Bgbit, &p.t, &p.basebit, &p.mu}) *v = r.u32();
+    p.alpha0 = r.f64();
+    p.alpha1 = r.f64();
+    if (p.n == 0 || p.n > 4096 || p.N == 0 || p.N > 65536 || p.k == 0 || p.k > 4 || p.l == 0 || p.l > 16 || p.t == 0 ||
+        p.t > 32 || p.basebit == 0 || p.basebit > 8)
+        die("Invalid archive: implausible parameter set");
+    r.u32vec(k.s0, p.n);
+    r.u32vec(k.s1, (uint64_t)p.k * p.N);
+    r.u32vec(k.bk, iyk_bk_words(&p));
+    r.u32vec(k.ksk, iyk_ksk_words(&p));
+    if ((!k.s0.empty() && k.s0.size() != p.n) || (!k.bk.empty() && k.bk.size() != iyk_bk_words(&p)) ||
+        (!k.ksk.empty() && k.ksk.size() != iyk_ksk_words(&p)))
+        die("Invalid archive: key sizes do not match the parameter set");
+    r.expectEnd();
+}
+
+template <class T, class... A>
+void writeToArchiveFile(const std::string& path, const T& src, const A&... a)
+{
+    std::ofstream ofs(path, std::ios::binary);
+    if (!ofs) die("Unable to write into archive: " + path);
+    writeToArchive(ofs, src, a...);
+}
+template <class T, class... A>
+T readFromArchiveFile(const std::string& path, const A&... a)
+{
+    std::ifstream ifs(path, std::ios::binary);
+    if (!ifs) die("Can't open the file to read from; Maybe not found?: " + path);
+    T ret;
+    readFromArchive(ret, ifs, a...);
+    return ret;
+}
+
+// ---- encrypt / decrypt of packets (PlainPacket::encrypt / TFHEPacket::decrypt, /root/reference/src/packet.hpp:225-285),
+// on the TLWE side the GPU path consumes; needs libiyokan_client.so (keygen / enc / dec stand-in for TFHEpp) ------
+extern "C" {
+int iyk_client_encrypt_bits(const iyk_params*, const uint32_t*, uint64_t, int, const uint8_t*, uint64_t, uint32_t*);
+int iyk_client_decrypt_bits(const iyk_params*, const uint32_t*, const uint32_t*, uint64_t, uint8_t*);
+}
+
+inline TLWEVec encryptBits(const iyk_params& p, const std::vector<uint32_t>& s0, const std::vector<Bit>& src, uint64_t seed = 0,
+                           int deterministic = 0)
+{
+    TLWEVec out(src.size() * ((size_t)p.n + 1));
+    if (!src.empty()) iyk_client_encrypt_bits(&p, s0.data(), seed, deterministic, src.data(), src.size(), out.data());
+    return out;
+}
+inline std::vector<Bit> decryptBits(const iyk_params& p, const std::vector<uint32_t>& s0, const TLWEVec& src)
+{
+    std::vector<Bit> out(src.size() / ((size_t)p.n + 1));
+    if (!out.empty()) iyk_client_decrypt_bits(&p, s0.data(), src.data(), out.size(), out.data());
+    return out;
+}
+// TLWE side only: bits, ramInTLWE, romInTLWE (the TRLWE copies feed the CPU-side CMUX memories upstream)
+inline TFHEPacket encryptPacket(const iyk_params& p, const std::vector<uint32_t>& s0, const PlainPacket& plain, uint64_t seed = 0,
+                                int deterministic = 0)
+{
+    TFHEPacket t;
+    t.numCycles = plain.numCycles;
+    uint64_t k = 0;
+    for (auto& kv : plain.ram) t.ramInTLWE.emplace(kv.first, encryptBits(p, s0, kv.second, seed + (++k), deterministic));
+    for (auto& kv : plain.rom) t.romInTLWE.emplace(kv.first, encryptBits(p, s0, kv.second, seed + (++k), deterministic));
+    for (auto& kv : plain.bits) t.bits.emplace(kv.first, encryptBits(p, s0, kv.second, seed + (++k), deterministic));
+    return t;
+}
+inline PlainPacket decryptPacket(const iyk_params& p, const std::vector<uint32_t>& s0, const TFHEPacket& t)
+{
+    PlainPacket plain;
+    plain.numCycles = t.numCycles;
+    for (auto& kv : t.ramInTLWE) plain.ram.emplace(kv.first, decryptBits(p, s0, kv.second));
+    for (auto& kv : t.romInTLWE) plain.rom.emplace(kv.first, decryptBits(p, s0, kv.second));
+    for (auto& kv : t.bits) plain.bits.emplace(kv.first, decryptBits(p, s0, kv.second));
+    return plain;
+}
+
+}  // namespace host
+}  // namespace iyk
