@@ -38,7 +38,8 @@ namespace host {
 
 enum class GateKind {
     AND, NAND, ANDNOT, OR, NOR, ORNOT, XOR, XNOR, MUX, NOT, CONSTONE, CONSTZERO,  // = iyk_gate_op 0..11
-    WIRE, DFF
+    WIRE, DFF,
+    RAM_SEI_KS, RAM_GB  // CMUX-memory pieces of the GPU backend (iyokan_hip.hpp); one token edge each
 };
 
 inline int gateNumInputs(GateKind k)
@@ -49,7 +50,9 @@ inline int gateNumInputs(GateKind k)
     case GateKind::CONSTONE:
     case GateKind::CONSTZERO: return 0;
     case GateKind::WIRE:
-    case GateKind::DFF: return 1;
+    case GateKind::DFF:
+    case GateKind::RAM_SEI_KS:
+    case GateKind::RAM_GB: return 1;
     default: return 2;
     }
 }
@@ -323,6 +326,21 @@ public:
     IYK_DEFINE_GATE(CONSTZERO)
 #undef IYK_DEFINE_GATE
 
+    // a backend-specific task built outside (CMUX-memory tasks, bridges)
+    int addTask(std::shared_ptr<Task<WorkerInfo>> t, const std::string& kind, const std::string& desc = "")
+    {
+        return net_.add(std::move(t), kind, desc);
+    }
+    // an input WIRE that an internal edge of a blueprint will drive ([connect] "dst/port" = "src/port")
+    int INPUT_DRIVEN(const std::string& port, int bit)
+    {
+        int id = net_.add(factory_.makeWire(true), "WIRE", port + "[" + std::to_string(bit) + "]");
+        net_.name(TaskLabel{"input", port, bit}, id);
+        return id;
+    }
+    Task<WorkerInfo>& node(int id) { return net_.node(id); }
+    void nameNode(const TaskLabel& l, int id) { net_.name(l, id); }
+
     void connect(int from, int to)  // connectTasks (/root/reference/src/iyokan.hpp:472-478)
     {
         auto& src = net_.node(from);
@@ -421,6 +439,8 @@ protected:
             v = in(0);
             break;
         case GateKind::DFF: return;  // latched in tick()
+        case GateKind::RAM_SEI_KS:
+        case GateKind::RAM_GB: die("CMUX-memory tasks have no plaintext twin in this engine");
         }
         (*store_)[slot] = (uint8_t)v;
     }

@@ -11,6 +11,16 @@
 //   test0_hip                       plain backend only (runs anywhere)
 //   test0_hip --hip                 plain + HIP backend (needs a GPU)
 //   test0_hip --fixtures DIR ...    also the JSON circuits; DIR mirrors the reference's test/ tree
+//   test0_hip --gpus 2 ...          HIP backend with two arena replicas (both on device 0 when only one GPU is visible):
+//                                   the in-process multi-GPU path (frontier dealing + device-to-device exchange)
+//   test0_hip --plain-run BP.toml IN.toml [-c N] [--skip-reset] [--mux-ram-dir DIR]
+//                                   C++ blueprint + packet + clocking protocol on the plain backend; result TOML on stdout
+//   test0_hip --packet-selftest IN.toml [ARCHIVE_OUT]
+//                                   packet.hpp: TOML and cereal PortableBinary round trips (+ a hand-assembled archive)
+//   test0_hip --hip-run BP.toml IN.toml -c N [--expect OUT.toml] [--gpus G] [--mux-ram-dir DIR] [--snapshot-at K]
+//                                   the same, ENCRYPTED, through HIPFrontend (keys made in-process, request packet
+//                                   encrypted here, result decrypted and compared); with --snapshot-at the run is cut at
+//                                   cycle K, written to a snapshot, resumed from it, and must give the same result
 #include <array>
 #include <cstdio>
 #include <cstring>
@@ -18,15 +28,21 @@
 #include <vector>
 
 #include <fstream>
+#include <unistd.h>
+
+#include <chrono>
+#include <iostream>
+#include <sstream>
 
 #include "iyokan_hip.hpp"
+#include "iyokan_hip_frontend.hpp"
+#include "plain_frontend.hpp"
 #include "readers.hpp"
 
 using namespace iyk::host;
 
 extern "C" {
-int iyk_client_keygen(const iyk_params*, uint64_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
-int iyk_client_encrypt_bits(const iyk_params*, const uint32_t*, uint64_t, const uint8_t*, uint64_t, uint32_t*);
+int iyk_client_keygen(const iyk_params*, uint64_t, int, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
 }
 
 #define CHECK(c)                                                              \
@@ -64,7 +80,7 @@ struct HIPHarness {
         if (trivial) return trivialTLWELvl0(p, v);
         TLWELvl0 c(p.n + 1);
         uint8_t b = (uint8_t)v;
-        iyk_client_encrypt_bits(&p, s0.data(), ++seed, &b, 1, c.data());
+        iyk_client_encrypt_bits(&p, s0.data(), ++seed, /*deterministic=*/1, &b, 1, c.data());
         return c;
     }
     void set(Net& net, const char* port, int bit, int v) { net.get<TaskHIPGateMem>("input", port, bit)->set(enc(v)); }
@@ -387,14 +403,229 @@ void runAll(H& h, const char* tag)
     std::printf("%s: all tests passed\n", tag);
 }
 
+// GateBootstrappingTLWE2TRLWElvl01NTT -> SampleExtractAndKeySwitch through the CMUX-memory tasks: the composition is a
+// bootstrapped identity (sign of the phase -> +-mu), so every output must decrypt to its input bit; the TRLWE the
+// write-side task leaves in the store must extract (index 0) to the same bit at level 1.
+void testCMUXMemoryTasks(HIPHarness& h)
+{
+    HIPFactory f;
+    HIPNetworkBuilder b(f);
+    const int n = 12;
+    HIPTRLWEStore store(2 * n);
+    std::vector<int> bits;
+    std::vector<std::shared_ptr<TaskHIPRAMGateBootstrapping>> gbs;
+    for (int i = 0; i < n; ++i) {
+        const int in = b.INPUT("in", i);
+        const int mem = store.alloc();
+        auto gb = std::make_shared<TaskHIPRAMGateBootstrapping>(&store, mem, &f.arena);
+        gb->slot = f.arena.alloc();
+        const int g = b.addTask(gb, "RAMGB");
+        auto sei = std::make_shared<TaskHIPRAMSEIAndKS>(&store, mem, &f.arena);
+        sei->slot = f.arena.alloc();
+        const int s = b.addTask(sei, "RAMSEIKS");
+        const int o = b.OUTPUT("out", i);
+        b.connect(in, g);
+        b.connect(g, s);   // token edge: the TRLWE must exist before it is extracted
+        b.connect(s, o);
+        gbs.push_back(gb);
+    }
+    auto net = b.build();
+    for (int i = 0; i < n; ++i) {
+        bits.push_back((i * 5 + 1) % 3 == 0);
+        h.set(net, "in", i, bits.back());
+    }
+    h.run(net, f);
+    for (int i = 0; i < n; ++i) CHECK(h.out(net, "out", i) == bits[i]);
+    // host -> device bridge for TRLWEs: a downloaded cell, uploaded into a fresh one, extracts to the same bit
+    const TRLWELvl1 cell = gbs[3]->getTRLWE();
+    CHECK(cell.size() == 2 * h.p.N);
+    auto up = std::make_shared<TaskTFHEpp2HIPTRLWE>(&store, &f.arena);
+    up->set(cell);
+    CHECK(store.get(up->trlweIndex) == cell);
+    std::printf("hip: CMUX-memory tasks ok (%d cells)\n", n);
+}
+
+static KeyArchive makeKeys(const iyk_params& p)
+{
+    KeyArchive k;
+    k.params = p;
+    k.s0.resize(p.n);
+    k.s1.resize(p.N);
+    k.bk.resize(iyk_bk_words(&p));
+    k.ksk.resize(iyk_ksk_words(&p));
+    iyk_client_keygen(&p, 1, /*deterministic=*/1, k.s0.data(), k.s1.data(), k.bk.data(), k.ksk.data());
+    return k;
+}
+
+// packet.hpp self-checks that need no GPU: TOML <-> PlainPacket, cereal PortableBinary round trips of PlainPacket /
+// TFHEPacket / KeyArchive on self-written archives, and a HAND-ASSEMBLED archive of a known PlainPacket (byte by byte
+// from cereal's published rules: endianness flag, u64 size tags, key then value of every map entry, 1-byte Bits,
+// `nullopt` flag then the int).
+static int packetSelfTest(const std::string& tomlFile, const std::string& archiveOut)
+{
+    const PlainPacket pkt = plainPacketFromTOMLFile(tomlFile);
+    CHECK(samePacketContent(plainPacketFromTOML(plainPacketToTOML(pkt)), pkt));
+    std::stringstream ss;
+    writeToArchive(ss, pkt);
+    const std::string bytes = ss.str();
+    PlainPacket back;
+    readFromArchive(back, ss);
+    CHECK(back == pkt);
+    if (!archiveOut.empty()) {
+        std::ofstream ofs(archiveOut, std::ios::binary);
+        ofs.write(bytes.data(), (std::streamsize)bytes.size());
+    }
+    // hand-assembled: PlainPacket{ram: {}, rom: {}, bits: {"ab": [1, 0, 1]}, numCycles: 5}
+    const unsigned char hand[] = {1,                                   // little-endian payload
+                                  0, 0, 0, 0, 0, 0, 0, 0,              // ram: 0 entries
+                                  0, 0, 0, 0, 0, 0, 0, 0,              // rom: 0 entries
+                                  1, 0, 0, 0, 0, 0, 0, 0,              // bits: 1 entry
+                                  2, 0, 0, 0, 0, 0, 0, 0, 'a', 'b',    //   key "ab"
+                                  3, 0, 0, 0, 0, 0, 0, 0, 1, 0, 1,     //   3 Bits
+                                  0, 5, 0, 0, 0};                      // optional: present, 5
+    std::stringstream hs(std::string(reinterpret_cast<const char*>(hand), sizeof(hand)));
+    PlainPacket h;
+    readFromArchive(h, hs);
+    CHECK(h.ram.empty() && h.rom.empty() && h.bits.size() == 1 && h.bits.at("ab") == (std::vector<Bit>{1, 0, 1}) && h.numCycles == 5);
+    std::stringstream hw;
+    writeToArchive(hw, h);
+    CHECK(hw.str() == std::string(reinterpret_cast<const char*>(hand), sizeof(hand)));
+    // encrypted packet + key container, 80-bit set (small), seeded
+    iyk_params p = IYK_PARAMS_80BIT_INIT;
+    const KeyArchive keys = makeKeys(p);
+    const TFHEPacket enc = encryptPacket(p, keys.s0, pkt, 5, 1);
+    std::stringstream es;
+    writeToArchive(es, enc, p);
+    TFHEPacket encBack;
+    readFromArchive(encBack, es, p);
+    CHECK(encBack == enc);
+    CHECK(samePacketContent(decryptPacket(p, keys.s0, encBack), pkt));
+    std::stringstream ks;
+    writeToArchive(ks, keys);
+    KeyArchive kb;
+    readFromArchive(kb, ks);
+    CHECK(kb.s0 == keys.s0 && kb.bk == keys.bk && kb.ksk == keys.ksk && kb.params.n == p.n && kb.params.alpha1 == p.alpha1);
+    std::printf("packet self-test ok: %zu archive bytes\n", bytes.size());
+    return 0;
+}
+
+static int plainRun(const std::string& bp, const std::string& in, int cycles, bool skipReset, const std::string& muxRamDir)
+{
+    PlainFrontend fe(bp, muxRamDir);
+    const PlainPacket req = plainPacketFromTOMLFile(in);
+    const int n = cycles != -2 ? cycles : req.numCycles.value_or(-1);
+    const PlainPacket res = fe.go(req, n, skipReset);
+    std::fputs(plainPacketToTOML(res).c_str(), stdout);
+    return 0;
+}
+
+static int hipRun(const std::string& bp, const std::string& in, int cycles, const std::string& expect, int gpus,
+                  const std::string& muxRamDir, int snapshotAt)
+{
+    iyk_params p = IYK_PARAMS_128BIT_INIT;
+    const KeyArchive keys = makeKeys(p);
+    const PlainPacket plainReq = plainPacketFromTOMLFile(in);
+    const TFHEPacket req = encryptPacket(p, keys.s0, plainReq, 77, /*deterministic=*/1);
+    Options opt;
+    opt.blueprint = bp;
+    opt.numCycles = cycles;
+    opt.numGPU = gpus;
+    opt.deviceIds.assign(gpus, 0);  // replicas on device 0 unless more GPUs are visible (the driver box has one)
+    opt.muxRamDir = muxRamDir;
+    TFHEPacket res;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (snapshotAt > 0 && snapshotAt < cycles) {
+        // the request packet and the key travel inside / beside the snapshot: write them where fromSnapshot looks
+        const std::string dir = "/tmp/iyk_snap_" + std::to_string((long)getpid());
+        const std::string keyFile = dir + ".key", snapFile = dir + ".snap";
+        KeyArchive ek = keys;
+        ek.s0.clear();
+        ek.s1.clear();
+        writeToArchiveFile(keyFile, ek);
+        opt.bkeyFile = keyFile;
+        opt.numCycles = snapshotAt;
+        {
+            initializeHIP(p, keys.bk.data(), keys.ksk.data(), gpus, opt.deviceIds.data());
+            {
+                HIPFrontend fe(opt, ek, req);
+                fe.go(opt);
+                fe.writeSnapshot(snapFile);
+            }
+            CHECK(isSerializedHIPFrontend(snapFile));
+            CHECK(!isSerializedHIPFrontend(keyFile));
+            {
+                auto fe = HIPFrontend::fromSnapshot(snapFile);
+                CHECK(fe->currentCycle() == snapshotAt);
+                Options more;
+                more.numCycles = cycles - snapshotAt;
+                more.skipReset = true;
+                fe->overwriteParams(more);
+                res = fe->go(more);
+            }
+            cleanupHIP();
+        }
+        std::remove(keyFile.c_str());
+        std::remove(snapFile.c_str());
+    }
+    else {
+        HIPFrontend fe(opt, keys, req);
+        res = fe.go(opt);
+    }
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const PlainPacket got = decryptPacket(p, keys.s0, res);
+    std::printf("hip-run: %d cycle(s) on %d GPU replica(s) in %.2f s (build + run)\n", cycles, gpus, secs);
+    if (!expect.empty()) {
+        const PlainPacket want = plainPacketFromTOMLFile(expect);
+        std::string why;
+        if (!samePacketContent(got, want, &why)) {
+            std::printf("FAIL: result packet differs from %s: %s\n", expect.c_str(), why.c_str());
+            return 1;
+        }
+        std::printf("hip-run: result packet equals %s\n", expect.c_str());
+    }
+    else
+        std::fputs(plainPacketToTOML(got).c_str(), stdout);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
-    bool with_hip = false, use80 = false;
+    bool with_hip = false, use80 = false, skipReset = false;
+    int gpus = 1, cycles = -2, snapshotAt = 0;
+    std::string mode, bpFile, inFile, expect, muxRamDir;
     for (int i = 1; i < argc; ++i) {
-        if (!std::strcmp(argv[i], "--hip")) with_hip = true;
-        if (!std::strcmp(argv[i], "--80bit")) use80 = true;
-        if (!std::strcmp(argv[i], "--fixtures") && i + 1 < argc) g_fixtures = argv[++i];
+        const std::string a = argv[i];
+        if (a == "--hip") with_hip = true;
+        else if (a == "--80bit") use80 = true;
+        else if (a == "--skip-reset") skipReset = true;
+        else if (a == "--fixtures" && i + 1 < argc) g_fixtures = argv[++i];
+        else if (a == "--gpus" && i + 1 < argc) gpus = std::atoi(argv[++i]);
+        else if (a == "-c" && i + 1 < argc) cycles = std::atoi(argv[++i]);
+        else if (a == "--expect" && i + 1 < argc) expect = argv[++i];
+        else if (a == "--mux-ram-dir" && i + 1 < argc) muxRamDir = argv[++i];
+        else if (a == "--snapshot-at" && i + 1 < argc) snapshotAt = std::atoi(argv[++i]);
+        else if (a == "--packet-selftest" && i + 1 < argc) {
+            mode = a;
+            inFile = argv[++i];
+            if (i + 1 < argc && argv[i + 1][0] != '-') expect = argv[++i];
+        }
+        else if ((a == "--plain-run" || a == "--hip-run") && i + 2 < argc) {
+            mode = a;
+            bpFile = argv[++i];
+            inFile = argv[++i];
+        }
+        else {
+            std::fprintf(stderr, "unknown argument: %s\n", a.c_str());
+            return 2;
+        }
     }
+    if (mode == "--packet-selftest") return packetSelfTest(inFile, expect);
+    if (mode == "--plain-run") return plainRun(bpFile, inFile, cycles, skipReset, muxRamDir);
+    if (mode == "--hip-run") {
+        if (cycles < 0) die("--hip-run needs -c N");
+        return hipRun(bpFile, inFile, cycles, expect, gpus, muxRamDir, snapshotAt);
+    }
+
     PlainHarness ph;
     runAll(ph, "plain");
     if (!with_hip) return 0;
@@ -404,13 +635,14 @@ int main(int argc, char** argv)
         iyk_params q = IYK_PARAMS_80BIT_INIT;
         p = q;
     }
-    std::vector<uint32_t> s0(p.n), s1(p.N), bk(iyk_bk_words(&p)), ksk(iyk_ksk_words(&p));
-    iyk_client_keygen(&p, 1, s0.data(), s1.data(), bk.data(), ksk.data());
-    initializeHIP(p, bk.data(), ksk.data(), 0);
+    const KeyArchive keys = makeKeys(p);
+    const std::vector<int> ids(gpus, 0);
+    initializeHIP(p, keys.bk.data(), keys.ksk.data(), gpus, ids.data());
     {
-        HIPHarness hh{p, s0, /*trivial=*/false};
+        HIPHarness hh{p, keys.s0, /*trivial=*/false};
         runAll(hh, "hip (fresh encryptions)");
-        HIPHarness ht{p, s0, /*trivial=*/true};
+        testCMUXMemoryTasks(hh);
+        HIPHarness ht{p, keys.s0, /*trivial=*/true};
         runAll(ht, "hip (trivial ciphertexts)");
     }
     cleanupHIP();

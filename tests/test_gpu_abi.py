@@ -197,3 +197,62 @@ def test_timing_log_covers_rotation_only_calls(gpu, keys128):
     assert st.last_batch_timing()[0] > 0
     arena.free()
     st.destroy()
+
+
+def test_cmux_memory_entry_points_256_jobs(gpu, keys128, oracle128):
+    """the two GPU pieces of the CMUX memories composed on 300 jobs —
+    GateBootstrappingTLWE2TRLWElvl01NTT into scattered TRLWE cells (trlwe_out indirection), then
+    SampleExtractAndKeySwitch of those cells into arena slots — against the oracle: every TLWE word of every job, and
+    the TRLWE words of a sample of cells."""
+    import ctypes as C
+    import os
+
+    import oracle_lib
+    import torch
+
+    st = gpu.Stream(0)
+    p = keys128.params
+    rng = np.random.default_rng(66)
+    jobs, cells = 300, 512
+    bits = rng.integers(0, 2, size=jobs).astype(np.uint8)
+    cts = client.encrypt_bits(keys128, bits, seed=96)
+    arena = gpu.Arena(2 * jobs)
+    st.upload(arena, 0, cts)
+    L = gpu.lib()
+    d_trlwe = C.c_void_p()
+    assert L.iyk_hip_trlwe_alloc(0, cells, C.byref(d_trlwe)) == 0
+    cell = rng.permutation(cells)[:jobs].astype(np.int32)
+    none = np.full(jobs, -1, dtype=np.int32)
+    st.bootstrap_trlwe_batch(arena, np.arange(jobs), none, np.ones(jobs), np.zeros(jobs), np.zeros(jobs, dtype=np.uint32),
+                             d_trlwe.value, trlwe_slots=cells, trlwe_out=cell)
+    st.sample_extract_keyswitch_batch(d_trlwe.value, cell, np.arange(jobs, 2 * jobs), arena, trlwe_slots=cells)
+    st.sync()
+    got = st.download(arena, jobs, jobs)
+    # TLWE words: blind rotation of the input as it is + sample extract + key switch = the oracle's pieces composed
+    u32p = C.POINTER(C.c_uint32)
+    sample = rng.choice(jobs, size=24, replace=False)
+    host = np.zeros((2, 2 * p.N), dtype=np.uint32)
+    for j in sample:
+        acc = np.zeros(2 * p.N, dtype=np.uint32)
+        oracle_lib.lib().orc_blind_rotate(oracle128.ctx, cts[j].ctypes.data_as(u32p), acc.ctypes.data_as(u32p), 2)
+        row = np.zeros(2 * p.N, dtype=np.uint32)
+        assert L.iyk_hip_trlwe_download(st.h, d_trlwe, cells, int(cell[j]), 1, row.ctypes.data_as(u32p)) == 0
+        st.sync()
+        assert np.array_equal(row, acc)
+        t1 = np.zeros(p.N + 1, dtype=np.uint32)
+        oracle_lib.lib().orc_sample_extract0(oracle128.ctx, acc.ctypes.data_as(u32p), t1.ctypes.data_as(u32p))
+        assert np.array_equal(got[j], oracle128.keyswitch(t1))
+    assert np.array_equal(client.decrypt_bits(keys128, got), bits)     # bootstrapped identity, all 300
+    # TRLWE upload / download round trip and bounds
+    img = rng.integers(0, 2**32, size=(3, 2 * p.N), dtype=np.uint64).astype(np.uint32)
+    assert L.iyk_hip_trlwe_upload(st.h, d_trlwe, cells, 7, 3, img.ctypes.data_as(u32p)) == 0
+    back = np.zeros_like(img)
+    assert L.iyk_hip_trlwe_download(st.h, d_trlwe, cells, 7, 3, back.ctypes.data_as(u32p)) == 0
+    st.sync()
+    assert np.array_equal(img, back)
+    assert L.iyk_hip_trlwe_download(st.h, d_trlwe, cells, cells - 1, 2, back.ctypes.data_as(u32p)) == -1
+    with pytest.raises(gpu.IykHipError, match="output index outside the buffer"):
+        st.bootstrap_trlwe_batch(arena, [0], [-1], [1], [0], [np.uint32(0)], d_trlwe.value, trlwe_slots=cells, trlwe_out=[cells])
+    assert L.iyk_hip_trlwe_free(0, d_trlwe) == 0
+    arena.free()
+    st.destroy()

@@ -172,3 +172,45 @@ def test_cpp_host_runtime_on_gpu(gpu, keys128):
         assert "ALL OK" in out.stdout
     finally:
         gpu.initialize(keys128, device_ids=(0,))   # module fixture teardown expects an initialised library
+
+
+def _cpp(gpu, keys128, args, timeout=900):
+    """Run the C++ host binary in its own process (it initialises the library itself)."""
+    gpu.cleanup()
+    try:
+        exe = os.path.join(ROOT, "iyokan_amd", "host", "test0_hip")
+        out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=timeout)
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+        return out.stdout
+    finally:
+        gpu.initialize(keys128, device_ids=(0,))   # module fixture teardown expects an initialised library
+
+
+def test_cpp_hip_frontend_cahp_system(gpu, keys128):
+    """the whole of config #4's system — CAHP-ruby core + MUX ROM + MUX RAM from the reference's
+    blueprint cahp-ruby-mux.toml, program test09.in — entirely in C++ on the GPU: TOML blueprint, encrypted request
+    packet, reset cycle, 7 clocks, result packet decrypted and equal to the reference's test09-ruby.out."""
+    from netlist_util import gold
+
+    out = _cpp(gpu, keys128, ["--hip-run", gold("cahp-ruby-mux.toml"), gold("test09.in"), "-c", "7", "--expect",
+                              gold("test09-ruby.out")])
+    assert "result packet equals" in out
+
+
+def test_cpp_hip_frontend_two_replicas_and_snapshot(gpu, keys128):
+    """In-process multi-GPU path of the C++ adapter (two arena replicas, frontier dealt between them, device-to-device
+    exchange at level boundaries) and snapshot / resume, on reference vectors: mux-ram-addr8bit (16 clocks, RAM
+    contents in the result packet) cut at clock 5, and the 4-bit counter."""
+    from netlist_util import gold
+
+    out = _cpp(gpu, keys128, ["--hip-run", gold("mux-ram-addr8bit.toml"), gold("test06.in"), "-c", "16", "--expect",
+                              gold("test06.out"), "--gpus", "2", "--snapshot-at", "5"])
+    assert "result packet equals" in out and "2 GPU replica(s)" in out
+    out = _cpp(gpu, keys128, ["--hip-run", gold("counter-4bit.toml"), gold("test13.in"), "-c", "3", "--expect",
+                              gold("test13.out"), "--gpus", "2"])
+    assert "result packet equals" in out
+
+
+def test_cpp_host_runtime_two_replicas(gpu, keys128):
+    out = _cpp(gpu, keys128, ["--hip", "--gpus", "2", "--fixtures", os.path.join(ROOT, "tests", "golden", "reftest")])
+    assert "ALL OK" in out and "CMUX-memory tasks ok" in out
