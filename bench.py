@@ -111,12 +111,24 @@ def empty_keys(params):
                          np.zeros(params.bk_words, np.uint32), np.zeros(params.ksk_words, np.uint32))
 
 
-def cpu_baseline(keys, params, op_code, sample, data_seed, budget_s=20.0):
-    """The oracle (kind 'port') timed on ALL of this host's cores on a bounded sample of the same workload.
+def cpu_quota():
+    """CPUs the cgroup lets this process use (cpu.max), or None: sched_getaffinity can list 256 CPUs on a box whose
+    container may only burn a few of them."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(keys, params, op_code, sample, data_seed, budget_s=24.0):
+    """The oracle (kind 'port') timed on this host's cores on a bounded sample of the same workload.
 
     Both exact restatements are timed (oracle/tfhe_oracle_fp.c: FP64-field products, AVX2 loops; oracle/tfhe_oracle.c:
-    Goldilocks 128-bit products) and the FASTER one is the reported value.  A first probe chunk (one gate per
-    thread) sizes the sample so the whole leg takes ~budget_s."""
+    Goldilocks 128-bit products) and the FASTER one is the reported value.  Thread count: ALL visible cores is tried
+    first, then halvings of it — the fastest wins and every attempt is listed (round 2 measured 256 threads slower
+    than 64 on the driver's box: a cgroup quota or SMT siblings, cpu_quota says which).  Probe chunks (one gate per
+    thread) size the final sample so the whole leg takes ~budget_s."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     from iyokan_amd import client
@@ -125,10 +137,9 @@ def cpu_baseline(keys, params, op_code, sample, data_seed, budget_s=20.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    threads = max(1, cores)
     orc = oracle_lib.Oracle(keys)
 
-    def run(count, seed, mode):
+    def run(count, seed, mode, threads):
         rng = np.random.default_rng(seed)
         bits = rng.integers(0, 2, size=2 * count).astype(np.uint8)
         arena = np.zeros((3 * count, params.n + 1), dtype=np.uint32)
@@ -142,26 +153,37 @@ def cpu_baseline(keys, params, op_code, sample, data_seed, budget_s=20.0):
         assert np.array_equal(dec, 1 - (bits[:count] & bits[count:])), "oracle decrypt mismatch"
         return dt
 
+    fast = "fp" if orc.has_fp() else "goldilocks"
+    # thread-count probe on the faster restatement: one untimed warm-up pass (thread start-up, page faults), then
+    # four gates per thread
+    tried, t = {}, cores
+    while t >= 1 and len(tried) < 5:
+        run(t, data_seed, fast, t)
+        tried[t] = 4 * t / run(4 * t, data_seed, fast, t)
+        t //= 2
+    threads = max(tried, key=tried.get)
     modes = ["fp", "goldilocks"] if orc.has_fp() else ["goldilocks"]
     results = {}
     for mode in modes:
-        share = budget_s / len(modes)
-        probe_dt = run(threads, data_seed, mode)
+        share = (budget_s * 0.6) / len(modes)
+        rate0 = tried[threads] if mode == fast else threads / run(threads, data_seed, mode, threads)
         n = sample
         if n < 0:
-            n = int(max(threads, min(64 * threads, threads * (share - probe_dt) / max(probe_dt, 1e-3))))
+            n = int(max(threads, min(64 * threads, rate0 * share)))
             n -= n % threads
             n = max(n, threads)
-        dt = run(n, data_seed + 1, mode)
+        dt = run(n, data_seed + 1, mode, threads)
         results[mode] = (n / dt, n, dt)
     orc.close()
     best = max(results, key=lambda m: results[m][0])
     rate, n, dt = results[best]
     names = {"fp": "oracle/tfhe_oracle_fp.c (FP64-field products)", "goldilocks": "oracle/tfhe_oracle.c (Goldilocks products)"}
     return {"value": rate, "unit": "gates/s", "cores": threads, "kind": "port",
-            "sample": f"{n} NAND gates of the same workload in {dt:.1f} s on {threads} threads (all {cores} visible cores), "
-                      f"own exact CPU restatement {names[best]}, OpenMP over gates; not TFHEpp",
+            "sample": f"{n} NAND gates of the same workload in {dt:.1f} s on {threads} threads ({cores} CPUs visible, fastest of "
+                      f"the thread counts tried), own exact CPU restatement {names[best]}, OpenMP over gates; not TFHEpp",
             "restatements": {m: {"gates_per_s": r[0], "sample_gates": r[1], "seconds": r[2]} for m, r in results.items()},
+            "threads_tried_gates_per_s": {str(k): v for k, v in tried.items()},
+            "visible_cpus": cores, "cpu_quota": cpu_quota(),
             "ms_per_gate_per_thread": threads / rate * 1e3}
 
 

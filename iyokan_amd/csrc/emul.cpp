@@ -282,19 +282,21 @@ void blind_rotate_fp(const iyk_params* p, const u32* lin, const double* bk_ntt, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Lane-by-lane emulation of kernels.hpp::blind_rotate_fp_lat3_kernel (blind_rotate_lat3.hpp): 2 LV waves per
-// rotation, wave (h, v) = digit polynomial h of level v, 16 points per lane, the two v_permlane32_swap rounds
-// of every pass modelled on the lane arrays, the shared NTT-domain sums as plain additions.
+// Lane-by-lane emulation of kernels.hpp::blind_rotate_fp_lat3_kernel (blind_rotate_lat3.hpp): 8 waves per rotation;
+// transform wave w < 2 LV = digit polynomial (w / LV, w % LV) with 16 points per lane, the two v_permlane32_swap
+// rounds of every pass modelled on the lane arrays; spectra to per-wave buffers in the key's device layout; the MAC
+// split by frequency over all 8 waves (lane = one adjacent pair of the layout); the last two waves run the inverse.
 template <class D>
 void blind_rotate_fp_lat3(const iyk_params* p, const u32* lin, const double* bk_ntt, u32* tlwe1)
 {
-    constexpr int LV = D::LV, W = 2 * LV;
+    constexpr int LV = D::LV, XF = 2 * LV, W = 8;
+    static_assert(XF <= W, "more digit polynomials than waves");
     const FpTables& T = fptables();
     const fp::NttConsts& C = T.t.c;
     std::vector<double> ztab(fp::ZTAB_ENTRIES);
     for (int e = 0; e < fp::ZTAB_ENTRIES; ++e) ztab[e] = fp::ztab_entry(e, C.zf);
     std::vector<u32> acc(2 * NTT_N);
-    std::vector<double> sum(2 * NTT_N, 0.0), xb((size_t)W * 32 * XB_STRIDE);
+    std::vector<double> sum(2 * NTT_N, 0.0), xb((size_t)XF * 32 * XB_STRIDE);
     struct Lane {
         double x[16], tw0[8], zi16[16];
     };
@@ -304,12 +306,13 @@ void blind_rotate_fp_lat3(const iyk_params* p, const u32* lin, const double* bk_
         for (int m = 0; m < 8; ++m)
             for (int l = 0; l < 32; ++l) std::swap(R[wave * 64 + 32 + l].x[2 * m], R[wave * 64 + l].x[2 * m + 1]);
     };
+    auto track1 = [&](double v) {
+        const double a = (v < 0 ? -v : v) / fp::P;
+        if (a > g_fp_maxabs) g_fp_maxabs = a;
+    };
     auto trackw = [&](int wave) {
         for (int lane = 0; lane < 64; ++lane)
-            for (double v : R[wave * 64 + lane].x) {
-                const double a = (v < 0 ? -v : v) / fp::P;
-                if (a > g_fp_maxabs) g_fp_maxabs = a;
-            }
+            for (double v : R[wave * 64 + lane].x) track1(v);
     };
 #define WAVE_LANES(w) for (int lane = 0; lane < 64; ++lane)
     auto dif16 = [&](int wave, int pass) {
@@ -332,27 +335,27 @@ void blind_rotate_fp_lat3(const iyk_params* p, const u32* lin, const double* bk_
     };
     const u32 bbar = br_modswitch_b(lin[p->n]);
     for (int wave = 0; wave < W; ++wave) {
-        const int h = wave / LV, v = wave % LV;
+        const int c_inv = wave - (W - 2);
         WAVE_LANES(wave)
         {
             const int half = lane >> 5, t = lane & 31;
             Lane& r = R[wave * 64 + lane];
             for (int m = 0; m < 8; ++m) r.tw0[m] = C.w[2 * m + half];
             for (int q = 0; q < 16; ++q) r.zi16[q] = C.zi[fp::inv16(half, q)];
-            if (v == 0)
+            if (c_inv >= 0)
                 for (int rr = 0; rr < 16; ++rr) {
                     const int j = t + 32 * (16 * half + rr);
                     const u32 idx = ((u32)j - bbar) & (2 * NTT_N - 1);
-                    acc[h * NTT_N + j] = h ? ((idx & NTT_N) ? 0u - p->mu : p->mu) : 0u;
+                    acc[c_inv * NTT_N + j] = c_inv ? ((idx & NTT_N) ? 0u - p->mu : p->mu) : 0u;
                 }
         }
     }
     for (u32 i = 0; i < p->n; ++i) {
         const u32 ab = br_modswitch_a(lin[i]);
-        const double* bk_step = bk_ntt + (size_t)i * (2 * LV) * 2 * NTT_N;
-        // forward phase (every wave), up to barrier 1
-        for (int wave = 0; wave < W; ++wave) {
-            const int h = wave / LV, v = wave % LV, row = h * LV + v;
+        const double* bk_step = bk_ntt + (size_t)i * XF * 2 * NTT_N;
+        // forward phase (transform waves), up to barrier 1
+        for (int wave = 0; wave < XF; ++wave) {
+            const int h = wave / LV, v = wave % LV;
             double* wxb = xb.data() + (size_t)wave * 32 * XB_STRIDE;
             WAVE_LANES(wave) fp::fwd1_pre16<D>(lane >> 5, lane & 31, v, ab, acc.data() + h * NTT_N, R[wave * 64 + lane].x, ztab.data());
             dif16(wave, 1);
@@ -366,37 +369,49 @@ void blind_rotate_fp_lat3(const iyk_params* p, const u32* lin, const double* bk_
             WAVE_LANES(wave)
             {
                 const int half = lane >> 5, t = lane & 31;
-                const double* b0 = fp::bk_lane16(bk_step, row, 0, half, t);
-                const double* b1 = fp::bk_lane16(bk_step, row, 1, half, t);
-                for (int q = 0; q < 16; ++q) {
-                    double p0 = fp::mulmod(R[wave * 64 + lane].x[q], b0[fp::brv4(q) * 64]);
-                    double p1 = fp::mulmod(R[wave * 64 + lane].x[q], b1[fp::brv4(q) * 64]);
-                    if (LV > 3) {
-                        p0 = fp::norm(p0);
-                        p1 = fp::norm(p1);
-                    }
-                    double* dst = sum.data() + fp::freq16(half, q) * 32 + t;
-                    dst[0] += p0;
-                    dst[NTT_N] += p1;
-                    for (double vv : {dst[0], dst[NTT_N]}) {
-                        const double a = (vv < 0 ? -vv : vv) / fp::P;
-                        if (a > g_fp_maxabs) g_fp_maxabs = a;
-                    }
-                }
+                for (int q = 0; q < 16; ++q) wxb[fp::brv4(q) * 64 + 2 * t + half] = R[wave * 64 + lane].x[q];
             }
         }
-        // inverse phase (waves (h, 0)), up to barrier 2
-        for (int h = 0; h < 2; ++h) {
-            const int wave = h * LV;
-            double* wxb = xb.data() + (size_t)wave * 32 * XB_STRIDE;
-            double* sum_c = sum.data() + h * NTT_N;
+        // MAC phase (all waves), up to barrier 2
+        for (int wave = 0; wave < W; ++wave)
+            WAVE_LANES(wave)
+            {
+                const int pair = 2 * (64 * wave + lane);
+                double s0[2] = {0, 0}, s1[2] = {0, 0};
+                for (int r = 0; r < XF; ++r) {
+                    const double* sp = xb.data() + (size_t)r * 32 * XB_STRIDE + pair;
+                    const double* b0 = bk_step + (size_t)(r * 2 + 0) * NTT_N + pair;
+                    const double* b1 = bk_step + (size_t)(r * 2 + 1) * NTT_N + pair;
+                    for (int e = 0; e < 2; ++e) {
+                        const double p0 = fp::mulmod(sp[e], b0[e]), p1 = fp::mulmod(sp[e], b1[e]);
+                        s0[e] = r ? s0[e] + p0 : p0;
+                        s1[e] = r ? s1[e] + p1 : p1;
+                        track1(s0[e]);
+                        track1(s1[e]);
+                    }
+                    if (XF > 6 && r == XF / 2 - 1)
+                        for (int e = 0; e < 2; ++e) {
+                            s0[e] = fp::norm(s0[e]);
+                            s1[e] = fp::norm(s1[e]);
+                        }
+                }
+                for (int e = 0; e < 2; ++e) {
+                    sum[pair + e] = s0[e];
+                    sum[NTT_N + pair + e] = s1[e];
+                }
+            }
+        // inverse phase (the last two waves), up to barrier 3
+        for (int c = 0; c < 2; ++c) {
+            const int wave = W - 2 + c;
+            double* wxb = xb.data() + (size_t)(wave < XF ? wave : c) * 32 * XB_STRIDE;
+            const double* sum_c = sum.data() + c * NTT_N;
             WAVE_LANES(wave)
             {
                 const int half = lane >> 5, t = lane & 31;
-                for (int rr = 0; rr < 16; ++rr) {
-                    double* src = sum_c + (16 * half + rr) * 32 + t;
-                    R[wave * 64 + lane].x[rr] = fp::norm(*src);
-                    *src = 0.0;
+                for (int rr = 0; rr < 16; rr += 2) {
+                    const double* src = sum_c + (8 * half + rr / 2) * 64 + 2 * t;
+                    R[wave * 64 + lane].x[rr] = fp::norm(src[0]);
+                    R[wave * 64 + lane].x[rr + 1] = fp::norm(src[1]);
                 }
             }
             dif16(wave, 1);
@@ -411,7 +426,7 @@ void blind_rotate_fp_lat3(const iyk_params* p, const u32* lin, const double* bk_
             {
                 const int half = lane >> 5, t = lane & 31;
                 const Lane& r = R[wave * 64 + lane];
-                for (int q = 0; q < 16; ++q) acc[h * NTT_N + t + 32 * fp::inv16(half, q)] += fp::inv2_post16(r.x[q], r.zi16[q]);
+                for (int q = 0; q < 16; ++q) acc[c * NTT_N + t + 32 * fp::inv16(half, q)] += fp::inv2_post16(r.x[q], r.zi16[q]);
             }
         }
     }

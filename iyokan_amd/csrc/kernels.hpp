@@ -828,22 +828,30 @@ __global__ __launch_bounds__(128 * D::LV) void blind_rotate_fp_lat2_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Low-latency variant 3: ONE ROTATION PER WORKGROUP of 2 LV wavefronts, wave (h, v) = digit polynomial h of
-// (virtual) gadget level v; 64-lane transforms with 16 points per lane (blind_rotate_lat3.hpp).  Per step:
-//   forward   every wave: digits of ITS polynomial -> NTT -> two key-row products -> ds_add_f64 into the shared
-//             NTT-domain sums [c][k1][k2];  then it issues the NEXT step's key-row loads and waits at barrier 1;
-//   inverse   waves (c, 0): sum_c -> inverse NTT -> accumulator polynomial c (and zero sum_c);  barrier 2.
-// Critical path per step ~ (0.14 k digits + 0.68 k NTT + 0.22 k MAC) + (0.05 k + 0.68 k NTT + 0.18 k post) VALU
-// of a lone wave, against 1.9 k + 1.5 k for the wave-per-level kernel; key-row latency is off the path entirely.
+// Low-latency variant 3: ONE ROTATION PER WORKGROUP of 8 wavefronts; 64-lane transforms with 16 points per lane
+// (blind_rotate_lat3.hpp).  Per CMUX step, three workgroup barriers:
+//   forward   wave w < 2 LV: digits of digit polynomial (h, v) = (w / LV, w % LV) -> 1024-point NTT -> its spectrum into
+//             the wave's own LDS buffer (the transpose matrix, free by then), in the key's device layout;     barrier 1
+//   MAC       ALL 8 waves, wave u = frequencies [128 u, 128 u + 128): each lane reads its two frequencies of the 2 LV
+//             spectra (ds_read_b128), multiplies them with the key rows (global_load_dwordx4, fetched a step ahead:
+//             issued right after the previous MAC, in flight during the inverse phase) and STORES the two sums —
+//             every (c, k) has exactly one writer, no atomics;                                              barrier 2
+//   inverse   the last two waves (c = 0, 1): sum_c -> inverse NTT -> accumulator polynomial c;               barrier 3
+// History (profiles/r02_lat3_*): v0 accumulated the products with ds_add_f64 from the transform waves: 32 LDS
+// float atomics per wave and step at ~64 cycles each, 3.5 k of the step's 18 k cycles; its stage-0 schedule look-ups
+// were run-time byte loads (+1 ms per rotation).  With 2 LV = 6 transform waves the helpers 6, 7 — alone on their
+// SIMDs during the forward phase — are the inverse waves.
 //
-// LDS (bytes): twiddles fwd + inv 16 K | twisted digits 16 K | accumulator 8 K | sums f64 [2][32][32] 16 K |
-// per wave one f64 [32][33] transpose matrix (8448).
+// LDS (bytes): twiddles fwd + inv 16 K | twisted digits 16 K | accumulator 8 K | sums f64 [2][1024] 16 K (device
+// layout) | per transform wave one f64 [32][33] transpose matrix (8448), reused for its spectrum (8192).
 template <class D>
 struct BrLat3 {
-    static constexpr int LV = D::LV, WAVES = 2 * LV, THREADS = 64 * WAVES;
+    static constexpr int LV = D::LV, XF = 2 * LV;       // transform waves
+    static constexpr int WAVES = 8, THREADS = 64 * WAVES;
+    static_assert(XF <= WAVES, "more digit polynomials than waves");
     static constexpr size_t XB_DOUBLES = 32 * XB_STRIDE;
     static constexpr size_t LDS_BYTES = (2 * NTT_N + fp::ZTAB_ENTRIES) * sizeof(double) + 2 * NTT_N * sizeof(u32) +
-                                        2 * NTT_N * sizeof(double) + (size_t)WAVES * XB_DOUBLES * sizeof(double);
+                                        2 * NTT_N * sizeof(double) + (size_t)XF * XB_DOUBLES * sizeof(double);
     static_assert(LDS_BYTES <= 160 * 1024, "latency kernel 3 does not fit the CU's LDS");
 };
 
@@ -889,15 +897,15 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
     const int32_t* __restrict__ out_index)
 {
     typedef BrLat3<D> M;
-    constexpr int LV = M::LV, NT = M::THREADS;
+    constexpr int LV = M::LV, XF = M::XF, NT = M::THREADS;
     const fp::NttConsts& C = *Cp;
     extern __shared__ __attribute__((aligned(4096))) unsigned char smem[];
     double* s_twf = reinterpret_cast<double*>(smem);                    // [k2][j1]
     double* s_twi = s_twf + NTT_N;                                      // [j1][k2]
     double* s_ztab = s_twi + NTT_N;                                     // [j2][digit + 32]
     u32* acc_lds = reinterpret_cast<u32*>(s_ztab + fp::ZTAB_ENTRIES);   // [2][1024]
-    double* s_sum = reinterpret_cast<double*>(acc_lds + 2 * NTT_N);     // [c][k1][k2]
-    double* s_xb = s_sum + 2 * NTT_N;                                   // [WAVES][32][33]
+    double* s_sum = reinterpret_cast<double*>(acc_lds + 2 * NTT_N);     // [c][device layout of k]
+    double* s_xb = s_sum + 2 * NTT_N;                                   // [XF][32][33]: transposes, then spectra
 
     for (int e = threadIdx.x; e < NTT_N; e += NT) {
         const int a = e >> 5, b = e & 31;
@@ -905,45 +913,50 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
         s_twi[b * 32 + a] = tw_inv[e];
     }
     for (int e = threadIdx.x; e < fp::ZTAB_ENTRIES; e += NT) s_ztab[e] = fp::ztab_entry(e, C.zf);
-    for (int e = threadIdx.x; e < 2 * NTT_N; e += NT) s_sum[e] = 0.0;
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int h = wave / LV, v = wave - h * LV;   // digit polynomial h, (virtual) level v
+    const bool xf = wave < XF;                        // transform wave?
+    const int h = xf ? wave / LV : 0, v = xf ? wave - h * LV : 0;   // its digit polynomial h, (virtual) level v
+    const bool inv = wave >= M::WAVES - 2;            // inverse wave?
+    const int c_inv = wave - (M::WAVES - 2);          // ... of accumulator polynomial c_inv
     const int lane = threadIdx.x & 63;
     const int half0 = lane >> 5, t0 = lane & 31;
     const int job = blockIdx.x;
     const u32* abar = abar_all + (size_t)job * abar_stride;
-    u32* acc_h = acc_lds + h * NTT_N;
-    const int half = half0, t = t0;
-    if (v == 0) {  // initial accumulator (0, X^bbar * sum_j mu X^j): each lane its 16 coefficients
+    if (inv) {  // initial accumulator (0, X^bbar * sum_j mu X^j): each lane its 16 coefficients
         const u32 bbar = abar[n];
+        u32* acc_c = acc_lds + c_inv * NTT_N;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int j = t + 32 * (16 * half + r);
+            const int j = t0 + 32 * (16 * half0 + r);
             const u32 idx = ((u32)j - bbar) & (2 * NTT_N - 1);
-            acc_h[j] = h ? ((idx & NTT_N) ? 0u - mu : mu) : 0u;
+            acc_c[j] = c_inv ? ((idx & NTT_N) ? 0u - mu : mu) : 0u;
         }
     }
     // lane constants: stage-0 twiddles w^(2m + half); inverse post-twists zeta^(-j2)
     double tw0[8], zi16[16];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) tw0[m] = C.w[2 * m + half];
+    for (int m = 0; m < 8; ++m) tw0[m] = C.w[2 * m + half0];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) zi16[q] = C.zi[fp::inv16(half, q)];
+    for (int q = 0; q < 16; ++q) zi16[q] = C.zi[fp::inv16(half0, q)];
     __syncthreads();
 
-    double* xb = s_xb + (size_t)wave * M::XB_DOUBLES;
-    const int row = h * LV + v;
-    double bk0[16], bk1[16];
-    {
-        const double* b0 = fp::bk_lane16(bk_ntt, row, 0, half, t);
-        const double* b1 = fp::bk_lane16(bk_ntt, row, 1, half, t);
+    // a transform wave's own matrix; a helper inverse wave borrows matrix c (that spectrum is consumed by barrier 2)
+    double* xb = s_xb + (size_t)(xf ? wave : c_inv) * M::XB_DOUBLES;
+    // MAC: this lane's two frequencies are the adjacent pair at device-layout offset 2 (64 wave + lane)
+    const int pair = 2 * (64 * wave + lane);
+    double bk[XF][2][2];
+    auto load_bk = [&](u32 step) {
+        const double* bk_step = bk_ntt + (size_t)step * XF * 2 * NTT_N + pair;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            bk0[q] = b0[fp::brv4(q) * 64];
-            bk1[q] = b1[fp::brv4(q) * 64];
-        }
-    }
+        for (int r = 0; r < XF; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                bk[r][c][0] = bk_step[(r * 2 + c) * NTT_N];
+                bk[r][c][1] = bk_step[(r * 2 + c) * NTT_N + 1];
+            }
+    };
+    load_bk(0);
 
     IYK_TRACE_DECL;
     u32 ab_next = abar[0];
@@ -954,56 +967,65 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
         int t = t0, half = half0;
         asm volatile("" : "+v"(t), "+v"(half));  // keep lane-dependent address math inside the iteration (no hoisting)
         IYK_TRACE(0);
-        // ---- forward: digits -> pass 1 -> twiddle -> transpose -> pass 2 -> two products into the shared sums
-        fp::fwd1_pre16<D>(half, t, v, ab, acc_h, x, s_ztab);
-        IYK_TRACE(1);
-        dif16<fp::PASS1>(x, half, tw0, C.w);
-        fp::fwd1_twiddle16(half, t, x, s_twf);
-        IYK_TRACE(2);
-        fp::xpose16_write<false>(half, t, x, xb);
-        lds_sync();
-        fp::xpose16_read(half, t, x, xb);
-        lds_sync();
-        IYK_TRACE(3);
-        dif16<fp::PASS2>(x, half, tw0, C.w);
-        IYK_TRACE(4);
+        // ---- forward (transform waves): digits -> pass 1 -> twiddle -> transpose -> pass 2 -> spectrum to LDS
+        if (xf) {
+            fp::fwd1_pre16<D>(half, t, v, ab, acc_lds + h * NTT_N, x, s_ztab);
+            IYK_TRACE(1);
+            dif16<fp::PASS1>(x, half, tw0, C.w);
+            fp::fwd1_twiddle16(half, t, x, s_twf);
+            IYK_TRACE(2);
+            fp::xpose16_write<false>(half, t, x, xb);
+            lds_sync();
+            fp::xpose16_read(half, t, x, xb);
+            lds_sync();
+            IYK_TRACE(3);
+            dif16<fp::PASS2>(x, half, tw0, C.w);
+            // frequency k = t + 32 k1, k1 = 2 brv4(q) + half, at device-layout offset brv4(q) * 64 + 2 t + half
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            double p0 = fp::mulmod(x[q], bk0[q]), p1 = fp::mulmod(x[q], bk1[q]);
-            if (LV > 3) {  // 2 LV terms of <= 1.34 p would pass 2^53: reduce each first
-                p0 = fp::norm(p0);
-                p1 = fp::norm(p1);
-            }
-            double* dst = s_sum + fp::freq16(half, q) * 32 + t;
-            __hip_atomic_fetch_add(dst, p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(dst + NTT_N, p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int q = 0; q < 16; ++q) xb[fp::brv4(q) * 64 + 2 * t + half] = x[q];
+            IYK_TRACE(4);
         }
-        // next step's key rows: in flight during the inverse phase, off the critical path
-        if (i + 1 < n) {
-            const double* bk_step = bk_ntt + (size_t)(i + 1) * (2 * LV) * 2 * NTT_N;
-            const double* b0 = fp::bk_lane16(bk_step, row, 0, half, t);
-            const double* b1 = fp::bk_lane16(bk_step, row, 1, half, t);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                bk0[q] = b0[fp::brv4(q) * 64];
-                bk1[q] = b1[fp::brv4(q) * 64];
-            }
-        }
+        wg_barrier_lds();  // the 2 LV spectra are in LDS
         IYK_TRACE(5);
-        wg_barrier_lds();  // all 2 (k+1) LV products are in the sums
-        IYK_TRACE(6);
-        // ---- inverse of sum_h -> accumulator polynomial h (waves (h, 0))
-        if (v == 0) {
-            asm volatile("" : "+v"(t), "+v"(half));
-            double* sum_c = s_sum + h * NTT_N;
+        // ---- MAC (all waves): sum_c[k] = sum_r D_r[k] BK_i[r][c][k] for this lane's two frequencies
+        {
+            double s0[2], s1[2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                double* src = sum_c + (16 * half + r) * 32 + t;
-                x[r] = *src;
-                *src = 0.0;
+            for (int r = 0; r < XF; ++r) {
+                const double* sp = s_xb + (size_t)r * M::XB_DOUBLES + pair;
+                const double d0 = sp[0], d1 = sp[1];
+                const double p00 = fp::mulmod(d0, bk[r][0][0]), p01 = fp::mulmod(d1, bk[r][0][1]);
+                const double p10 = fp::mulmod(d0, bk[r][1][0]), p11 = fp::mulmod(d1, bk[r][1][1]);
+                if (r == 0) {
+                    s0[0] = p00; s0[1] = p01; s1[0] = p10; s1[1] = p11;
+                }
+                else {
+                    s0[0] += p00; s0[1] += p01; s1[0] += p10; s1[1] += p11;
+                }
+                if (XF > 6 && r == XF / 2 - 1) {  // 8 terms of <= 1.34 p would pass 2^53: renormalise half way
+                    s0[0] = fp::norm(s0[0]); s0[1] = fp::norm(s0[1]); s1[0] = fp::norm(s1[0]); s1[1] = fp::norm(s1[1]);
+                }
             }
+            s_sum[pair] = s0[0];
+            s_sum[pair + 1] = s0[1];
+            s_sum[NTT_N + pair] = s1[0];
+            s_sum[NTT_N + pair + 1] = s1[1];
+        }
+        if (i + 1 < n) load_bk(i + 1);  // next step's key rows: in flight during the inverse phase, off the critical path
+        IYK_TRACE(6);
+        wg_barrier_lds();  // both sums are complete
+        // ---- inverse of sum_c -> accumulator polynomial c (the last two waves)
+        if (inv) {
+            asm volatile("" : "+v"(t), "+v"(half));
+            const double* sum_c = s_sum + c_inv * NTT_N;
+            u32* acc_c = acc_lds + c_inv * NTT_N;
+            // k1 = 16 half + r at device-layout offset (k1 >> 1) * 64 + 2 t + (k1 & 1): (r, r + 1) are adjacent
 #pragma unroll
-            for (int r = 0; r < 16; ++r) x[r] = fp::norm(x[r]);
+            for (int r = 0; r < 16; r += 2) {
+                const double* src = sum_c + (8 * half + r / 2) * 64 + 2 * t;
+                x[r] = fp::norm(src[0]);
+                x[r + 1] = fp::norm(src[1]);
+            }
             IYK_TRACE(7);
             dif16<fp::PASS1>(x, half, tw0, C.w);
             fp::inv1_twiddle16(half, t, x, s_twi);
@@ -1017,7 +1039,7 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
             IYK_TRACE(10);
 #pragma unroll
             for (int q = 0; q < 16; ++q)
-                __hip_atomic_fetch_add(acc_h + t + 32 * fp::inv16(half, q), fp::inv2_post16(x[q], zi16[q]), __ATOMIC_RELAXED,
+                __hip_atomic_fetch_add(acc_c + t + 32 * fp::inv16(half, q), fp::inv2_post16(x[q], zi16[q]), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WAVEFRONT);
             IYK_TRACE(11);
         }

@@ -1,0 +1,200 @@
+// tfhepp_crosscheck.cpp — ciphertext-level cross-check of the HIP path against REAL TFHEpp on identical keys and
+// inputs.  This is the hook SURVEY.md section 8(c)/(d) promises: everything else in this repository is pinned against
+// its own oracle (bit for bit) and against the reference's decrypt-level known answers; only a TFHEpp checkout can say
+// whether the oracle's frozen conventions (parameter values, mod-switch rounding, decomposition offset, key layouts)
+// are TFHEpp's.  TFHEpp is not in this container (an empty, un-vendored submodule of /root/reference), so this
+// file is NOT built by default and has never been run here:
+//
+//   make -C tools tfhepp_crosscheck IYOKAN_HIP_TFHEPP_DIR=/path/to/TFHEpp      (see tools/Makefile)
+//   ./tools/tfhepp_crosscheck [gates]
+//
+// It uses TFHEpp exactly as the reference's own call sites do:
+//   keys     SecretKey sk; EvalKey ek; ek.emplaceiksk<lvl10param>(sk); ek.emplacebk<lvl01param>(sk); ek.emplacebk2bkfft<lvl01param>()
+//            (/root/reference/src/test0.cpp:535-546, /root/reference/src/iyokan-packet.cpp:150-160)
+//   inputs   TFHEpp::bootsSymEncrypt<lvl0param>(bits, sk)                (/root/reference/src/packet.hpp:68-76)
+//   gates    TFHEpp::HomNAND<lvl01param, lvl1param::μ, lvl10param>(out, in0, in1, ek), ... HomMUX<lvl0param>(out, cs, c1, c0, ek)
+//            (/root/reference/src/iyokan_tfhepp.hpp:131-144)
+//   GPU key  ek.getbk<lvl01param>() (torus-domain TRGSWs: required by the GPU path, /root/reference/src/iyokan_cufhe.cpp:734)
+//            and ek.getiksk<lvl10param>(), handed to iyk_hip_init as raw uint32 arrays — the binding INTEGRATION.md describes.
+// Report, per gate kind: how many output ciphertexts are word-for-word identical, the largest |difference| of any
+// word, the largest distance between the two PHASES (b - <a, s>, as a fraction of the torus), and whether both
+// decrypt to the plaintext truth table.  Reading of the result:
+//   * TFHEpp's default CPU gates run the external product through a double-precision FFT (spqlios), which is
+//     approximate: its outputs differ from the exact integer product in the low bits, so word equality is NOT expected
+//     against it; the phase distance must then be at the FFT's noise level (<= 2^-20 of the torus or so) and every
+//     decryption must agree.
+//   * Built against a TFHEpp whose gates use the exact NTT bootstrapping key (ek.emplacebkntt<lvl01param>(sk) and the
+//     NTT HomGate path, where the checkout has one) every word must be identical; a difference then points at a
+//     convention this repository froze differently (SURVEY.md section 8 a-ext lists them) — that is the finding to fix.
+#include <cinttypes>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include <tfhe++.hpp>
+
+#include "../include/iyokan_hip.h"
+
+namespace {
+
+using namespace TFHEpp;
+using TLWE0 = TLWE<lvl0param>;
+
+#define CK(call)                                                                  \
+    do {                                                                          \
+        if ((call) < 0) {                                                         \
+            std::fprintf(stderr, "%s: %s\n", #call, iyk_hip_last_error());        \
+            std::exit(1);                                                         \
+        }                                                                         \
+    } while (0)
+
+uint32_t phase0(const TLWE0& c, const SecretKey& sk)
+{
+    uint32_t ph = c[lvl0param::n];
+    for (uint32_t i = 0; i < lvl0param::n; ++i) ph -= c[i] * (uint32_t)sk.key.lvl0[i];
+    return ph;
+}
+
+struct Kind {
+    const char* name;
+    int op;     // iyk_gate_op
+    int inputs;
+    int (*plain)(int, int, int);
+};
+
+void cpuGate(int op, TLWE0& out, const TLWE0& a, const TLWE0& b, const TLWE0& s, const EvalKey& ek)
+{
+    // the template arguments of /root/reference/src/iyokan_tfhepp.hpp:131-144
+    switch (op) {
+    case IYK_OP_AND: HomAND<lvl01param, lvl1param::μ, lvl10param>(out, a, b, ek); break;
+    case IYK_OP_NAND: HomNAND<lvl01param, lvl1param::μ, lvl10param>(out, a, b, ek); break;
+    case IYK_OP_ANDNOT: HomANDYN<lvl01param, lvl1param::μ, lvl10param>(out, a, b, ek); break;
+    case IYK_OP_OR: HomOR<lvl01param, lvl1param::μ, lvl10param>(out, a, b, ek); break;
+    case IYK_OP_NOR: HomNOR<lvl01param, lvl1param::μ, lvl10param>(out, a, b, ek); break;
+    case IYK_OP_ORNOT: HomORYN<lvl01param, lvl1param::μ, lvl10param>(out, a, b, ek); break;
+    case IYK_OP_XOR: HomXOR<lvl01param, lvl1param::μ, lvl10param>(out, a, b, ek); break;
+    case IYK_OP_XNOR: HomXNOR<lvl01param, lvl1param::μ, lvl10param>(out, a, b, ek); break;
+    case IYK_OP_MUX: HomMUX<lvl0param>(out, s, b, a, ek); break;  // (out, cs, c1, c0): MUX(A = in0, B = in1, S = in2)
+    case IYK_OP_NOT: HomNOT<lvl0param>(out, a); break;
+    default: std::abort();
+    }
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    const int perKind = argc > 1 ? std::atoi(argv[1]) : 64;
+
+    // ---- parameter set: TFHEpp's compile-time constants, printed so a mismatch with include/iyokan_hip_params.h shows
+    iyk_params p{};
+    p.n = lvl0param::n;
+    p.N = lvl1param::n;
+    p.k = lvl1param::k;
+    p.l = lvl1param::l;
+    p.Bgbit = lvl1param::Bgbit;
+    p.t = lvl10param::t;
+    p.basebit = lvl10param::basebit;
+    p.mu = lvl1param::μ;
+    p.alpha0 = lvl0param::α;
+    p.alpha1 = lvl1param::α;
+    const iyk_params mine = IYK_PARAMS_128BIT_INIT;
+    std::printf("TFHEpp parameters: n=%u N=%u k=%u l=%u Bgbit=%u t=%u basebit=%u mu=%u\n", p.n, p.N, p.k, p.l, p.Bgbit, p.t, p.basebit, p.mu);
+    std::printf("this repository's 128-bit set: n=%u N=%u k=%u l=%u Bgbit=%u t=%u basebit=%u mu=%u  -> %s\n", mine.n, mine.N, mine.k, mine.l,
+                mine.Bgbit, mine.t, mine.basebit, mine.mu,
+                (mine.n == p.n && mine.N == p.N && mine.l == p.l && mine.Bgbit == p.Bgbit && mine.t == p.t && mine.basebit == p.basebit) ? "same"
+                                                                                                                                          : "DIFFERENT");
+
+    // ---- keys, exactly as test0 / iyokan-packet genevalkey make them
+    SecretKey sk;
+    EvalKey ek;
+    ek.emplaceiksk<lvl10param>(sk);
+    ek.emplacebk<lvl01param>(sk);
+    ek.emplacebk2bkfft<lvl01param>();
+    const auto& bk = ek.getbk<lvl01param>();        // std::array<TRGSW<lvl1param>, lvl0param::n>
+    const auto& iksk = ek.getiksk<lvl10param>();    // [N][t][2^basebit - 1] TLWE<lvl0param>
+    static_assert(sizeof(bk) == sizeof(uint32_t) * (size_t)lvl0param::n * (lvl1param::k + 1) * lvl1param::l * (lvl1param::k + 1) * lvl1param::n,
+                  "BootstrappingKey<lvl01param> is not the flat u32[n][(k+1)l][k+1][N] array iyk_hip_init expects");
+    static_assert(sizeof(iksk) == sizeof(uint32_t) * (size_t)lvl1param::k * lvl1param::n * lvl10param::t * ((1u << lvl10param::basebit) - 1) *
+                                      (lvl0param::n + 1),
+                  "KeySwitchingKey<lvl10param> is not the flat u32[kN][t][2^basebit-1][n+1] array iyk_hip_init expects");
+    static_assert(sizeof(TLWE0) == sizeof(uint32_t) * (lvl0param::n + 1), "TLWE<lvl0param> is not u32[n+1]");
+    CK(iyk_hip_init(1, nullptr, &p, reinterpret_cast<const uint32_t*>(&bk), reinterpret_cast<const uint32_t*>(&iksk)));
+    iyk_hip_stream* st = nullptr;
+    CK(iyk_hip_stream_create(0, &st));
+
+    static const Kind kinds[] = {
+        {"AND", IYK_OP_AND, 2, [](int a, int b, int) { return a & b; }},
+        {"NAND", IYK_OP_NAND, 2, [](int a, int b, int) { return 1 ^ (a & b); }},
+        {"ANDNOT", IYK_OP_ANDNOT, 2, [](int a, int b, int) { return a & (1 ^ b); }},
+        {"OR", IYK_OP_OR, 2, [](int a, int b, int) { return a | b; }},
+        {"NOR", IYK_OP_NOR, 2, [](int a, int b, int) { return 1 ^ (a | b); }},
+        {"ORNOT", IYK_OP_ORNOT, 2, [](int a, int b, int) { return a | (1 ^ b); }},
+        {"XOR", IYK_OP_XOR, 2, [](int a, int b, int) { return a ^ b; }},
+        {"XNOR", IYK_OP_XNOR, 2, [](int a, int b, int) { return 1 ^ a ^ b; }},
+        {"MUX", IYK_OP_MUX, 3, [](int a, int b, int s) { return s ? b : a; }},
+        {"NOT", IYK_OP_NOT, 1, [](int a, int, int) { return 1 ^ a; }},
+    };
+    const int nkinds = (int)(sizeof(kinds) / sizeof(kinds[0]));
+    const int gates = nkinds * perKind, nin = 3 * gates;
+
+    // ---- identical inputs on both sides
+    std::mt19937_64 rng(12345);
+    std::vector<uint8_t> bits(nin);
+    for (auto& b : bits) b = (uint8_t)(rng() & 1);
+    const std::vector<TLWE0> in = bootsSymEncrypt<lvl0param>(bits, sk);
+    const uint64_t slots = (uint64_t)nin + gates;
+    uint32_t* d_arena = nullptr;
+    CK(iyk_hip_arena_alloc(0, slots, &d_arena));
+    CK(iyk_hip_arena_upload(st, d_arena, slots, 0, (uint64_t)nin, reinterpret_cast<const uint32_t*>(in.data())));
+
+    std::vector<int32_t> ops(gates), i0(gates), i1(gates), i2(gates), out(gates);
+    for (int g = 0; g < gates; ++g) {
+        const Kind& k = kinds[g / perKind];
+        ops[g] = k.op;
+        i0[g] = 3 * g;
+        i1[g] = k.inputs > 1 ? 3 * g + 1 : -1;
+        i2[g] = k.inputs > 2 ? 3 * g + 2 : -1;
+        out[g] = nin + g;
+    }
+    CK(iyk_hip_gate_batch(st, d_arena, slots, (uint64_t)gates, ops.data(), i0.data(), i1.data(), i2.data(), out.data()));
+    std::vector<TLWE0> gpu(gates);
+    CK(iyk_hip_arena_download(st, d_arena, slots, (uint64_t)nin, (uint64_t)gates, reinterpret_cast<uint32_t*>(gpu.data())));
+    CK(iyk_hip_stream_sync(st));
+
+    // ---- TFHEpp on the host cores, gate by gate
+    std::vector<TLWE0> cpu(gates);
+    for (int g = 0; g < gates; ++g) cpuGate(ops[g], cpu[g], in[3 * g], in[3 * g + 1], in[3 * g + 2], ek);
+
+    // ---- compare
+    int bad = 0;
+    std::printf("%-7s %9s %12s %14s %8s %8s\n", "gate", "identical", "max|dword|", "max|dphase|/2^32", "dec(gpu)", "dec(cpu)");
+    for (int k = 0; k < nkinds; ++k) {
+        int same = 0, okG = 0, okC = 0;
+        uint32_t maxWord = 0, maxPhase = 0;
+        for (int g = k * perKind; g < (k + 1) * perKind; ++g) {
+            bool eq = true;
+            for (uint32_t w = 0; w <= lvl0param::n; ++w) {
+                const uint32_t d = gpu[g][w] - cpu[g][w], ad = (int32_t)d < 0 ? 0u - d : d;
+                if (ad) eq = false;
+                if (ad > maxWord) maxWord = ad;
+            }
+            same += eq;
+            const uint32_t pg = phase0(gpu[g], sk), pc = phase0(cpu[g], sk), dp = pg - pc, adp = (int32_t)dp < 0 ? 0u - dp : dp;
+            if (adp > maxPhase) maxPhase = adp;
+            const int want = kinds[k].plain(bits[3 * g], bits[3 * g + 1], bits[3 * g + 2]);
+            okG += ((int32_t)pg > 0) == want;
+            okC += ((int32_t)pc > 0) == want;
+        }
+        std::printf("%-7s %5d/%-3d %12" PRIu32 " %14.3e %5d/%-3d %5d/%-3d\n", kinds[k].name, same, perKind, maxWord, maxPhase / 4294967296.0, okG,
+                    perKind, okC, perKind);
+        if (okG != perKind || okC != perKind) ++bad;
+    }
+    CK(iyk_hip_arena_free(0, d_arena));
+    CK(iyk_hip_stream_destroy(st));
+    CK(iyk_hip_cleanup());
+    std::printf(bad ? "DECRYPTION MISMATCH in %d gate kind(s)\n" : "all decryptions agree with the truth tables (%d)\n", bad);
+    return bad ? 1 : 0;
+}
