@@ -259,9 +259,10 @@ int dispatch_fp(iyk_hip_stream* st, int njobs, const RotOut& o)
     const int rem = njobs % round, full = njobs - rem;
     if (rem > G.lat_threshold) return launch_br_fp<DC>(st, 0, njobs, o);
     if (full && (rc = launch_br_fp<DC>(st, 0, full, o))) return rc;
-    // one workgroup per CU: the widest-split kernel (lat_kernel, default 3) wins while every rotation has a CU of its
-    // own (<= 256); above that two rotations share a CU and the 3-wave kernel (two workgroups per CU fit) is faster
-    if (rem) return launch_br_fp_lat_any<DC>(st, rem <= 256 ? G.lat_kernel : 1, full, rem, o);
+    // The 8-wave kernel (lat_kernel, default 3) takes one CU per rotation: 4.3 ms per 256 rotations, in sequence — faster than
+    // the 3-wave kernel (6.0 ms for <= 256, 9.3 / 14.0 / 17.5 ms for 512 / 768 / 1024, two workgroups per CU) up to 1024
+    // rotations (profiles/r02_sweep_lat3_*.txt); between 1024 and lat_threshold the 3-wave kernel still beats a whole round.
+    if (rem) return launch_br_fp_lat_any<DC>(st, rem <= 1024 ? G.lat_kernel : 1, full, rem, o);
     return IYK_OK;
 }
 

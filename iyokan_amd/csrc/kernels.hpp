@@ -851,7 +851,7 @@ struct BrLat3 {
     static_assert(XF <= WAVES, "more digit polynomials than waves");
     static constexpr size_t XB_DOUBLES = 32 * XB_STRIDE;
     static constexpr size_t LDS_BYTES = (2 * NTT_N + fp::ZTAB_ENTRIES) * sizeof(double) + 2 * NTT_N * sizeof(u32) +
-                                        2 * NTT_N * sizeof(double) + (size_t)XF * XB_DOUBLES * sizeof(double);
+                                        2 * NTT_N * sizeof(double) + (size_t)XF * XB_DOUBLES * sizeof(double) + 16;
     static_assert(LDS_BYTES <= 160 * 1024, "latency kernel 3 does not fit the CU's LDS");
 };
 
@@ -940,6 +940,14 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
 #pragma unroll
     for (int q = 0; q < 16; ++q) zi16[q] = C.zi[fp::inv16(half0, q)];
     __syncthreads();
+    // the inter-pass twiddles of a lane never change either: forward psi^(j1 (2 k2 + 1)) with j1 = t, k2 = freq16(half, q);
+    // inverse psi^(-j1 (2 k2 + 1)) / N with k2 = t, j1 = inv16(half, q).  In registers, they cost no LDS round trip per step.
+    double twf16[16], twi16[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        twf16[q] = s_twf[fp::freq16(half0, q) * 32 + t0];
+        twi16[q] = s_twi[fp::inv16(half0, q) * 32 + t0];
+    }
 
     // a transform wave's own matrix; a helper inverse wave borrows matrix c (that spectrum is consumed by barrier 2)
     double* xb = s_xb + (size_t)(xf ? wave : c_inv) * M::XB_DOUBLES;
@@ -958,6 +966,22 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
     };
     load_bk(0);
 
+    // Forward work split (2 LV = 6 transforms on 4 SIMDs would leave two SIMDs with two whole transforms each while the
+    // helper waves idle): a transform is part A (digits, pass 1, twiddle, transpose write) + part B (transpose read, pass 2,
+    // spectrum write).  Waves 0..3 run A and B of polynomials 0..3; the helpers 6, 7 run part A of polynomials 4, 5 —
+    // at raised priority, they share their SIMDs with waves 2, 3 — and hand over through the transpose matrix to waves
+    // 4, 5, which run part B (an LDS flag carrying the step number; all eight waves are resident, so the spin cannot
+    // deadlock).  VALU load per SIMD: 0.84 k + 0.30 k | 0.84 k + 0.53 k instead of 1.68 k | 0.84 k.
+    constexpr bool SPLIT = (XF == 6);
+    const bool doA = SPLIT ? (wave < 4 || wave >= 6) : xf;
+    const bool doB = xf;
+    const int polyA = SPLIT && wave >= 6 ? wave - 2 : wave;            // digit polynomial of this wave's part A
+    const int hA = polyA / LV, vA = polyA - hA * LV;
+    double* xbA = s_xb + (size_t)(doA ? polyA : 0) * M::XB_DOUBLES;
+    u32* s_handoff = reinterpret_cast<u32*>(s_xb + (size_t)XF * M::XB_DOUBLES);  // [2] step stamps, after the matrices
+    if (threadIdx.x < 2) s_handoff[threadIdx.x] = 0u;
+    __syncthreads();
+
     IYK_TRACE_DECL;
     u32 ab_next = abar[0];
     for (u32 i = 0; i < n; ++i) {
@@ -967,15 +991,28 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
         int t = t0, half = half0;
         asm volatile("" : "+v"(t), "+v"(half));  // keep lane-dependent address math inside the iteration (no hoisting)
         IYK_TRACE(0);
-        // ---- forward (transform waves): digits -> pass 1 -> twiddle -> transpose -> pass 2 -> spectrum to LDS
-        if (xf) {
-            fp::fwd1_pre16<D>(half, t, v, ab, acc_lds + h * NTT_N, x, s_ztab);
+        // ---- forward, part A: digits -> pass 1 -> twiddle -> transpose write
+        if (doA) {
+            if (SPLIT && wave >= 6) __builtin_amdgcn_s_setprio(3);
+            fp::fwd1_pre16<D>(half, t, vA, ab, acc_lds + hA * NTT_N, x, s_ztab);
             IYK_TRACE(1);
             dif16<fp::PASS1>(x, half, tw0, C.w);
-            fp::fwd1_twiddle16(half, t, x, s_twf);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) x[q] = fp::mulmod(x[q], twf16[q]);
             IYK_TRACE(2);
-            fp::xpose16_write<false>(half, t, x, xb);
+            fp::xpose16_write<false>(half, t, x, xbA);
             lds_sync();
+            if (SPLIT && wave >= 6) {  // publish: the matrix of polynomial 4 / 5 is complete for step i
+                if (lane == 0) __hip_atomic_store(&s_handoff[wave - 6], i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_s_setprio(0);
+            }
+        }
+        // ---- forward, part B: transpose read -> pass 2 -> spectrum to LDS (device layout)
+        if (doB) {
+            if (SPLIT && wave >= 4) {
+                while (__hip_atomic_load(&s_handoff[wave - 4], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != i + 1)
+                    __builtin_amdgcn_s_sleep(1);
+            }
             fp::xpose16_read(half, t, x, xb);
             lds_sync();
             IYK_TRACE(3);
@@ -1011,9 +1048,13 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
             s_sum[NTT_N + pair] = s1[0];
             s_sum[NTT_N + pair + 1] = s1[1];
         }
-        if (i + 1 < n) load_bk(i + 1);  // next step's key rows: in flight during the inverse phase, off the critical path
         IYK_TRACE(6);
         wg_barrier_lds();  // both sums are complete
+        // next step's key rows, off the critical path: the waves with no inverse work issue theirs now (in flight during the
+        // inverse phase), the inverse waves after their transform (in flight during the next forward phase).  Issued before
+        // barrier 2 by everyone, 8 x 12 KiB through the CU's one texture path took 1.5 k cycles of the MAC phase; issued
+        // right after it, they delayed the inverse waves by as much.
+        if (!inv && i + 1 < n) load_bk(i + 1);
         // ---- inverse of sum_c -> accumulator polynomial c (the last two waves)
         if (inv) {
             asm volatile("" : "+v"(t), "+v"(half));
@@ -1028,7 +1069,8 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
             }
             IYK_TRACE(7);
             dif16<fp::PASS1>(x, half, tw0, C.w);
-            fp::inv1_twiddle16(half, t, x, s_twi);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) x[q] = fp::mulmod(x[q], twi16[q]);
             IYK_TRACE(8);
             fp::xpose16_write<true>(half, t, x, xb);
             lds_sync();
@@ -1042,6 +1084,7 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
                 __hip_atomic_fetch_add(acc_c + t + 32 * fp::inv16(half, q), fp::inv2_post16(x[q], zi16[q]), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WAVEFRONT);
             IYK_TRACE(11);
+            if (i + 1 < n) load_bk(i + 1);
         }
         wg_barrier_lds();  // accumulator of step i is complete before anyone derives step i+1's digits
         IYK_TRACE(12);
