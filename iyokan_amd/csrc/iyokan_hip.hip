@@ -84,7 +84,7 @@ struct Global {
     iyk_params p{};
     u32 ksk_stride = 0;
     bool use_fp = false;          // FP64 path (fp50.hpp) instead of Goldilocks integers
-    int lat_threshold = 1100;     // rotations per batch at or below which a workgroup-per-rotation kernel is used
+    int lat_threshold = 1024;     // rotations per batch at or below which a workgroup-per-rotation kernel is used
     int lat_kernel = 3;           // which one: 1 = wave per level, 2 = two waves per level, 3 = wave per (polynomial, level)
     fp::NttConsts fpc{};
     std::vector<Device> devs;
@@ -259,10 +259,10 @@ int dispatch_fp(iyk_hip_stream* st, int njobs, const RotOut& o)
     const int rem = njobs % round, full = njobs - rem;
     if (rem > G.lat_threshold) return launch_br_fp<DC>(st, 0, njobs, o);
     if (full && (rc = launch_br_fp<DC>(st, 0, full, o))) return rc;
-    // The 8-wave kernel (lat_kernel, default 3) takes one CU per rotation: 4.3 ms per 256 rotations, in sequence — faster than
-    // the 3-wave kernel (6.0 ms for <= 256, 9.3 / 14.0 / 17.5 ms for 512 / 768 / 1024, two workgroups per CU) up to 1024
-    // rotations (profiles/r02_sweep_lat3_*.txt); between 1024 and lat_threshold the 3-wave kernel still beats a whole round.
-    if (rem) return launch_br_fp_lat_any<DC>(st, rem <= 1024 ? G.lat_kernel : 1, full, rem, o);
+    // The 8-wave kernel (lat_kernel, default 3) takes one CU per rotation: 4.4 ms per 256 rotations, in sequence (8.6 / 12.8 /
+    // 17.1 ms for 512 / 768 / 1024) — ahead of the 3-wave kernel (6.1 / 9.3 / 13.9 / 17.5 ms) everywhere; above 1024 a whole
+    // round of the wave-per-rotation kernel (19.9 ms) is the fastest (profiles/r02_sweep_kernels.txt).
+    if (rem) return launch_br_fp_lat_any<DC>(st, G.lat_kernel, full, rem, o);
     return IYK_OK;
 }
 
