@@ -130,6 +130,113 @@ IYK_HD constexpr int freq16(int half, int q) { return 2 * brv4(q) + half; }
 // ... and, read as an inverse transform, index (32 - freq) mod 32
 IYK_HD constexpr int inv16(int half, int q) { return (32 - freq16(half, q)) & 31; }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The inverse transforms, one polynomial on TWO waves (g = 0, 1), 8 points per lane: lane (half, t) of wave g holds
+// elements 8 half + r, r < 8, of the g-th 16-block of column t.
+//   stage 0 pairs (j, j + 16): every wave reads BOTH inputs of its eight pairs from LDS (the inputs are in LDS anyway:
+//           the NTT-domain sums, or the transposed matrix) and keeps only its branch: g = 0 the sums, g = 1 the twiddled
+//           differences (twiddle w^(8 half + r), a lane register).  A wave-uniform branch: no lane computes a product
+//           it throws away.
+//   stage 1 pairs (j, j + 8) of the 16-block — the same r in the two half-waves: the v_permlane32_swap exchange of
+//           dif16, on four register pairs (twiddle w^(2 (2m + half)) from four lane registers).
+//   stages 2..4 in-lane on the 8-block.
+// Position 16 g + 8 half + q of the DIF output holds frequency brv5(.) = 4 brv3(q) + 2 half + g.
+template <int PASS>
+struct Sched8 {
+    static constexpr const NormSched& S() { return PASS == PASS1 ? kSched1 : kSched2; }
+    // stage 0, element r of a lane: positions 8 half + r (sum branch) / 16 + 8 half + r (difference branch), any half
+    static constexpr bool sum0(int r) { return S().sum[0][r] || S().sum[0][8 + r]; }
+    static constexpr bool dif0() { return S().dif[0][16]; }
+    // stage 1, pair j = 2m + half inside 16-block g: sum at 16 g + j, twiddle-free difference (j = 0) at 16 g + 8
+    static constexpr bool sum1(int m) { return S().sum[1][2 * m] || S().sum[1][2 * m + 1] || S().sum[1][16 + 2 * m] || S().sum[1][16 + 2 * m + 1]; }
+    static constexpr bool dif1() { return S().dif[1][8] || S().dif[1][24]; }
+    // stages 2..4 inside 8-block (g, half): position 16 g + 8 half + x
+    static constexpr bool sum(int s, int x) { return S().sum[s][x] || S().sum[s][8 + x] || S().sum[s][16 + x] || S().sum[s][24 + x]; }
+    static constexpr bool dif(int s, int y) { return S().dif[s][y] || S().dif[s][8 + y] || S().dif[s][16 + y] || S().dif[s][24 + y]; }
+};
+
+// u[r] = x[8 half + r], v[r] = x[16 + 8 half + r]; tw0g[r] = w32^(8 half + r)
+template <int PASS>
+IYK_HD void dif8_stage0(const double (&u)[8], const double (&v)[8], int g, int half, const double (&tw0g)[8], double (&e)[8])
+{
+    typedef Sched8<PASS> U;
+    if (g == 0) {
+        static_for<8>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            const double sum = u[r] + v[r];
+            if constexpr (U::sum0(r)) e[r] = norm(sum);
+            else e[r] = sum;
+        });
+    }
+    else {
+        static_for<8>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            const double dif = u[r] - v[r];
+            const double tw = mulmod(dif, tw0g[r]);
+            if constexpr (r == 0) {  // pair j = 0 (lower half-wave): trivial twiddle, the schedule treats it like a sum
+                double plain = dif;
+                if constexpr (U::dif0()) plain = norm(dif);
+                e[0] = half ? tw : plain;
+            }
+            else {
+                e[r] = tw;
+            }
+        });
+    }
+}
+// between the two swaps: (e[2m], e[2m+1]) = (a, b) of pair j = 2m + half; tw1[m] = w32^(2 (2m + half))
+template <int PASS>
+IYK_HD void dif8_stage1(double (&e)[8], int half, const double (&tw1)[4])
+{
+    typedef Sched8<PASS> U;
+    static_for<4>([&](auto M) {
+        constexpr int m = decltype(M)::value;
+        const double a = e[2 * m], b = e[2 * m + 1];
+        const double sum = a + b, dif = a - b;
+        if constexpr (U::sum1(m)) e[2 * m] = norm(sum);
+        else e[2 * m] = sum;
+        const double tw = mulmod(dif, tw1[m]);
+        if constexpr (m == 0) {
+            double plain = dif;
+            if constexpr (U::dif1()) plain = norm(dif);
+            e[1] = half ? tw : plain;
+        }
+        else {
+            e[2 * m + 1] = tw;
+        }
+    });
+}
+template <int PASS, int S_, int X, int Y, int J>
+IYK_HD void dif8_bfly(double (&a)[8], const double* w)
+{
+    typedef Sched8<PASS> U;
+    const double u = a[X], v = a[Y];
+    const double sum = u + v, dif = u - v;
+    if constexpr (U::sum(S_, X)) a[X] = norm(sum);
+    else a[X] = sum;
+    if constexpr (J == 0) {
+        if constexpr (U::dif(S_, Y)) a[Y] = norm(dif);
+        else a[Y] = dif;
+    }
+    else {
+        a[Y] = mulmod(dif, w[J << S_]);
+    }
+}
+template <int PASS>
+IYK_HD void dif8_stages24(double (&a)[8], const double* w)
+{
+    // 3 stages x 4 butterflies; butterfly b of stage s: len = 16 >> s, block = b / len, j = b % len
+    static_for<12>([&](auto B) {
+        constexpr int idx = decltype(B)::value;
+        constexpr int s = 2 + idx / 4, b = idx % 4;
+        constexpr int len = 16 >> s, blk = (b / len) * 2 * len, j = b % len;
+        dif8_bfly<PASS, s, blk + j, blk + j + len, j>(a, w);
+    });
+}
+IYK_HD constexpr int brv3(int x) { return ((x & 1) << 2) | (x & 2) | ((x & 4) >> 2); }
+IYK_HD constexpr int freq8(int g, int half, int q) { return 4 * brv3(q) + 2 * half + g; }
+IYK_HD constexpr int inv8(int g, int half, int q) { return (32 - freq8(g, half, q)) & 31; }
+
 // forward pass 1, pre: td[r] = ((X^abar - 1) acc_h)[t + 32 (16 half + r)], digit of virtual level v, times
 // zeta^j2 from the twisted-digit table
 template <class D>

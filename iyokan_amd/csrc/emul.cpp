@@ -3,6 +3,7 @@
 // kernel's exact data flow (index maps, transposes, MAC, lift) against the oracle in this
 // GPU-less container.  Not loaded by the product path.  Built as libiyk_emul.so.
 #include <cstdint>
+#include <array>
 #include <cstring>
 #include <vector>
 
@@ -285,7 +286,8 @@ void blind_rotate_fp(const iyk_params* p, const u32* lin, const double* bk_ntt, 
 // Lane-by-lane emulation of kernels.hpp::blind_rotate_fp_lat3_kernel (blind_rotate_lat3.hpp): 8 waves per rotation;
 // transform wave w < 2 LV = digit polynomial (w / LV, w % LV) with 16 points per lane, the two v_permlane32_swap
 // rounds of every pass modelled on the lane arrays; spectra to per-wave buffers in the key's device layout; the MAC
-// split by frequency over all 8 waves (lane = one adjacent pair of the layout); the last two waves run the inverse.
+// split by frequency over all 8 waves (lane = one adjacent pair of the layout); waves 4..7 run the two inverse
+// transforms, two waves per polynomial with 8 points per lane.
 template <class D>
 void blind_rotate_fp_lat3(const iyk_params* p, const u32* lin, const double* bk_ntt, u32* tlwe1)
 {
@@ -359,12 +361,13 @@ void blind_rotate_fp_lat3(const iyk_params* p, const u32* lin, const double* bk_
             double* wxb = xb.data() + (size_t)wave * 32 * XB_STRIDE;
             WAVE_LANES(wave) fp::fwd1_pre16<D>(lane >> 5, lane & 31, v, ab, acc.data() + h * NTT_N, R[wave * 64 + lane].x, ztab.data());
             dif16(wave, 1);
+            WAVE_LANES(wave) fp::xpose16_write<false>(lane >> 5, lane & 31, R[wave * 64 + lane].x, wxb);
             WAVE_LANES(wave)
-            {
-                fp::fwd1_twiddle16(lane >> 5, lane & 31, R[wave * 64 + lane].x, T.twf_t.data());
-                fp::xpose16_write<false>(lane >> 5, lane & 31, R[wave * 64 + lane].x, wxb);
+            {   // part B: transposed read, then the inter-pass twiddle of element j1 = 16 half + r of row k2 = t
+                const int half = lane >> 5, t = lane & 31;
+                fp::xpose16_read(half, t, R[wave * 64 + lane].x, wxb);
+                for (int r = 0; r < 16; ++r) R[wave * 64 + lane].x[r] = fp::mulmod(R[wave * 64 + lane].x[r], T.twf_t[t * 32 + 16 * half + r]);
             }
-            WAVE_LANES(wave) fp::xpose16_read(lane >> 5, lane & 31, R[wave * 64 + lane].x, wxb);
             dif16(wave, 2);
             WAVE_LANES(wave)
             {
@@ -400,33 +403,93 @@ void blind_rotate_fp_lat3(const iyk_params* p, const u32* lin, const double* bk_
                     sum[NTT_N + pair + e] = s1[e];
                 }
             }
-        // inverse phase (the last two waves), up to barrier 3
-        for (int c = 0; c < 2; ++c) {
-            const int wave = W - 2 + c;
-            double* wxb = xb.data() + (size_t)(wave < XF ? wave : c) * 32 * XB_STRIDE;
+        // inverse phase: polynomial c on waves (c, g), g = 0 -> waves 6, 7, g = 1 -> waves 4, 5; 8 points per lane
+        struct Lane8 {
+            double e[8];
+        };
+        std::vector<Lane8> E((size_t)W * 64);
+        auto swap8 = [&](int wave) {
+            for (int m = 0; m < 4; ++m)
+                for (int l = 0; l < 32; ++l) std::swap(E[wave * 64 + 32 + l].e[2 * m], E[wave * 64 + l].e[2 * m + 1]);
+        };
+        auto dif8 = [&](int wave, int g, int pass, const std::vector<std::array<double, 16>>& in) {
+            WAVE_LANES(wave)
+            {
+                const int half = lane >> 5;
+                double u[8], vv[8], tw0g[8];
+                for (int r = 0; r < 8; ++r) {
+                    u[r] = in[lane][r];
+                    vv[r] = in[lane][8 + r];
+                    tw0g[r] = C.w[8 * half + r];
+                }
+                if (pass == 1) fp::dif8_stage0<fp::PASS1>(u, vv, g, half, tw0g, E[wave * 64 + lane].e);
+                else fp::dif8_stage0<fp::PASS2>(u, vv, g, half, tw0g, E[wave * 64 + lane].e);
+                for (double x : E[wave * 64 + lane].e) track1(x);
+            }
+            swap8(wave);
+            WAVE_LANES(wave)
+            {
+                const int half = lane >> 5;
+                double tw1[4];
+                for (int m = 0; m < 4; ++m) tw1[m] = C.w[4 * m + 2 * half];
+                if (pass == 1) fp::dif8_stage1<fp::PASS1>(E[wave * 64 + lane].e, half, tw1);
+                else fp::dif8_stage1<fp::PASS2>(E[wave * 64 + lane].e, half, tw1);
+                for (double x : E[wave * 64 + lane].e) track1(x);
+            }
+            swap8(wave);
+            WAVE_LANES(wave)
+            {
+                if (pass == 1) fp::dif8_stages24<fp::PASS1>(E[wave * 64 + lane].e, C.w);
+                else fp::dif8_stages24<fp::PASS2>(E[wave * 64 + lane].e, C.w);
+                for (double x : E[wave * 64 + lane].e) track1(x);
+            }
+        };
+        std::vector<std::array<double, 16>> in(64);
+        for (int wave = 4; wave < 8; ++wave) {  // pass 1', up to barrier 3
+            const int c = wave & 1, g = wave >= 6 ? 0 : 1;
+            double* wxb = xb.data() + (size_t)c * 32 * XB_STRIDE;
             const double* sum_c = sum.data() + c * NTT_N;
             WAVE_LANES(wave)
             {
                 const int half = lane >> 5, t = lane & 31;
-                for (int rr = 0; rr < 16; rr += 2) {
-                    const double* src = sum_c + (8 * half + rr / 2) * 64 + 2 * t;
-                    R[wave * 64 + lane].x[rr] = fp::norm(src[0]);
-                    R[wave * 64 + lane].x[rr + 1] = fp::norm(src[1]);
+                for (int rr = 0; rr < 8; rr += 2) {
+                    const double* su = sum_c + (4 * half + rr / 2) * 64 + 2 * t;
+                    const double* sv = su + 8 * 64;
+                    in[lane][rr] = fp::norm(su[0]);
+                    in[lane][rr + 1] = fp::norm(su[1]);
+                    in[lane][8 + rr] = fp::norm(sv[0]);
+                    in[lane][8 + rr + 1] = fp::norm(sv[1]);
                 }
             }
-            dif16(wave, 1);
-            WAVE_LANES(wave)
-            {
-                fp::inv1_twiddle16(lane >> 5, lane & 31, R[wave * 64 + lane].x, T.twi_t.data());
-                fp::xpose16_write<true>(lane >> 5, lane & 31, R[wave * 64 + lane].x, wxb);
-            }
-            WAVE_LANES(wave) fp::xpose16_read(lane >> 5, lane & 31, R[wave * 64 + lane].x, wxb);
-            dif16(wave, 2);
+            dif8(wave, g, 1, in);
             WAVE_LANES(wave)
             {
                 const int half = lane >> 5, t = lane & 31;
-                const Lane& r = R[wave * 64 + lane];
-                for (int q = 0; q < 16; ++q) acc[c * NTT_N + t + 32 * fp::inv16(half, q)] += fp::inv2_post16(r.x[q], r.zi16[q]);
+                for (int q = 0; q < 8; ++q) {
+                    const int j1 = fp::inv8(g, half, q);
+                    wxb[j1 * XB_STRIDE + t] = fp::mulmod(E[wave * 64 + lane].e[q], T.twi_t[j1 * 32 + t]);
+                }
+            }
+        }
+        for (int wave = 4; wave < 8; ++wave) {  // pass 2', up to barrier 4
+            const int c = wave & 1, g = wave >= 6 ? 0 : 1;
+            const double* wxb = xb.data() + (size_t)c * 32 * XB_STRIDE;
+            WAVE_LANES(wave)
+            {
+                const int half = lane >> 5, t = lane & 31;
+                for (int rr = 0; rr < 8; ++rr) {
+                    in[lane][rr] = wxb[t * XB_STRIDE + 8 * half + rr];
+                    in[lane][8 + rr] = wxb[t * XB_STRIDE + 16 + 8 * half + rr];
+                }
+            }
+            dif8(wave, g, 2, in);
+            WAVE_LANES(wave)
+            {
+                const int half = lane >> 5, t = lane & 31;
+                for (int q = 0; q < 8; ++q) {
+                    const int j2 = fp::inv8(g, half, q);
+                    acc[c * NTT_N + t + 32 * j2] += fp::inv2_post16(E[wave * 64 + lane].e[q], C.zi[j2]);
+                }
             }
         }
     }

@@ -829,14 +829,16 @@ __global__ __launch_bounds__(128 * D::LV) void blind_rotate_fp_lat2_kernel(
 
 // ------------------------------------------------------------------------------------------
 // Low-latency variant 3: ONE ROTATION PER WORKGROUP of 8 wavefronts; 64-lane transforms with 16 points per lane
-// (blind_rotate_lat3.hpp).  Per CMUX step, three workgroup barriers:
+// (blind_rotate_lat3.hpp).  Per CMUX step, four workgroup barriers:
 //   forward   wave w < 2 LV: digits of digit polynomial (h, v) = (w / LV, w % LV) -> 1024-point NTT -> its spectrum into
 //             the wave's own LDS buffer (the transpose matrix, free by then), in the key's device layout;     barrier 1
 //   MAC       ALL 8 waves, wave u = frequencies [128 u, 128 u + 128): each lane reads its two frequencies of the 2 LV
 //             spectra (ds_read_b128), multiplies them with the key rows (global_load_dwordx4, fetched a step ahead:
 //             issued right after the previous MAC, in flight during the inverse phase) and STORES the two sums —
 //             every (c, k) has exactly one writer, no atomics;                                              barrier 2
-//   inverse   the last two waves (c = 0, 1): sum_c -> inverse NTT -> accumulator polynomial c;               barrier 3
+//   inverse   polynomial c on TWO waves (g = 0: waves 6, 7; g = 1: waves 4, 5), 8 points per lane: each reads both
+//             inputs of its stage-0 pairs from LDS and keeps its branch, stage 1 by v_permlane32_swap, stages 2..4
+//             in-lane; transposed matrix through LDS (barrier 3); second pass likewise; accumulator update;    barrier 4
 // History (profiles/r02_lat3_*): v0 accumulated the products with ds_add_f64 from the transform waves: 32 LDS
 // float atomics per wave and step at ~64 cycles each, 3.5 k of the step's 18 k cycles; its stage-0 schedule look-ups
 // were run-time byte loads (+1 ms per rotation).  With 2 LV = 6 transform waves the helpers 6, 7 — alone on their
@@ -860,6 +862,17 @@ __device__ __forceinline__ void swap16(double (&a)[16])
 {
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
+        const u64 ua = fp::d2u(a[2 * m]), ub = fp::d2u(a[2 * m + 1]);
+        const auto lo = __builtin_amdgcn_permlane32_swap((u32)ua, (u32)ub, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((u32)(ua >> 32), (u32)(ub >> 32), false, false);
+        a[2 * m] = fp::u2d(((u64)hi[0] << 32) | lo[0]);
+        a[2 * m + 1] = fp::u2d(((u64)hi[1] << 32) | lo[1]);
+    }
+}
+__device__ __forceinline__ void swap8(double (&a)[8])
+{
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
         const u64 ua = fp::d2u(a[2 * m]), ub = fp::d2u(a[2 * m + 1]);
         const auto lo = __builtin_amdgcn_permlane32_swap((u32)ua, (u32)ub, false, false);
         const auto hi = __builtin_amdgcn_permlane32_swap((u32)(ua >> 32), (u32)(ub >> 32), false, false);
@@ -917,13 +930,14 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool xf = wave < XF;                        // transform wave?
     const int h = xf ? wave / LV : 0, v = xf ? wave - h * LV : 0;   // its digit polynomial h, (virtual) level v
-    const bool inv = wave >= M::WAVES - 2;            // inverse wave?
-    const int c_inv = wave - (M::WAVES - 2);          // ... of accumulator polynomial c_inv
+    // inverse: polynomial c on two waves, g = 0 (sums of stage 0) on waves 6, 7 and g = 1 (differences) on waves 4, 5
+    const bool inv = wave >= 4;
+    const int c_inv = wave & 1, g_inv = wave >= 6 ? 0 : 1;
     const int lane = threadIdx.x & 63;
     const int half0 = lane >> 5, t0 = lane & 31;
     const int job = blockIdx.x;
     const u32* abar = abar_all + (size_t)job * abar_stride;
-    if (inv) {  // initial accumulator (0, X^bbar * sum_j mu X^j): each lane its 16 coefficients
+    if (wave >= 6) {  // initial accumulator (0, X^bbar * sum_j mu X^j): each lane its 16 coefficients
         const u32 bbar = abar[n];
         u32* acc_c = acc_lds + c_inv * NTT_N;
 #pragma unroll
@@ -933,24 +947,31 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
             acc_c[j] = c_inv ? ((idx & NTT_N) ? 0u - mu : mu) : 0u;
         }
     }
-    // lane constants: stage-0 twiddles w^(2m + half); inverse post-twists zeta^(-j2)
-    double tw0[8], zi16[16];
+    // lane constants.  Forward (16 points per lane): stage-0 twiddles w^(2m + half).  Inverse (8 points per lane, wave g):
+    // stage-0 twiddles w^(8 half + r), stage-1 twiddles w^(2 (2m + half)), post-twists zeta^(-j2) with j2 = inv8(g, half, q).
+    double tw0[8], tw0g[8], tw1[4], zi8[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) tw0[m] = C.w[2 * m + half0];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) zi16[q] = C.zi[fp::inv16(half0, q)];
+    for (int r = 0; r < 8; ++r) tw0g[r] = C.w[8 * half0 + r];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) tw1[m] = C.w[4 * m + 2 * half0];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) zi8[q] = C.zi[fp::inv8(g_inv, half0, q)];
     __syncthreads();
     // the inter-pass twiddles of a lane never change either: forward psi^(j1 (2 k2 + 1)) with j1 = t, k2 = freq16(half, q);
-    // inverse psi^(-j1 (2 k2 + 1)) / N with k2 = t, j1 = inv16(half, q).  In registers, they cost no LDS round trip per step.
-    double twf16[16], twi16[16];
+    // inverse psi^(-j1 (2 k2 + 1)) / N with k2 = t, j1 = inv8(g, half, q).  In registers, they cost no LDS round trip per step.
+    // (The forward twiddle is applied AFTER the transpose, by part B: element j1 = 16 half + r of row k2 = t.  It is the same
+    // product on the same element either side; after it, the 96 instructions sit with the lighter part of a split transform.)
+    double twf16[16], twi8[8];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        twf16[q] = s_twf[fp::freq16(half0, q) * 32 + t0];
-        twi16[q] = s_twi[fp::inv16(half0, q) * 32 + t0];
-    }
+    for (int r = 0; r < 16; ++r) twf16[r] = s_twf[t0 * 32 + 16 * half0 + r];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) twi8[q] = s_twi[fp::inv8(g_inv, half0, q) * 32 + t0];
 
-    // a transform wave's own matrix; a helper inverse wave borrows matrix c (that spectrum is consumed by barrier 2)
-    double* xb = s_xb + (size_t)(xf ? wave : c_inv) * M::XB_DOUBLES;
+    // forward part B: the transform wave's own matrix.  Inverse of polynomial c: matrix c (its spectrum is consumed by barrier 2)
+    double* xb = s_xb + (size_t)(xf ? wave : 0) * M::XB_DOUBLES;
+    double* xbI = s_xb + (size_t)c_inv * M::XB_DOUBLES;
     // MAC: this lane's two frequencies are the adjacent pair at device-layout offset 2 (64 wave + lane)
     const int pair = 2 * (64 * wave + lane);
     double bk[XF][2][2];
@@ -971,7 +992,7 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
     // spectrum write).  Waves 0..3 run A and B of polynomials 0..3; the helpers 6, 7 run part A of polynomials 4, 5 —
     // at raised priority, they share their SIMDs with waves 2, 3 — and hand over through the transpose matrix to waves
     // 4, 5, which run part B (an LDS flag carrying the step number; all eight waves are resident, so the spin cannot
-    // deadlock).  VALU load per SIMD: 0.84 k + 0.30 k | 0.84 k + 0.53 k instead of 1.68 k | 0.84 k.
+    // deadlock).  VALU load per SIMD: 0.87 k + 0.43 k | 0.87 k + 0.43 k instead of 1.74 k | 0.87 k.
     constexpr bool SPLIT = (XF == 6);
     const bool doA = SPLIT ? (wave < 4 || wave >= 6) : xf;
     const bool doB = xf;
@@ -997,8 +1018,6 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
             fp::fwd1_pre16<D>(half, t, vA, ab, acc_lds + hA * NTT_N, x, s_ztab);
             IYK_TRACE(1);
             dif16<fp::PASS1>(x, half, tw0, C.w);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) x[q] = fp::mulmod(x[q], twf16[q]);
             IYK_TRACE(2);
             fp::xpose16_write<false>(half, t, x, xbA);
             lds_sync();
@@ -1015,6 +1034,8 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
             }
             fp::xpose16_read(half, t, x, xb);
             lds_sync();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = fp::mulmod(x[r], twf16[r]);
             IYK_TRACE(3);
             dif16<fp::PASS2>(x, half, tw0, C.w);
             // frequency k = t + 32 k1, k1 = 2 brv4(q) + half, at device-layout offset brv4(q) * 64 + 2 t + half
@@ -1055,33 +1076,52 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
         // barrier 2 by everyone, 8 x 12 KiB through the CU's one texture path took 1.5 k cycles of the MAC phase; issued
         // right after it, they delayed the inverse waves by as much.
         if (!inv && i + 1 < n) load_bk(i + 1);
-        // ---- inverse of sum_c -> accumulator polynomial c (the last two waves)
+        // ---- inverse of sum_c -> accumulator polynomial c, on waves (c, g): 8 points per lane (blind_rotate_lat3.hpp)
+        double e[8];
         if (inv) {
             asm volatile("" : "+v"(t), "+v"(half));
             const double* sum_c = s_sum + c_inv * NTT_N;
-            u32* acc_c = acc_lds + c_inv * NTT_N;
-            // k1 = 16 half + r at device-layout offset (k1 >> 1) * 64 + 2 t + (k1 & 1): (r, r + 1) are adjacent
+            // inputs k1 = 8 half + r and 16 + 8 half + r of column k2 = t, device layout (k1 >> 1) * 64 + 2 t + (k1 & 1)
+            double u[8], vv[8];
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const double* src = sum_c + (8 * half + r / 2) * 64 + 2 * t;
-                x[r] = fp::norm(src[0]);
-                x[r + 1] = fp::norm(src[1]);
+            for (int r = 0; r < 8; r += 2) {
+                const double* su = sum_c + (4 * half + r / 2) * 64 + 2 * t;
+                const double* sv = su + 8 * 64;
+                u[r] = fp::norm(su[0]);
+                u[r + 1] = fp::norm(su[1]);
+                vv[r] = fp::norm(sv[0]);
+                vv[r + 1] = fp::norm(sv[1]);
             }
             IYK_TRACE(7);
-            dif16<fp::PASS1>(x, half, tw0, C.w);
+            fp::dif8_stage0<fp::PASS1>(u, vv, g_inv, half, tw0g, e);
+            swap8(e);
+            fp::dif8_stage1<fp::PASS1>(e, half, tw1);
+            swap8(e);
+            fp::dif8_stages24<fp::PASS1>(e, C.w);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) x[q] = fp::mulmod(x[q], twi16[q]);
+            for (int q = 0; q < 8; ++q) xbI[fp::inv8(g_inv, half, q) * XB_STRIDE + t] = fp::mulmod(e[q], twi8[q]);
             IYK_TRACE(8);
-            fp::xpose16_write<true>(half, t, x, xb);
-            lds_sync();
-            fp::xpose16_read(half, t, x, xb);
-            lds_sync();
+        }
+        wg_barrier_lds();  // both waves of a polynomial have written its transposed matrix
+        if (inv) {
+            asm volatile("" : "+v"(t), "+v"(half));
+            u32* acc_c = acc_lds + c_inv * NTT_N;
+            double u[8], vv[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                u[r] = xbI[t * XB_STRIDE + 8 * half + r];
+                vv[r] = xbI[t * XB_STRIDE + 16 + 8 * half + r];
+            }
             IYK_TRACE(9);
-            dif16<fp::PASS2>(x, half, tw0, C.w);
+            fp::dif8_stage0<fp::PASS2>(u, vv, g_inv, half, tw0g, e);
+            swap8(e);
+            fp::dif8_stage1<fp::PASS2>(e, half, tw1);
+            swap8(e);
+            fp::dif8_stages24<fp::PASS2>(e, C.w);
             IYK_TRACE(10);
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
-                __hip_atomic_fetch_add(acc_c + t + 32 * fp::inv16(half, q), fp::inv2_post16(x[q], zi16[q]), __ATOMIC_RELAXED,
+            for (int q = 0; q < 8; ++q)
+                __hip_atomic_fetch_add(acc_c + t + 32 * fp::inv8(g_inv, half, q), fp::inv2_post16(e[q], zi8[q]), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WAVEFRONT);
             IYK_TRACE(11);
             if (i + 1 < n) load_bk(i + 1);

@@ -47,8 +47,8 @@ int main(int argc, char** argv)
     }
     std::vector<unsigned long long> tr(M::WAVES * 16);
     CK(hipMemcpy(tr.data(), d_tr, tr.size() * 8, hipMemcpyDeviceToHost));
-    const char* names[13] = {"top", "digits", "pass1+tw", "xpose", "pass2+spectrum", "barrier1", "mac+prefetch", "barrier2+sumread", "ipass1+tw",
-                             "ixpose", "ipass2", "post", "barrier3"};
+    const char* names[13] = {"top", "digits", "pass1+tw", "xpose", "pass2+spectrum", "barrier1", "mac+prefetch", "barrier2+sumread", "ipass1+tw+xw",
+                             "barrier3+xread", "ipass2", "post", "barrier4"};
     printf("s_memtime ticks since the step's first stamp (100 MHz constant clock or shader clock: compare with us/step above)\n");
     for (int w = 0; w < M::WAVES; ++w) {
         printf("wave %d:", w);
