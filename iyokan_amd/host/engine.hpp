@@ -360,15 +360,13 @@ public:
 };
 
 // Spins workers until every node of the net has finished (processAllGates,
-// /root/reference/src/iyokan_cufhe.cpp:854-878).
-template <class WorkerInfo, class WorkerType, class... Args>
-void processAllGatesWith(TaskNetwork<WorkerInfo>& net, int numWorkers, Args&&... args)
+// /root/reference/src/iyokan_cufhe.cpp:854-878).  `workers` may be long-lived (a runner keeps its workers — and their
+// streams and staging buffers — across clocks); `numFinished` must be the counter they were constructed with.
+template <class WorkerInfo, class WorkerPtr>
+void spinWorkers(TaskNetwork<WorkerInfo>& net, ReadyQueue<WorkerInfo>& q, size_t& numFinished, std::vector<WorkerPtr>& workers)
 {
-    ReadyQueue<WorkerInfo> q;
+    numFinished = 0;
     net.pushReadyTasks(q);
-    size_t numFinished = 0;
-    std::vector<std::unique_ptr<WorkerType>> workers;
-    for (int i = 0; i < numWorkers; ++i) workers.emplace_back(new WorkerType(q, numFinished, args...));
     size_t spins = 0;
     while (numFinished < net.numNodes()) {
         bool working = false;
@@ -383,6 +381,15 @@ void processAllGatesWith(TaskNetwork<WorkerInfo>& net, int numWorkers, Args&&...
             spins = 0;
         }
     }
+}
+template <class WorkerInfo, class WorkerType, class... Args>
+void processAllGatesWith(TaskNetwork<WorkerInfo>& net, int numWorkers, Args&&... args)
+{
+    ReadyQueue<WorkerInfo> q;
+    size_t numFinished = 0;
+    std::vector<std::unique_ptr<WorkerType>> workers;
+    for (int i = 0; i < numWorkers; ++i) workers.emplace_back(new WorkerType(q, numFinished, args...));
+    spinWorkers(net, q, numFinished, workers);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -528,12 +528,16 @@ inline void processAllGates(HIPNetwork& net, HIPFactory& f, int numWorkers = 1)
     processAllGatesWith<HIPWorkerInfo, HIPWorker>(net, 1, &f.arena);
 }
 
-// Per-clock driver: run() = one combinational evaluation, tick() = clock edge.
+// Per-clock driver: run() = one combinational evaluation, tick() = clock edge.  The batching worker (its streams, their
+// pinned staging buffers and rotation scratch) lives as long as the runner: nothing is allocated per clock.
 class HIPNetworkRunner {
     HIPNetwork& net_;
     HIPFactory& f_;
     std::vector<std::unique_ptr<HIPStream>> st_;
     std::vector<int32_t> latchIn_, latchShadow_, latchOut_;  // every DFF: D, shadow, Q
+    ReadyQueue<HIPWorkerInfo> queue_;
+    size_t numFinished_ = 0;
+    std::vector<std::unique_ptr<HIPWorker>> workers_;
 
 public:
     HIPNetworkRunner(HIPNetwork& net, HIPFactory& f) : net_(net), f_(f)
@@ -546,8 +550,13 @@ public:
             latchShadow_.push_back(d.shadow);
             latchOut_.push_back(d.slot);
         });
+        workers_.emplace_back(new HIPWorker(queue_, numFinished_, &f.arena));
     }
-    void run(int numWorkers = 1) { processAllGates(net_, f_, numWorkers); }
+    void run(int numWorkers = 1)
+    {
+        (void)numWorkers;  // one batching worker drives every GPU
+        spinWorkers(net_, queue_, numFinished_, workers_);
+    }
     void tick()
     {
         // two-phase latch on every replica: D -> shadow for every DFF, then shadow -> Q (shift registers latch old values)

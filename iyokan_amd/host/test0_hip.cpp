@@ -17,6 +17,11 @@
 //                                   C++ blueprint + packet + clocking protocol on the plain backend; result TOML on stdout
 //   test0_hip --packet-selftest IN.toml [ARCHIVE_OUT]
 //                                   packet.hpp: TOML and cereal PortableBinary round trips (+ a hand-assembled archive)
+//   test0_hip --genkey SK.bin EK.bin | --enc SK.bin IN.toml REQ.bin | --dec SK.bin RES.bin
+//                                   file-based key / packet tools in the shape of `iyokan-packet genkey / genevalkey / enc / dec`
+//                                   (/root/reference/src/iyokan-packet.cpp:144-178) on this repository's KeyArchive
+//   test0_hip --do-hip BP.toml --bkey EK.bin --in REQ.bin --out RES.bin -c N [--gpus G] [--snapshot F] [--resume F]
+//                                   doHIP(opt): everything from files, like `iyokan tfhe --enable-gpu` (/root/reference/src/main.cpp)
 //   test0_hip --hip-run BP.toml IN.toml -c N [--expect OUT.toml] [--gpus G] [--mux-ram-dir DIR] [--snapshot-at K]
 //                                   the same, ENCRYPTED, through HIPFrontend (keys made in-process, request packet
 //                                   encrypted here, result decrypted and compared); with --snapshot-at the run is cut at
@@ -592,7 +597,7 @@ int main(int argc, char** argv)
 {
     bool with_hip = false, use80 = false, skipReset = false;
     int gpus = 1, cycles = -2, snapshotAt = 0;
-    std::string mode, bpFile, inFile, expect, muxRamDir;
+    std::string mode, bpFile, inFile, expect, muxRamDir, bkey, outFile, snapshotFile, resumeFile;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--hip") with_hip = true;
@@ -604,6 +609,31 @@ int main(int argc, char** argv)
         else if (a == "--expect" && i + 1 < argc) expect = argv[++i];
         else if (a == "--mux-ram-dir" && i + 1 < argc) muxRamDir = argv[++i];
         else if (a == "--snapshot-at" && i + 1 < argc) snapshotAt = std::atoi(argv[++i]);
+        else if (a == "--genkey" && i + 2 < argc) {
+            mode = a;
+            bpFile = argv[++i];
+            inFile = argv[++i];
+        }
+        else if (a == "--enc" && i + 3 < argc) {
+            mode = a;
+            bpFile = argv[++i];
+            inFile = argv[++i];
+            expect = argv[++i];
+        }
+        else if (a == "--dec" && i + 2 < argc) {
+            mode = a;
+            bpFile = argv[++i];
+            inFile = argv[++i];
+        }
+        else if (a == "--do-hip" && i + 1 < argc) {
+            mode = a;
+            bpFile = argv[++i];
+        }
+        else if (a == "--bkey" && i + 1 < argc) bkey = argv[++i];
+        else if (a == "--in" && i + 1 < argc) inFile = argv[++i];
+        else if (a == "--out" && i + 1 < argc) outFile = argv[++i];
+        else if (a == "--snapshot" && i + 1 < argc) snapshotFile = argv[++i];
+        else if (a == "--resume" && i + 1 < argc) resumeFile = argv[++i];
         else if (a == "--packet-selftest" && i + 1 < argc) {
             mode = a;
             inFile = argv[++i];
@@ -618,6 +648,51 @@ int main(int argc, char** argv)
             std::fprintf(stderr, "unknown argument: %s\n", a.c_str());
             return 2;
         }
+    }
+    if (mode == "--genkey") {  // secret key archive (s0, s1 only) + evaluation key archive (bk, ksk only)
+        iyk_params p = IYK_PARAMS_128BIT_INIT;
+        KeyArchive all;
+        all.params = p;
+        all.s0.resize(p.n);
+        all.s1.resize(p.N);
+        all.bk.resize(iyk_bk_words(&p));
+        all.ksk.resize(iyk_ksk_words(&p));
+        iyk_client_keygen(&p, 0, /*deterministic=*/0, all.s0.data(), all.s1.data(), all.bk.data(), all.ksk.data());  // OS entropy
+        KeyArchive sk = all, ek = all;
+        sk.bk.clear();
+        sk.ksk.clear();
+        ek.s0.clear();
+        ek.s1.clear();
+        writeToArchiveFile(bpFile, sk);
+        writeToArchiveFile(inFile, ek);
+        return 0;
+    }
+    if (mode == "--enc") {  // bpFile = SK, inFile = IN.toml, expect = REQ.bin
+        const KeyArchive sk = readFromArchiveFile<KeyArchive>(bpFile);
+        writeToArchiveFile(expect, encryptPacket(sk.params, sk.s0, plainPacketFromTOMLFile(inFile)), sk.params);
+        return 0;
+    }
+    if (mode == "--dec") {  // bpFile = SK, inFile = RES.bin; TOML on stdout
+        const KeyArchive sk = readFromArchiveFile<KeyArchive>(bpFile);
+        const TFHEPacket res = readFromArchiveFile<TFHEPacket>(inFile, sk.params);
+        std::fputs(plainPacketToTOML(decryptPacket(sk.params, sk.s0, res)).c_str(), stdout);
+        return 0;
+    }
+    if (mode == "--do-hip") {
+        Options opt;
+        opt.blueprint = bpFile;
+        opt.bkeyFile = bkey;
+        opt.inputFile = inFile;
+        opt.outputFile = outFile;
+        if (cycles >= 0) opt.numCycles = cycles;
+        opt.numGPU = gpus;
+        opt.deviceIds.assign(gpus, 0);
+        opt.muxRamDir = muxRamDir;
+        opt.skipReset = skipReset;
+        if (!snapshotFile.empty()) opt.snapshotFile = snapshotFile;
+        if (!resumeFile.empty()) opt.resumeFile = resumeFile;
+        doHIP(opt);
+        return 0;
     }
     if (mode == "--packet-selftest") return packetSelfTest(inFile, expect);
     if (mode == "--plain-run") return plainRun(bpFile, inFile, cycles, skipReset, muxRamDir);

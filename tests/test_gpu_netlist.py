@@ -214,3 +214,28 @@ def test_cpp_hip_frontend_two_replicas_and_snapshot(gpu, keys128):
 def test_cpp_host_runtime_two_replicas(gpu, keys128):
     out = _cpp(gpu, keys128, ["--hip", "--gpus", "2", "--fixtures", os.path.join(ROOT, "tests", "golden", "reftest")])
     assert "ALL OK" in out and "CMUX-memory tasks ok" in out
+
+
+def test_cpp_do_hip_from_files(gpu, keys128, tmp_path):
+    """doHIP(opt) with everything in files, the shape of `iyokan-packet genkey / genevalkey / enc` -> `iyokan tfhe
+    --enable-gpu -c N` -> `iyokan-packet dec`: key archives (OS-entropy keys), cereal request packet, result packet;
+    then the same run cut by a snapshot after 1 clock and resumed for the remaining 2."""
+    from iyokan_amd.packet import PlainPacket
+    from netlist_util import gold
+
+    sk, ek, req, res = (str(tmp_path / n) for n in ("sk.bin", "ek.bin", "req.bin", "res.bin"))
+    _cpp(gpu, keys128, ["--genkey", sk, ek])
+    _cpp(gpu, keys128, ["--enc", sk, gold("test13.in"), req])
+    _cpp(gpu, keys128, ["--do-hip", gold("counter-4bit.toml"), "--bkey", ek, "--in", req, "--out", res, "-c", "3"])
+    out = _cpp(gpu, keys128, ["--dec", sk, res])
+    (tmp_path / "res.toml").write_text(out)
+    expected = PlainPacket.load(gold("test13.out"))
+    got = PlainPacket.load(str(tmp_path / "res.toml"))
+    assert got.same_content(expected), got.diff(expected)
+    snap, res2 = str(tmp_path / "snap.bin"), str(tmp_path / "res2.bin")
+    _cpp(gpu, keys128, ["--do-hip", gold("counter-4bit.toml"), "--bkey", ek, "--in", req, "--out", res2, "-c", "1", "--snapshot", snap])
+    _cpp(gpu, keys128, ["--do-hip", gold("counter-4bit.toml"), "--resume", snap, "--out", res2, "-c", "2", "--skip-reset"])
+    out = _cpp(gpu, keys128, ["--dec", sk, res2])
+    (tmp_path / "res2.toml").write_text(out)
+    got2 = PlainPacket.load(str(tmp_path / "res2.toml"))
+    assert got2.same_content(expected), got2.diff(expected)
