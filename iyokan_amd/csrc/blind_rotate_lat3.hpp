@@ -1,18 +1,17 @@
-// blind_rotate_lat3.hpp — per-lane phases of the wave-per-(polynomial, level) low-latency blind rotation.
+// blind_rotate_lat3.hpp — per-lane phases of the workgroup-per-rotation low-latency blind rotation (kernels.hpp,
+// blind_rotate_fp_lat3_kernel).
 //
-// Narrow frontiers (CAHP-class netlist levels: a few dozen gates) are bound by the LATENCY of one rotation:
-// n = 636 dependent CMUX steps.  A lone wavefront issues one VALU instruction per ~8 cycles on gfx950, so the
-// time of a step is (instructions on its longest dependent path) x 8 cycles: the way down is to cut that
-// path, i.e. to spread the step over more wavefronts.  Here ONE rotation runs on a workgroup of 2 LV waves:
-//   forward phase   wave (h, v) transforms digit polynomial (h, v) — a whole 1024-point negacyclic NTT on
-//                   64 lanes, 16 points per lane instead of 32 — multiplies it with the two key rows
-//                   BK_i[h LV + v][c], c = 0, 1, and adds both products into a shared NTT-domain sum in LDS
-//                   (ds_add_f64: the addends are exact integers below 2^53, so the order is irrelevant);
-//   inverse phase   waves (c, 0) transform sum_c back and update accumulator polynomial c.
-// Two workgroup barriers per step.  The other waves spend the inverse phase fetching the next step's key rows.
+// Narrow frontiers (CAHP-class netlist levels: a few dozen gates) are bound by the LATENCY of one rotation: n = 636
+// dependent CMUX steps.  The time of a step is the length of its longest dependent instruction path plus the LDS round
+// trips on it, so the way down is to spread the step over the wavefronts of a whole CU.  ONE rotation runs on a
+// workgroup of 8 waves; per step (kernels.hpp has the schedule and its history):
+//   forward   the 2 LV digit polynomials are transformed by 64-LANE transforms with 16 points per lane (dif16_*), one
+//             polynomial per wave (two of the six split by pass over two waves to balance the four SIMDs), spectra to LDS;
+//   MAC       split by frequency over all 8 waves, plain stores of the two NTT-domain sums;
+//   inverse   each of the two sums on TWO waves with 8 points per lane (dif8_*).
 //
-// 64-lane transform.  Same 32 x 32 four-step structure, tables and renormalisation schedules as the other
-// kernels (fpntt32.hpp), but a column's 32-point DIF is shared by the TWO half-waves: lane (half, t) holds
+// 64-lane transform (16 points per lane).  Same 32 x 32 four-step structure, tables and renormalisation schedules as the
+// other kernels (fpntt32.hpp), but a column's 32-point DIF is shared by the TWO half-waves: lane (half, t) holds
 // elements 16 half + r, r < 16, of column t.  Stage 0 pairs (j, j + 16) — one element in each half.  Two
 // v_permlane32_swap rounds do it without duplicating work:
 //   swap-in   (a[2m], a[2m+1]) of lanes (0, t) / (1, t)  ->  lane (0, t) holds the pair j = 2m, lane (1, t) the
@@ -24,7 +23,8 @@
 // 32 swap instructions per pass on top of the arithmetic of half a 32-point DIF.  Operations on values are
 // those of ntt32_dif (plus renormalisations where EITHER half's static schedule asks for one), so all
 // magnitudes stay within the bounds proven there and the results are the same integers mod p: bit-identical
-// output.  csrc/emul.cpp runs these functions lane by lane on the CPU against the oracle.
+// output.  The 8-points-per-lane variant (two waves per polynomial) is described at dif8_stage0 below.
+// csrc/emul.cpp runs these functions lane by lane on the CPU against the oracle (tests/test_kernel_emulation.py).
 #pragma once
 #include <type_traits>
 #include <utility>
