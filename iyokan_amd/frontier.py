@@ -210,8 +210,19 @@ class FrontierExecutor:
                     lo, B = L["base"], L["B"]
                     whole = be.arena[lo: lo + w * B]
                     mine = be.arena[lo + self.rank * B: lo + (self.rank + 1) * B].clone()
-                    self.dist.all_gather_into_tensor(whole, mine)
+                    self._all_gather(whole, mine)
                     self.collectives += 1
+
+    def _all_gather(self, whole, mine):
+        """RCCL all_gather_into_tensor on the device arena.  Test rigs with ONE GPU run the ranks as processes sharing that
+        GPU over gloo (RCCL refuses two ranks on one device; gloo has no device all-gather): the same per-level exchange,
+        staged through the host — every other line of the sharded path (plans, per-rank batches, slot layout) is the product's."""
+        if whole.is_cuda and self.dist.get_backend() == "gloo":
+            host = whole.new_empty(whole.shape, device="cpu")
+            self.dist.all_gather_into_tensor(host, mine.cpu())
+            whole.copy_(host)
+        else:
+            self.dist.all_gather_into_tensor(whole, mine)
 
     # ---- clock edge: two-phase latch so DFF -> DFF chains sample the old value ---------------
     def tick(self):

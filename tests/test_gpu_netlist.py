@@ -239,3 +239,75 @@ def test_cpp_do_hip_from_files(gpu, keys128, tmp_path):
     (tmp_path / "res2.toml").write_text(out)
     got2 = PlainPacket.load(str(tmp_path / "res2.toml"))
     assert got2.same_content(expected), got2.diff(expected)
+
+
+def _two_rank_worker(rank, world, port, q):
+    """One of two processes sharing GPU 0: the frontier-sharded executor with real ciphertexts and kernels."""
+    import hashlib
+
+    import torch
+    import torch.distributed as dist
+
+    from iyokan_amd import hip
+    from iyokan_amd.params import params_128bit
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = params_128bit()
+        keys = client.keygen(p, seed=1)                       # same seed: identical keys on both ranks
+        hip.initialize(keys, device_ids=(0,))
+        nl = N.load_iyokanl1_json(gold("counter-4bit-iyokanl1.json"))
+        plan = FrontierPlan(nl, world)
+        be = HipBackend(plan.num_slots, p, torch.device("cuda", 0))
+        ex = FrontierExecutor(plan, be, rank, world, dist)
+        sim = N.PlainSimulator(nl)
+        zero = client.trivial(p, 0)
+        be.write_many([plan.slot[i] for i in plan.dffs + plan.sources], np.tile(zero, (len(plan.dffs) + len(plan.sources), 1)))
+        seed = 500
+        outs = []
+        for c in range(4):
+            ex.tick(); sim.tick()
+            for (port_, bit) in sorted(nl.inputs):
+                v = int(c == 0) if port_ == "reset" else 1
+                seed += 1
+                ex.set_input(port_, bit, client.encrypt_bits(keys, [v], seed=seed)[0])   # same seed on both ranks
+                sim.set_input(port_, bit, v)
+            ex.run(); ex.sync(); sim.evaluate()
+            keys_out = sorted(nl.outputs)
+            got = client.decrypt_bits(keys, be.read_many([plan.slot[nl.outputs[k]] for k in keys_out]))
+            outs.append((list(map(int, got)), [sim.get_output(*k) for k in keys_out]))
+        digest = hashlib.sha256(be.arena.cpu().numpy().tobytes()).hexdigest()
+        q.put((rank, outs, digest, ex.collectives))
+        be.close()
+        hip.cleanup()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frontier_two_ranks_one_gpu(gpu, keys128):
+    """the sharded executor had only ever run on a bit backend.  Two processes share GPU 0 (gloo,
+    host-staged all-gather: RCCL refuses two ranks on one device); each evaluates its share of every level of the 4-bit
+    counter with the HIP kernels on real ciphertexts; after 4 clocks both arenas are bit-identical and decrypt like the
+    plaintext simulator."""
+    import torch.multiprocessing as mp
+
+    gpu.cleanup()
+    try:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = 29900 + (os.getpid() % 2000)
+        procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+        for p_ in procs:
+            p_.start()
+        for p_ in procs:
+            p_.join(timeout=600)
+            assert p_.exitcode == 0
+        got = sorted(q.get(timeout=10) for _ in range(2))
+    finally:
+        gpu.initialize(keys128, device_ids=(0,))
+    assert got[0][2] == got[1][2]                                   # identical arenas
+    for rank_out in got:
+        for dec, want in rank_out[1]:
+            assert dec == want
+    assert got[0][3] == got[1][3] > 0

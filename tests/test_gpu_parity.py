@@ -356,3 +356,32 @@ def test_dispatch_split_bit_exact_vs_oracle(gpu128, keys128, oracle128):
     oracle128.gate_batch(ops[sample], ia[sample], ib[sample], [-1] * len(sample),
                          list(range(nin, nin + len(sample))), ref, nthreads=os.cpu_count() or 1)
     assert np.array_equal(got[nin + sample], ref[nin:])
+
+
+def test_mux_batch_straddles_the_dispatch_split(gpu128, keys128, oracle128):
+    """1400 MUX gates = 2800 rotations: 2048 on the wave-per-rotation kernel, 752 on the workgroup-per-rotation kernel
+    (three passes of <= 256), and some gates have their two rotations on DIFFERENT kernels; an empty batch is a no-op.
+    96 gates around the split and 32 random ones are compared word for word with the oracle, all of them by decryption."""
+    hip, st = gpu128
+    p = keys128.params
+    rng = np.random.default_rng(2468)
+    nin, ng = 200, 1400
+    bits = rng.integers(0, 2, size=nin).astype(np.uint8)
+    a, b, s_ = (rng.integers(0, nin, size=ng).astype(np.int32) for _ in range(3))
+    host = np.zeros((nin + ng, p.n + 1), dtype=np.uint32)
+    host[:nin] = client.encrypt_bits(keys128, bits, seed=80)
+    arena = hip.Arena(host.shape[0])
+    st.upload(arena, 0, host)
+    st.gate_batch(arena, [], [], [], [], [])                                   # count == 0
+    st.gate_batch(arena, np.full(ng, OPS["MUX"], dtype=np.int32), a, b, s_, np.arange(nin, nin + ng, dtype=np.int32))
+    st.sync()
+    got = st.download(arena, 0, host.shape[0])
+    arena.free()
+    assert np.array_equal(got[:nin], host[:nin])
+    assert np.array_equal(client.decrypt_bits(keys128, got[nin:]), np.where(bits[s_] == 1, bits[b], bits[a]))
+    sample = np.concatenate([np.arange(976, 1072), rng.choice(ng, size=32, replace=False)])   # gate 1024 = rotations 2048, 2049
+    ref = np.zeros((nin + len(sample), p.n + 1), dtype=np.uint32)
+    ref[:nin] = host[:nin]
+    oracle128.gate_batch([OPS["MUX"]] * len(sample), a[sample], b[sample], s_[sample], list(range(nin, nin + len(sample))), ref,
+                         nthreads=os.cpu_count() or 1, mode="fp")
+    assert np.array_equal(got[nin + sample], ref[nin:])
