@@ -231,7 +231,9 @@ int iyk_hip_timing_log_end(iyk_hip_stream* st, uint64_t* batches, double* blind_
  * wave-per-rotation kernel or one of the workgroup-per-rotation kernels (1: wave per level, 2: two waves per
  * level, 3: wave per (polynomial, level) — the default for narrow frontiers); unset = chosen by batch size
  * (DESIGN.md section 6).  IYK_HIP_LATENCY_DEFAULT = 1 / 2 / 3 at init changes which of them the size-based
- * dispatch uses. */
+ * dispatch uses.  IYK_HIP_KS_KERNEL = 0 / 1, also read at every batch, forces the key switch with 16 gates per
+ * workgroup (3 words per thread) or the one with 16 gates per wave (whole rows per wave; the default where
+ * instantiated); both subtract the same rows mod 2^32, so they agree word for word. */
 int iyk_hip_ntt_path(void);
 
 /* Bytes of device memory holding keys on one GPU (NTT-domain BK + padded KSK + tables). */

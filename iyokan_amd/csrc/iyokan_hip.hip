@@ -83,6 +83,7 @@ struct Global {
     bool debug = false;           // IYK_HIP_DEBUG=1 at init: gate_batch also verifies the independence contract
     iyk_params p{};
     u32 ksk_stride = 0;
+    int ks_kernel = 1;    // 1: keyswitch_wave_kernel where instantiated, 0: keyswitch_kernel (IYK_HIP_KS_KERNEL)
     bool use_fp = false;          // FP64 path (fp50.hpp) instead of Goldilocks integers
     int lat_threshold = 1024;     // rotations per batch at or below which a workgroup-per-rotation kernel is used
     int lat_kernel = 3;           // which one: 1 = wave per level, 2 = two waves per level, 3 = wave per (polynomial, level)
@@ -284,8 +285,24 @@ int launch_blind_rotate(iyk_hip_stream* st, const u32* d_arena, const RotJob* d_
     return fail(IYK_ERR_INVALID, "unsupported (l, Bgbit)");
 }
 
-// Key switch: init outputs to (0,..,0,b'), then KS_G gates per workgroup, i range sliced so that at
-// least ~2 workgroups per CU exist even for small frontiers (slices combine by integer atomics).
+// Key switch: init outputs to (0,..,0,b'), then the partial sums are subtracted with integer atomics.  The i range
+// is sliced so that at least ~2 workgroups per CU exist even for small frontiers.  Default: keyswitch_wave_kernel
+// (a wave per 16 gates and whole rows) for the (t, n) shapes it is instantiated for; IYK_HIP_KS_KERNEL=0 (or any
+// other shape) selects keyswitch_kernel (16 gates per workgroup, 3 words per thread).
+template <int T, int NC, int GW>
+int launch_keyswitch_wave(iyk_hip_stream* st, u32* d_arena, const KsJob* d_jobs, int njobs)
+{
+    const Device& D = G.devs[st->gpu];
+    const int groups = (njobs + 4 * GW - 1) / (4 * GW);
+    int slices = 1;
+    while (slices < 256 && groups * slices < 512) slices *= 2;
+    const u32 i_per_slice = (u32)NTT_N / (u32)slices;
+    hipLaunchKernelGGL((keyswitch_wave_kernel<T, NC, GW>), dim3((unsigned)groups, (unsigned)slices), dim3(256),
+                       (size_t)4 * GW * KS2_CHUNK * 2, st->s, (const u32*)st->d_rot, d_jobs, njobs, (const u32*)D.ksk,
+                       d_arena, G.p.n, G.ksk_stride, i_per_slice);
+    HIP_TRY(hipGetLastError());
+    return IYK_OK;
+}
 template <int T>
 int launch_keyswitch_t(iyk_hip_stream* st, u32* d_arena, const KsJob* d_jobs, int njobs)
 {
@@ -294,6 +311,13 @@ int launch_keyswitch_t(iyk_hip_stream* st, u32* d_arena, const KsJob* d_jobs, in
     hipLaunchKernelGGL(keyswitch_init_kernel, dim3((unsigned)njobs), dim3(KS_THREADS), 0, st->s,
                        (const u32*)st->d_rot, d_jobs, d_arena, p.n);
     HIP_TRY(hipGetLastError());
+    const char* force = std::getenv("IYK_HIP_KS_KERNEL");  // "0" / "1" per call (A/B, tests), like IYK_HIP_LATENCY_KERNEL
+    const int kind = force && (force[0] == '0' || force[0] == '1') ? force[0] - '0' : G.ks_kernel;
+    const u32 nc = (G.ksk_stride + 127u) / 128u;
+    if (kind == 1) {
+        if (T == 7 && nc == 5) return launch_keyswitch_wave<7, 5, 16>(st, d_arena, d_jobs, njobs);
+        if (T == 8 && nc == 4) return launch_keyswitch_wave<8, 4, 16>(st, d_arena, d_jobs, njobs);
+    }
     const int groups = (njobs + KS_G - 1) / KS_G;
     int slices = 1;
     while (slices < 64 && groups * slices < 512) slices *= 2;
@@ -604,6 +628,7 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
     }
     const char* dbg = std::getenv("IYK_HIP_DEBUG");
     const char* lk = std::getenv("IYK_HIP_LATENCY_DEFAULT");  // 1 / 2 / 3: kernel used for narrow frontiers
+    G.ks_kernel = 1;
     G.debug = dbg && dbg[0] == '1';
     G.lat_kernel = (lk && lk[0] >= '1' && lk[0] <= '3') ? lk[0] - '0' : 3;
     G.p = p;

@@ -55,6 +55,18 @@ __device__ __forceinline__ void lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// (t, h) = (lane & 31, lane >> 5) derived again where a loop iteration needs them.  Two purposes: the address math
+// that hangs off them stays inside the iteration (hoisted, it costs more registers than it saves instructions), and
+// — unlike an empty asm on the loop-invariant values — the pair is never worth spilling: with the wave-per-rotation
+// kernel at 256 VGPRs the allocator used to park t and h in scratch and reload them at every level.
+__device__ __forceinline__ void lane_th(int& t, int& h)
+{
+    u32 lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    t = (int)(lane & 31u);
+    h = (int)(lane >> 5);
+}
+
 // Workgroup barrier for LDS hand-offs only: waits for this wave's LDS operations (lgkmcnt), NOT for its
 // outstanding global loads — __syncthreads() would also drain vmcnt and so expose the latency of the key
 // rows prefetched at the top of the step at the very first barrier (measured: 0.5 ms of 6.5 per rotation).
@@ -392,8 +404,8 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
         // ((X^abar - 1) acc)[t + 32 j2] is the same for every gadget level of this step: derived once
         u32 td[32];
         {
-            int t = t0, h = h0;
-            asm volatile("" : "+v"(t), "+v"(h));
+            int t, h;
+            lane_th(t, h);
             fp::fwd1_diff(t, ab, acc_lds + h * NTT_N, td);
         }
 
@@ -402,8 +414,8 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
         // each with its own renormalisation schedule (fpntt32.hpp).
 #pragma unroll 1
         for (int lvl = 0; lvl < L; ++lvl) {
-            int t = t0, h = h0;
-            asm volatile("" : "+v"(t), "+v"(h));  // keep address math inside the iteration (see blind_rotate_kernel)
+            int t, h;
+            lane_th(t, h);  // keep address math inside the iteration (see blind_rotate_kernel)
             const u32* acc_h = acc_lds + h * NTT_N;
             u32* xb = xb_lds + h * XB_WORDS32;
             double* xb64_own = reinterpret_cast<double*>(xb);
@@ -471,8 +483,8 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
         // straight from global memory (L2-resident, 8 KB) into the registers the now dead sum occupied: the
         // loads are issued before pass 1 and land long before they are needed.
         {
-            int t = t0, h = h0;
-            asm volatile("" : "+v"(t), "+v"(h));
+            int t, h;
+            lane_th(t, h);
             u32* acc_h = acc_lds + h * NTT_N;
             u32* xb = xb_lds + h * XB_WORDS32;
             double twi[32];
@@ -1255,6 +1267,129 @@ __global__ __launch_bounds__(KS_THREADS) void keyswitch_kernel(
         atomicSub(out + w0, acc[g][0]);
         if (w1 <= n) atomicSub(out + w1, acc[g][1]);
         if (w2 <= n) atomicSub(out + w2, acc[g][2]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Key switch, wave-per-16-gates variant (the default).  keyswitch_kernel above spends its time in the scalar unit:
+// every wave decodes every (gate, digit) for the 3 words it owns per row (2.6 k SALU instructions per i against
+// 250 additions).  Here a wave owns KSW_G gates and the WHOLE row (lane = 2 words of each 128-word chunk, NC
+// chunks), so one decode serves 2 NC words instead of 3; the three candidate rows of a stage (i, j) are fetched
+// one stage ahead straight into registers (L2 / L1 hits: every wave of the launch walks the same rows), digits
+// are staged per chunk of <= 128 coefficients in this wave's LDS slice, read by lane = gate and broadcast with
+// v_readlane.  No workgroup barrier anywhere: the four waves of a workgroup are independent (they only share the
+// launch geometry).  Sums are order-independent mod 2^32, so the result is bit-identical to keyswitch_kernel's.
+// Measured (65 536 NANDs): 31.3 -> 15.6 ms.  Sharing the rows of a workgroup through a double-buffered LDS block
+// (4 x less L2 traffic) measured the same 15.4-16.0 ms at 16, 8 and 6 gates per wave: what bounds the kernel is
+// the per-wave latency of the decode's compare-and-branch chain (tools/ubench/issue_model.hip: ~19 cycles per
+// not-taken s_cmp + s_cbranch pair), not the row traffic.
+static constexpr int KS2_CHUNK = 128;  // digits staged per gate at a time
+
+// a += b in the SAME register: left to the compiler, the uniform branches below become renamed copies of every
+// sum and a move per sum on each path not taken (1.4 k v_mov per i).
+__device__ __forceinline__ void add_in_place(u32& a, u32 b) { asm volatile("v_add_u32 %0, %0, %1" : "+v"(a) : "v"(b)); }
+
+template <int T, int NC, int KSW_G>
+__global__ __launch_bounds__(256, (KSW_G > 10 ? 2 : KSW_G > 6 ? 3 : 4)) void keyswitch_wave_kernel(
+    const u32* __restrict__ rot, const KsJob* __restrict__ jobs, int njobs, const u32* __restrict__ ksk,
+    u32* __restrict__ arena, u32 n, u32 stride, u32 i_per_slice)
+{
+    constexpr u32 dbits = 2u * T;
+    constexpr u32 prec = 1u << (32 - (1 + dbits));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_ks[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    unsigned short* s_dig = reinterpret_cast<unsigned short*>(smem_ks) + wave * (KSW_G * KS2_CHUNK);  // [KSW_G][chunk], this wave's
+    const int gbase = blockIdx.x * (4 * KSW_G);
+    const u32 i0 = blockIdx.y * i_per_slice;
+    const u32 chunk = i_per_slice < (u32)KS2_CHUNK ? i_per_slice : (u32)KS2_CHUNK;
+    const u32 block_words = 3 * stride;
+    const u32 wl = 2u * (u32)lane;
+
+    // lane k < KSW_G holds the job of this wave's gate k = workgroup gate 4 k + wave
+    KsJob mine;
+    {
+        const int gi = gbase + 4 * (lane < KSW_G ? lane : 0) + wave;
+        mine = jobs[gi < njobs ? gi : njobs - 1];
+        if (gi >= njobs) mine.out = -1;
+    }
+    u32 acc[KSW_G][NC][2];
+#pragma unroll
+    for (int g = 0; g < KSW_G; ++g)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[g][c][0] = acc[g][c][1] = 0u;
+
+    const u32* blk = ksk + (size_t)i0 * T * block_words + wl;
+    const u32 stages = i_per_slice * T;
+    uint2 rn[3][NC];
+    auto fetch = [&](u32 s, uint2 (&r)[3][NC]) {
+        const u32* q = blk + (size_t)(s < stages ? s : stages - 1) * block_words;
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if ((c + 1) * 128 <= 256 || (u32)c * 128 + wl < stride)  // n + 1 > 256: the first two chunks are whole
+                    r[v][c] = *reinterpret_cast<const uint2*>(q + v * stride + c * 128);
+                else
+                    r[v][c] = make_uint2(0, 0);
+            }
+    };
+    fetch(0, rn);
+    u32 s = 0;
+    u32 dg[KSW_G];
+    for (u32 cb = 0; cb < i_per_slice; cb += chunk) {
+        lds_sync();
+#pragma unroll
+        for (int g = 0; g < KSW_G; ++g) {
+            const int ra = __builtin_amdgcn_readlane(mine.ra, g), rb = __builtin_amdgcn_readlane(mine.rb, g);
+            const int ok = __builtin_amdgcn_readlane(mine.out, g);
+            for (u32 k = (u32)lane; k < chunk; k += 64) {
+                u32 a = rot[(size_t)ra * (NTT_N + 1) + i0 + cb + k];
+                if (rb >= 0) a += rot[(size_t)rb * (NTT_N + 1) + i0 + cb + k];
+                a += prec;
+                s_dig[g * KS2_CHUNK + k] = ok >= 0 ? (unsigned short)(a >> (32 - dbits)) : (unsigned short)0;
+            }
+        }
+        lds_sync();
+#pragma unroll 1
+        for (u32 ii = 0; ii < chunk; ++ii) {
+            {
+                const u32 d = s_dig[(lane < KSW_G ? (u32)lane : 0u) * KS2_CHUNK + ii];
+#pragma unroll
+                for (int g = 0; g < KSW_G; ++g) dg[g] = __builtin_amdgcn_readlane(d, g);
+            }
+#pragma unroll
+            for (int j = 0; j < T; ++j, ++s) {
+                uint2 r[3][NC];
+#pragma unroll
+                for (int v = 0; v < 3; ++v)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) r[v][c] = rn[v][c];
+                fetch(s + 1, rn);
+                const u32 sh = 2u * (u32)(T - 1 - j);
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+#pragma unroll
+                    for (int g = 0; g < KSW_G; ++g) {
+                        if (((dg[g] >> sh) & 3u) == (u32)(v + 1)) {
+#pragma unroll
+                            for (int c = 0; c < NC; ++c) { add_in_place(acc[g][c][0], r[v][c].x); add_in_place(acc[g][c][1], r[v][c].y); }
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < KSW_G; ++g) {
+        const int out_slot = __builtin_amdgcn_readlane(mine.out, g);
+        if (out_slot < 0) continue;
+        u32* out = arena + (size_t)out_slot * ((size_t)n + 1);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const u32 w = (u32)c * 128 + wl;
+            if (w <= n) atomicSub(out + w, acc[g][c][0]);
+            if (w + 1 <= n) atomicSub(out + w + 1, acc[g][c][1]);
+        }
     }
 }
 

@@ -10,12 +10,18 @@ from iyokan_amd.params import OPS, PLAIN
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("path,kernel", [("fp50", "0"), ("fp50", "1"), ("fp50", "2"), ("fp50", "3"), ("goldilocks", None)])
-def test_80bit_gates_bit_exact(path, kernel, keys80, oracle80, monkeypatch):
+@pytest.mark.parametrize("path,kernel,ks", [("fp50", "0", None), ("fp50", "1", None), ("fp50", "2", None), ("fp50", "3", None),
+                                            ("goldilocks", None, None), ("fp50", None, "0")])
+def test_80bit_gates_bit_exact(path, kernel, ks, keys80, oracle80, monkeypatch):
     """Both exact-arithmetic paths at the 80-bit set: FP64 field with split digits (default; each of its
-    four rotation kernels forced in turn) and the 64-bit integer field (IYK_HIP_NTT=goldilocks)."""
+    four rotation kernels forced in turn) and the 64-bit integer field (IYK_HIP_NTT=goldilocks); the last case
+    forces the workgroup-per-16-gates key switch (the default is the wave-per-16-gates one, t = 8 / 4 chunks of 128 words)."""
     from iyokan_amd import hip
 
+    if ks is None:
+        monkeypatch.delenv("IYK_HIP_KS_KERNEL", raising=False)
+    else:
+        monkeypatch.setenv("IYK_HIP_KS_KERNEL", ks)
     if kernel is None:
         monkeypatch.delenv("IYK_HIP_LATENCY_KERNEL", raising=False)
     else:

@@ -274,6 +274,35 @@ def test_all_rotation_kernels_agree(gpu128, keys128, oracle128):
     assert np.array_equal(results["0"], ref)
 
 
+@pytest.mark.parametrize("ng", [1, 10, 64, 65, 300])
+def test_key_switch_kernels_agree(gpu128, keys128, oracle128, ng, monkeypatch):
+    """The two key-switch kernels (IYK_HIP_KS_KERNEL=0: 16 gates per workgroup, 3 words per thread; 1, the default:
+    16 gates and whole rows per wave, 64 gates per workgroup) subtract the same KSK rows mod 2^32: word-for-word
+    equal, at batch sizes below, at and above a workgroup's 64 gates, MUX included (two rotations summed before
+    the switch)."""
+    hip, st = gpu128
+    p = keys128.params
+    rng = np.random.default_rng(100 + ng)
+    nin = 32
+    bits = rng.integers(0, 2, size=nin).astype(np.uint8)
+    ops = rng.choice([OPS["NAND"], OPS["XOR"], OPS["MUX"], OPS["ANDNOT"]], size=ng).astype(np.int32)
+    in0, in1, in2 = (rng.integers(0, nin, size=ng).astype(np.int32) for _ in range(3))
+    in2 = np.where(ops == OPS["MUX"], in2, -1).astype(np.int32)
+    out = np.arange(nin, nin + ng, dtype=np.int32)
+    host = np.zeros((nin + ng, p.n + 1), dtype=np.uint32)
+    host[:nin] = client.encrypt_bits(keys128, bits, seed=78)
+    results = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("IYK_HIP_KS_KERNEL", mode)
+        results[mode] = _run(hip, st, host, ops, in0, in1, in2, out)
+    monkeypatch.delenv("IYK_HIP_KS_KERNEL")
+    assert np.array_equal(results["0"], results["1"])
+    sample = rng.choice(ng, size=min(ng, 24), replace=False)
+    ref = host.copy()
+    oracle128.gate_batch(ops[sample], in0[sample], in1[sample], in2[sample], out[sample], ref, nthreads=os.cpu_count() or 1)
+    assert np.array_equal(results["1"][out[sample]], ref[out[sample]])
+
+
 def test_in_place_outputs(gpu128, keys128, oracle128):
     """A gate may write its result over one of its own inputs (the reference's tasks own separate buffers, a
     device arena invites reuse): every input of a batch is consumed before any output is written, so the result

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU session M: full GPU suite (incl. two ranks on one GPU, MUX straddle, doHIP from files), smoke, default bench
 cd "$(dirname "$0")/.." && mkdir -p gpurun_out
-T=r02m
+T=${T:-r02m}
 timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > gpurun_out/${T}_pytest.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 > gpurun_out/${T}_smoke.txt
 timeout 900 python bench.py 2>gpurun_out/${T}_bench.err | tail -1 > gpurun_out/${T}_bench.json
