@@ -325,6 +325,18 @@ def main():
                 clk = pmc["sustained_clock_ghz"]
                 valu["sustained_clock_ghz"] = clk
                 valu["frac_at_sustained_clock"] = (4.0 / clk) / ns
+            if pmc.get("issue_ceiling"):                     # what pure instruction streams reach on this chip
+                ic = pmc["issue_ceiling"]
+                share = ic["valu_f64_share"]
+                mix2 = share * ic["fma64_ns_2_waves_per_simd"] + (1 - share) * ic["int32_ns_2_waves_per_simd"]
+                mix4 = share * ic["fma64_ns_4_waves_per_simd"] + (1 - share) * ic["int32_ns_4_waves_per_simd"]
+                valu["stream_ceiling"] = {
+                    "note": "ns per wave-instruction per SIMD of dependency-free v_fma_f64 / v_add_u32 streams in the "
+                            "kernel's FP64 : integer proportion (tools/ubench/valu_occ.hip, 10-26 ms runs); the kernel "
+                            "holds 2 waves per SIMD (256 VGPRs), where a pure FP64 stream issues 21 % slower than at 4",
+                    "mix_ns_2_waves_per_simd": mix2, "frac_of_2_wave_stream": mix2 / ns,
+                    "mix_ns_4_waves_per_simd": mix4, "frac_of_4_wave_stream": mix4 / ns,
+                }
             roofline["valu"] = valu
         line = {
             "metric": baseline_metric() if args.params == "128bit" else "TFHE gate bootstraps/sec (80-bit params)",
