@@ -399,8 +399,8 @@ void blind_rotate_fp_lat3(const iyk_params* p, const u32* lin, const double* bk_
                         }
                 }
                 for (int e = 0; e < 2; ++e) {
-                    sum[pair + e] = s0[e];
-                    sum[NTT_N + pair + e] = s1[e];
+                    sum[pair + e] = fp::norm(s0[e]);
+                    sum[NTT_N + pair + e] = fp::norm(s1[e]);
                 }
             }
         // inverse phase: polynomial c on waves (c, g), g = 0 -> waves 6, 7, g = 1 -> waves 4, 5; 8 points per lane
@@ -455,10 +455,10 @@ void blind_rotate_fp_lat3(const iyk_params* p, const u32* lin, const double* bk_
                 for (int rr = 0; rr < 8; rr += 2) {
                     const double* su = sum_c + (4 * half + rr / 2) * 64 + 2 * t;
                     const double* sv = su + 8 * 64;
-                    in[lane][rr] = fp::norm(su[0]);
-                    in[lane][rr + 1] = fp::norm(su[1]);
-                    in[lane][8 + rr] = fp::norm(sv[0]);
-                    in[lane][8 + rr + 1] = fp::norm(sv[1]);
+                    in[lane][rr] = su[0];
+                    in[lane][rr + 1] = su[1];
+                    in[lane][8 + rr] = sv[0];
+                    in[lane][8 + rr + 1] = sv[1];
                 }
             }
             dif8(wave, g, 1, in);

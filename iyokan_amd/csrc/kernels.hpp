@@ -1078,17 +1078,19 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
                     s0[0] = fp::norm(s0[0]); s0[1] = fp::norm(s0[1]); s1[0] = fp::norm(s1[0]); s1[1] = fp::norm(s1[1]);
                 }
             }
-            s_sum[pair] = s0[0];
-            s_sum[pair + 1] = s0[1];
-            s_sum[NTT_N + pair] = s1[0];
-            s_sum[NTT_N + pair + 1] = s1[1];
+            // renormalised here, four values on each of the eight waves, not as sixteen on the inverse waves' critical path
+            s_sum[pair] = fp::norm(s0[0]);
+            s_sum[pair + 1] = fp::norm(s0[1]);
+            s_sum[NTT_N + pair] = fp::norm(s1[0]);
+            s_sum[NTT_N + pair + 1] = fp::norm(s1[1]);
         }
         IYK_TRACE(6);
         wg_barrier_lds();  // both sums are complete
-        // next step's key rows, off the critical path: the waves with no inverse work issue theirs now (in flight during the
-        // inverse phase), the inverse waves after their transform (in flight during the next forward phase).  Issued before
-        // barrier 2 by everyone, 8 x 12 KiB through the CU's one texture path took 1.5 k cycles of the MAC phase; issued
-        // right after it, they delayed the inverse waves by as much.
+        // next step's key rows, off the critical path: the waves with no inverse work issue theirs now, the inverse waves
+        // after their first pass, when the texture path has drained the first four waves' 48 KiB (in flight during pass 2
+        // and the accumulator update).  Issued before barrier 2 by everyone, 8 x 12 KiB through the CU's one texture path
+        // took 1.5 k cycles of the MAC phase; issued right after it, they delayed the inverse waves by as much; issued
+        // after the accumulator update, they kept the inverse waves 0.6 k cycles from the step's last barrier.
         if (!inv && i + 1 < n) load_bk(i + 1);
         // ---- inverse of sum_c -> accumulator polynomial c, on waves (c, g): 8 points per lane (blind_rotate_lat3.hpp)
         double e[8];
@@ -1101,10 +1103,10 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
             for (int r = 0; r < 8; r += 2) {
                 const double* su = sum_c + (4 * half + r / 2) * 64 + 2 * t;
                 const double* sv = su + 8 * 64;
-                u[r] = fp::norm(su[0]);
-                u[r + 1] = fp::norm(su[1]);
-                vv[r] = fp::norm(sv[0]);
-                vv[r + 1] = fp::norm(sv[1]);
+                u[r] = su[0];
+                u[r + 1] = su[1];
+                vv[r] = sv[0];
+                vv[r + 1] = sv[1];
             }
             IYK_TRACE(7);
             fp::dif8_stage0<fp::PASS1>(u, vv, g_inv, half, tw0g, e);
@@ -1115,6 +1117,7 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
 #pragma unroll
             for (int q = 0; q < 8; ++q) xbI[fp::inv8(g_inv, half, q) * XB_STRIDE + t] = fp::mulmod(e[q], twi8[q]);
             IYK_TRACE(8);
+            if (i + 1 < n) load_bk(i + 1);  // the other waves' loads (issued after barrier 2) have drained by now
         }
         wg_barrier_lds();  // both waves of a polynomial have written its transposed matrix
         if (inv) {
@@ -1138,7 +1141,6 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
                 __hip_atomic_fetch_add(acc_c + t + 32 * fp::inv8(g_inv, half, q), fp::inv2_post16(e[q], zi8[q]), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WAVEFRONT);
             IYK_TRACE(11);
-            if (i + 1 < n) load_bk(i + 1);
         }
         wg_barrier_lds();  // accumulator of step i is complete before anyone derives step i+1's digits
         IYK_TRACE(12);
