@@ -4,11 +4,13 @@
 //   per batch   modswitch_kernel                      linear step + mod-switch of every rotation -> abar[job][n+1]
 //               blind_rotate_fp_kernel<Decomp>        one wavefront per rotation, FP64 field (fp50.hpp): default
 //               blind_rotate_fp_lat3_kernel<Decomp>   one rotation per workgroup of 8 wavefronts (16 / 8 points per lane): narrow
-//                                                     frontiers, <= 1024 rotations (3.7-4.0 ms per rotation instead of 20)
+//                                                     frontiers, <= 1024 rotations (3.6-3.9 ms per rotation instead of 20)
 //               blind_rotate_fp_lat_kernel<Decomp>, blind_rotate_fp_lat2_kernel<Decomp>   round 1's 3- and 6-wave variants (A/B)
 //               blind_rotate_kernel<L,BGBIT>          one wavefront per rotation, Goldilocks integers (IYK_HIP_NTT=goldilocks)
 //               sample_extract_kernel                 TRLWE -> TLWE lvl1 (CMUX-memory helper entry point only)
-//               keyswitch_init_kernel + keyswitch_kernel   lvl1 -> lvl0 identity key switch, 16 gates per workgroup
+//               keyswitch_init_kernel + keyswitch_wave_kernel<T,NC,16>   lvl1 -> lvl0 identity key switch, 16 gates and whole rows
+//                                                     per wavefront (keyswitch_kernel<T>: round 1's 16 gates per workgroup, A/B + fallback)
+//               gather_slots_kernel / scatter_slots_kernel   bulk slot I/O
 //               elementwise_kernel                    NOT / COPY / CONSTONE / CONSTZERO on arena slots
 //
 // Replaces cufhe's device code behind cufhe::Initialize and cufhe::{And..Mux,Not}<lvl0param>
