@@ -85,7 +85,7 @@ struct Global {
     u32 ksk_stride = 0;
     int ks_kernel = 1;    // 1: keyswitch_wave_kernel where instantiated, 0: keyswitch_kernel (IYK_HIP_KS_KERNEL)
     bool use_fp = false;          // FP64 path (fp50.hpp) instead of Goldilocks integers
-    int lat_threshold = 1024;     // rotations per batch at or below which a workgroup-per-rotation kernel is used
+    int lat_threshold = 1280;     // rotations per batch at or below which a workgroup-per-rotation kernel is used
     int lat_kernel = 3;           // which one: 1 = wave per level, 2 = two waves per level, 3 = wave per (polynomial, level)
     fp::NttConsts fpc{};
     std::vector<Device> devs;
@@ -260,9 +260,9 @@ int dispatch_fp(iyk_hip_stream* st, int njobs, const RotOut& o)
     const int rem = njobs % round, full = njobs - rem;
     if (rem > G.lat_threshold) return launch_br_fp<DC>(st, 0, njobs, o);
     if (full && (rc = launch_br_fp<DC>(st, 0, full, o))) return rc;
-    // The 8-wave kernel (lat_kernel, default 3) takes one CU per rotation: 4.4 ms per 256 rotations, in sequence (8.6 / 12.8 /
-    // 17.1 ms for 512 / 768 / 1024) — ahead of the 3-wave kernel (6.1 / 9.3 / 13.9 / 17.5 ms) everywhere; above 1024 a whole
-    // round of the wave-per-rotation kernel (19.9 ms) is the fastest (profiles/r02_sweep_kernels.txt).
+    // The 8-wave kernel (lat_kernel, default 3) takes one CU per rotation: 3.6-4.0 ms per 256 rotations, in sequence (7.5 /
+    // 11.1 / 14.6 / 18.5 ms for 512 / 768 / 1024 / 1280) — ahead of the 3-wave kernel (6.1 / 9.4 / 13.8 / 17.6 ms) everywhere;
+    // above 1280 a whole round of the wave-per-rotation kernel (19.9 ms) is the fastest (profiles/r02_sweep_kernels_v7.txt).
     if (rem) return launch_br_fp_lat_any<DC>(st, G.lat_kernel, full, rem, o);
     return IYK_OK;
 }

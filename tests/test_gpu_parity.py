@@ -344,11 +344,11 @@ def test_repeated_batches_are_bit_identical(gpu128, keys128):
     assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])
 
 
-@pytest.mark.parametrize("rem", [100, 300])
+@pytest.mark.parametrize("rem", [100, 300, 1200, 1400])
 def test_mid_size_batch_uses_both_kernels(gpu128, keys128, rem):
-    """2048 + rem rotations: full round on the wave-per-rotation kernel, remainder on a low-latency kernel
-    (two waves per level for rem <= 256, one wave per level above); every output must decrypt correctly
-    (size-independent property) and inputs stay untouched."""
+    """2048 + rem rotations: full round on the wave-per-rotation kernel, a remainder of up to 1280 on the
+    workgroup-per-rotation kernel (one to five passes of 256), a larger one as a second wave-per-rotation round; every
+    output must decrypt correctly (size-independent property) and inputs stay untouched."""
     hip, st = gpu128
     rng = np.random.default_rng(43)
     nin, ng = 512, 2048 + rem
