@@ -127,3 +127,28 @@ class OracleBackend:
 
     def sync(self):
         pass
+
+
+def adversarial_rows(n, seed=9):
+    """TLWE-shaped rows of n + 1 words that no encryption would produce but the deterministic pipeline must still map
+    identically everywhere: all-ones, the sign bit, the mod-switch rounding threshold and its neighbours (a' = (a +
+    2^20) >> 21 for N = 1024), alternating extremes, a single non-zero coefficient, and uniform words.  Parity between
+    the oracle's restatements and the HIP kernels on these rows exercises digit extremes (-Bg/2, Bg/2 - 1), exponent
+    wrap-around (abar = 0, 2N - 1) and skipped CMUX steps without relying on how likely fresh ciphertexts hit them."""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    rows = [
+        np.full(n + 1, 0xFFFFFFFF, dtype=np.uint32),
+        np.full(n + 1, 0x80000000, dtype=np.uint32),
+        np.full(n + 1, 0x000FFFFF, dtype=np.uint32),            # just below the rounding threshold: abar = 0 everywhere
+        np.full(n + 1, 0x00100000, dtype=np.uint32),            # exactly on it: abar = 1
+        np.full(n + 1, 0xFFF00000, dtype=np.uint32),            # rounds up to 2N: abar wraps to 0
+        np.where(np.arange(n + 1) % 2 == 0, 0, 0xFFFFFFFF).astype(np.uint32),
+        np.zeros(n + 1, dtype=np.uint32),
+        rng.integers(0, 2**32, size=n + 1, dtype=np.uint64).astype(np.uint32),
+        rng.integers(0, 2**32, size=n + 1, dtype=np.uint64).astype(np.uint32),
+    ]
+    rows[6][n // 2] = 0x7FE00000                                # one coefficient, abar = 1023
+    rows[6][n] = 0x40000000
+    return np.stack(rows)

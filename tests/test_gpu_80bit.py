@@ -67,6 +67,48 @@ def test_80bit_gates_bit_exact(path, kernel, ks, keys80, oracle80, monkeypatch):
     assert list(client.decrypt_bits(keys80, got[16:])) == want
 
 
+@pytest.mark.parametrize("path", ["fp50", "goldilocks"])
+def test_80bit_adversarial_rows(path, keys80, oracle80, monkeypatch):
+    """Rows no encryption produces (oracle_lib.adversarial_rows) at the 80-bit set, split-digit FP64 field and
+    Goldilocks integers: oracle words (digit extremes of the 10-bit decomposition and of its 5-bit halves)."""
+    import oracle_lib
+    from iyokan_amd import hip
+
+    monkeypatch.delenv("IYK_HIP_LATENCY_KERNEL", raising=False)
+    monkeypatch.delenv("IYK_HIP_KS_KERNEL", raising=False)
+    if path == "goldilocks":
+        monkeypatch.setenv("IYK_HIP_NTT", "goldilocks")
+    else:
+        monkeypatch.delenv("IYK_HIP_NTT", raising=False)
+    p = keys80.params
+    rows = oracle_lib.adversarial_rows(p.n)
+    nin = rows.shape[0]
+    kinds = ["NAND", "XOR", "MUX", "ANDNOT", "MUX", "XNOR", "OR", "NAND", "MUX"]
+    ops = [OPS[k] for k in kinds]
+    in0 = list(range(nin))
+    in1 = [(i + 1) % nin for i in range(nin)]
+    in2 = [(i + 4) % nin if k == "MUX" else -1 for i, k in enumerate(kinds)]
+    out = list(range(nin, 2 * nin))
+    host = np.zeros((2 * nin, p.n + 1), dtype=np.uint32)
+    host[:nin] = rows
+    hip.initialize(keys80, device_ids=(0,))
+    try:
+        assert hip.ntt_path() == path
+        st = hip.Stream(0)
+        arena = hip.Arena(host.shape[0])
+        st.upload(arena, 0, host)
+        st.gate_batch(arena, ops, in0, in1, in2, out)
+        st.sync()
+        got = st.download(arena, 0, host.shape[0])
+        arena.free()
+        st.destroy()
+    finally:
+        hip.cleanup()
+    ref = host.copy()
+    oracle80.gate_batch(ops, in0, in1, in2, out, ref, nthreads=os.cpu_count() or 1)
+    assert np.array_equal(got, ref)
+
+
 def test_80bit_full_size_flat_nand_property(keys80, oracle80):
     """BASELINE config #5 shape at full size: 65 536 independent NANDs at the 80-bit set; every output decrypts to
     the NAND of its plaintexts, and a 32-gate sample is bit-equal to the oracle."""

@@ -303,6 +303,36 @@ def test_key_switch_kernels_agree(gpu128, keys128, oracle128, ng, monkeypatch):
     assert np.array_equal(results["1"][out[sample]], ref[out[sample]])
 
 
+def test_adversarial_rows_bit_exact_on_every_kernel(gpu128, keys128, oracle128, monkeypatch):
+    """Rows no encryption produces (all-ones, sign bit, mod-switch rounding threshold either side, one non-zero
+    coefficient, uniform words; oracle_lib.adversarial_rows): every rotation kernel and both key-switch kernels must
+    map them to the oracle's words — digit extremes, exponent wrap-around and skipped CMUX steps, deterministically."""
+    import oracle_lib
+
+    hip, st = gpu128
+    p = keys128.params
+    rows = oracle_lib.adversarial_rows(p.n)
+    nin = rows.shape[0]
+    kinds = ["NAND", "XOR", "MUX", "ANDNOT", "MUX", "XNOR", "OR", "NAND", "MUX"]
+    ops = np.array([OPS[k] for k in kinds], dtype=np.int32)
+    in0 = np.arange(nin, dtype=np.int32)
+    in1 = ((in0 + 1) % nin).astype(np.int32)
+    in2 = np.array([(i + 4) % nin if k == "MUX" else -1 for i, k in enumerate(kinds)], dtype=np.int32)
+    out = np.arange(nin, 2 * nin, dtype=np.int32)
+    host = np.zeros((2 * nin, p.n + 1), dtype=np.uint32)
+    host[:nin] = rows
+    ref = host.copy()
+    oracle128.gate_batch(ops, in0, in1, in2, out, ref, nthreads=os.cpu_count() or 1)
+    for lat in ("0", "1", "2", "3"):
+        for ks in ("0", "1"):
+            monkeypatch.setenv("IYK_HIP_LATENCY_KERNEL", lat)
+            monkeypatch.setenv("IYK_HIP_KS_KERNEL", ks)
+            got = _run(hip, st, host, ops, in0, in1, in2, out)
+            assert np.array_equal(got, ref), (lat, ks)
+    monkeypatch.delenv("IYK_HIP_LATENCY_KERNEL")
+    monkeypatch.delenv("IYK_HIP_KS_KERNEL")
+
+
 def test_in_place_outputs(gpu128, keys128, oracle128):
     """A gate may write its result over one of its own inputs (the reference's tasks own separate buffers, a
     device arena invites reuse): every input of a batch is consumed before any output is written, so the result

@@ -67,3 +67,29 @@ def test_emulated_fp64_path_bit_exact(which, request):
                                                 got3.ctypes.data_as(u32p)) == 0
         assert np.array_equal(ref, got3)
     assert em.iyk_emul_fp_max_magnitude() < 0.95 * 2.0 ** 53 / 844424931229697
+
+
+@pytest.mark.parametrize("which", ["128", "80"])
+def test_emulated_kernels_on_adversarial_rows(which, request):
+    """The lane-by-lane emulations of the wave-per-rotation and the workgroup-per-rotation FP64 kernels on rows no
+    encryption produces (all-ones, rounding threshold, one non-zero coefficient, uniform words): oracle words, and the
+    lazily-reduced magnitudes still inside the exact range."""
+    import oracle_lib
+
+    keys = request.getfixturevalue("keys" + which)
+    orc = request.getfixturevalue("oracle" + which)
+    p = keys.params
+    em = _emul()
+    em.iyk_emul_fp_max_magnitude.restype = ctypes.c_double
+    dp = ctypes.POINTER(ctypes.c_double)
+    bk = np.zeros(p.bk_words * (2 if p.l == 2 else 1), dtype=np.float64)
+    assert em.iyk_emul_bk_ntt_fp(ctypes.byref(p), keys.bk.ctypes.data_as(u32p), bk.ctypes.data_as(dp)) == 0
+    rows = oracle_lib.adversarial_rows(p.n)
+    for r in (0, 3, 6, 7):
+        lin = np.ascontiguousarray(rows[r])
+        ref = orc.bootstrap_lvl1(lin)
+        for fn in (em.iyk_emul_blind_rotate_fp, em.iyk_emul_blind_rotate_fp_lat3):
+            got = np.zeros(p.N + 1, dtype=np.uint32)
+            assert fn(ctypes.byref(p), lin.ctypes.data_as(u32p), bk.ctypes.data_as(dp), got.ctypes.data_as(u32p)) == 0
+            assert np.array_equal(ref, got), (r, fn)
+    assert em.iyk_emul_fp_max_magnitude() < 0.95 * 2.0 ** 53 / 844424931229697

@@ -128,3 +128,25 @@ def test_fp_restatement_equals_goldilocks_restatement(keys128, oracle128, keys80
     oracle128.gate_batch(ops, in0b, in1b, in2b, out2, a, nthreads=nt, mode="goldilocks")
     oracle128.gate_batch(ops, in0b, in1b, in2b, out2, b, nthreads=nt, mode="fp")
     assert np.array_equal(a, b)
+
+
+def test_adversarial_rows_same_words_in_both_restatements(keys128, oracle128):
+    """Rows no encryption produces (oracle_lib.adversarial_rows): the Goldilocks and the FP64-field restatements
+    must still agree word for word — the pipeline is a deterministic map on u32 vectors, valid ciphertext or not."""
+    p = keys128.params
+    rows = oracle_lib.adversarial_rows(p.n)
+    nin = rows.shape[0]
+    kinds = ["NAND", "XOR", "MUX", "ANDNOT", "MUX", "XNOR", "OR", "NAND", "MUX"]
+    ops = [OPS[k] for k in kinds]
+    in0 = list(range(nin))
+    in1 = [(i + 1) % nin for i in range(nin)]
+    in2 = [(i + 4) % nin if k == "MUX" else -1 for i, k in enumerate(kinds)]
+    out = list(range(nin, 2 * nin))
+    a = np.zeros((2 * nin, p.n + 1), dtype=np.uint32)
+    a[:nin] = rows
+    b = a.copy()
+    nt = os.cpu_count() or 1
+    oracle128.gate_batch(ops, in0, in1, in2, out, a, nthreads=nt, mode="goldilocks")
+    oracle128.gate_batch(ops, in0, in1, in2, out, b, nthreads=nt, mode="fp")
+    assert np.array_equal(a, b)
+    assert len({a[nin + i].tobytes() for i in range(nin)}) == nin      # nine different outputs: nothing degenerate
