@@ -256,3 +256,43 @@ def test_cmux_memory_entry_points_256_jobs(gpu, keys128, oracle128):
     assert L.iyk_hip_trlwe_free(0, d_trlwe) == 0
     arena.free()
     st.destroy()
+
+
+@pytest.mark.parametrize("ks", ["0", "1"])
+def test_extract_keyswitch_on_arbitrary_trlwe_words(gpu, keys128, oracle128, ks, monkeypatch):
+    """SampleExtractAndKeySwitch on TRLWE cells no bootstrap produces — all-ones (every key-switch digit 3), the sign
+    bit, just below the rounding offset (every digit 0: no row subtracted), alternating extremes, uniform words — with
+    each key-switch kernel: the oracle's sample-extract + key-switch words."""
+    import ctypes as C
+
+    import oracle_lib
+
+    monkeypatch.setenv("IYK_HIP_KS_KERNEL", ks)
+    st = gpu.Stream(0)
+    p = keys128.params
+    rng = np.random.default_rng(67)
+    cells = 70                                            # more than one workgroup of 64 gates
+    img = rng.integers(0, 2**32, size=(cells, 2 * p.N), dtype=np.uint64).astype(np.uint32)
+    img[0] = 0xFFFFFFFF
+    img[1] = 0x80000000
+    img[2] = (1 << (32 - 1 - 2 * p.t)) - 1                # a + prec stays below the first digit: nothing to subtract
+    img[3] = np.where(np.arange(2 * p.N) % 2 == 0, 0, 0xFFFFFFFF)
+    img[4] = 0
+    L = gpu.lib()
+    u32p = C.POINTER(C.c_uint32)
+    d_trlwe = C.c_void_p()
+    assert L.iyk_hip_trlwe_alloc(0, cells, C.byref(d_trlwe)) == 0
+    assert L.iyk_hip_trlwe_upload(st.h, d_trlwe, cells, 0, cells, img.ctypes.data_as(u32p)) == 0
+    arena = gpu.Arena(cells)
+    order = rng.permutation(cells).astype(np.int32)       # cell order[j] -> slot j
+    st.sample_extract_keyswitch_batch(d_trlwe.value, order, np.arange(cells), arena, trlwe_slots=cells)
+    st.sync()
+    got = st.download(arena, 0, cells)
+    for j in range(cells):
+        t1 = np.zeros(p.N + 1, dtype=np.uint32)
+        acc = np.ascontiguousarray(img[order[j]])
+        oracle_lib.lib().orc_sample_extract0(oracle128.ctx, acc.ctypes.data_as(u32p), t1.ctypes.data_as(u32p))
+        assert np.array_equal(got[j], oracle128.keyswitch(t1)), j
+    assert L.iyk_hip_trlwe_free(0, d_trlwe) == 0
+    arena.free()
+    st.destroy()
