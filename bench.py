@@ -5,8 +5,9 @@ Workload (BASELINE.json configs[1], SURVEY.md §8d "Config 2"): a flat DAG of 65
 HomNAND gates at the 128-bit parameter set, inputs are FRESH encryptions (never trivial
 ciphertexts, which skip every CMUX).  One "step" = one pass of the hot path over the whole
 batch: iyk_hip_gate_batch -> {blind_rotate kernel, keyswitch kernel}, inputs and keys already
-resident in HBM.  With N > 1 (one process per GPU, launched by torch.distributed.run) the SAME
-65 536-gate batch is sharded over the ranks (8 192 gates per GPU at N = 8), with no
+resident in HBM.  With N > 1 — one process per GPU: either the driver launches the ranks with
+torch.distributed.run, or `python bench.py --gpus N` alone re-executes itself under it (launcher(): 127.0.0.1
+rendezvous on a free port) — the SAME 65 536-gate batch is sharded over the ranks (8 192 gates per GPU at N = 8), with no
 data-path collective for a flat DAG: "scaling": "strong".  The weak-scaling figure (every rank its own
 65 536 gates) is measured right after and reported as the extra field "weak".  The key material is
 generated on rank 0 and broadcast once over RCCL.
@@ -16,11 +17,17 @@ what the counters say beside it: the kernel is bound by FP64 VALU issue, `roofli
 instruction count (SQ_INSTS_VALU pass committed under profiles/) against 4 cycles per wave-instruction per
 SIMD, and `traffic_over_algorithmic` shows the key stream is served by L2.
 
+A run never reports fewer GPUs than it was asked for: `--gpus N` with fewer than N visible devices, or with a
+WORLD_SIZE that is not N, exits non-zero before anything is timed (the reference takes --num-gpu the same way:
+/root/reference/src/main.cpp:147-148 -> iyokan_cufhe.cpp:530-536).
+
 Prints ONE JSON line on rank 0 (see README of the contract in DESIGN.md §Measurement).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -48,6 +55,8 @@ def parse_args():
                     help="binary gate of the flat batch (BASELINE config #2 is NAND)")
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="gates timed on the CPU oracle for cpu_baseline (-1: sized for ~15 s, 0: skip)")
+    ap.add_argument("--spawn", action="store_true",
+                    help="re-execute under torch.distributed.run even for --gpus 1 (exercises the RCCL path on one GPU)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="measured HBM bytes per blind_rotate launch from a separate rocprofv3 --pmc pass")
     return ap.parse_args()
@@ -187,27 +196,76 @@ def cpu_baseline(keys, params, op_code, sample, data_seed, budget_s=24.0):
             "ms_per_gate_per_thread": threads / rate * 1e3}
 
 
+EXIT_BAD_WORLD = 3   # --gpus does not match the ranks that exist / the devices that are visible
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher(args, script=None, argv=None, visible_gpus=None):
+    """Make sure this process is one of exactly args.gpus ranks, one per GPU.
+
+    * Under a launcher (RANK / WORLD_SIZE in the environment): WORLD_SIZE must equal --gpus, else exit EXIT_BAD_WORLD.
+    * Stand-alone with --gpus N > 1 (or --spawn): check that N devices are visible, then re-execute this script under
+      `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` and
+      exit with its status — so `python bench.py --gpus 8` is a complete 8-GPU run, never a silent 1-GPU one.
+    * Stand-alone with --gpus 1: nothing to do.
+    Returns (rank, world, local_rank, distributed)."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None:
+        if args.gpus < 1:
+            print(f"bench: --gpus {args.gpus} is not a GPU count", file=sys.stderr)
+            sys.exit(EXIT_BAD_WORLD)
+        if args.gpus == 1 and not getattr(args, "spawn", False):
+            return 0, 1, 0, False
+        if visible_gpus is None:
+            import torch
+
+            visible_gpus = torch.cuda.device_count()
+        if visible_gpus < args.gpus:
+            print(f"bench: --gpus {args.gpus} but only {visible_gpus} GPU(s) visible; refusing to run on fewer", file=sys.stderr)
+            sys.exit(EXIT_BAD_WORLD)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+               script or os.path.abspath(sys.argv[0])] + list(sys.argv[1:] if argv is None else argv)
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+        sys.exit(subprocess.call(cmd, env=env))
+    world = int(env_world)
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to report a "
+                  f"{args.gpus}-GPU number from {world} rank(s)", file=sys.stderr)
+        sys.exit(EXIT_BAD_WORLD)
+    return rank, world, int(os.environ.get("LOCAL_RANK", "0")), True
+
+
 def main():
     args = parse_args()
+    rank, world, local_rank, distributed = launcher(args)
     import torch
     import torch.distributed as dist
 
     from iyokan_amd import client, hip
     from iyokan_amd.params import OPS, PLAIN, params_by_name
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+    if torch.cuda.device_count() <= local_rank:
+        print(f"bench: rank {rank} wants cuda:{local_rank} but {torch.cuda.device_count()} device(s) are visible", file=sys.stderr)
+        sys.exit(EXIT_BAD_WORLD)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if distributed:   # also with one rank (--spawn): the RCCL communicator, broadcast and reductions run for real
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            print(f"bench: RCCL sees {dist.get_world_size()} rank(s), --gpus {args.gpus}", file=sys.stderr)
+            sys.exit(EXIT_BAD_WORLD)
 
     params = params_by_name(args.params)
     op_code = OPS[args.op]
@@ -217,7 +275,7 @@ def main():
 
     # ---- keys: rank 0 generates, RCCL broadcast (north_star: "bootstrapping key broadcast once") ----
     keys = client.keygen(params, seed=1) if rank == 0 else empty_keys(params)
-    if world > 1:
+    if distributed:
         keys = broadcast_keys(keys, dist, dev, rank)
     hip.initialize(keys, device_ids=(local_rank,))
 
@@ -239,7 +297,7 @@ def main():
                 idx + 2 * G_alloc)
 
     def fence():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -257,13 +315,17 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
         nb, br_ms, ks_ms = st.timing_log_end()
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        return elapsed, nb, br_ms, ks_ms
+        per_rank = [elapsed]
+        if distributed:
+            mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            every = torch.zeros(world, dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(every, mine)
+            dist.all_reduce(mine, op=dist.ReduceOp.MAX)
+            elapsed = float(mine.item())
+            per_rank = [float(v) for v in every.cpu()]
+        return elapsed, nb, br_ms, ks_ms, per_rank
 
-    elapsed, nb, br_ms, ks_ms = timed(G_mine, args.steps, args.warmup)
+    elapsed, nb, br_ms, ks_ms, per_rank = timed(G_mine, args.steps, args.warmup)
 
     # ---- correctness of what was just timed: decrypt every output of the last step ----
     got = arena_t[2 * G_alloc: 2 * G_alloc + G_mine].cpu().numpy().view(np.uint32)
@@ -273,7 +335,7 @@ def main():
 
     weak = None
     if world > 1 and not args.no_weak:
-        w_elapsed, _, _, _ = timed(G_total, args.steps, 1)
+        w_elapsed, _, _, _, _ = timed(G_total, args.steps, 1)
         weak = {"value": G_total * world * args.steps / w_elapsed, "unit": "gates/s",
                 "gates_per_step_per_gpu": G_total, "ms_per_step": w_elapsed / args.steps * 1e3, "scaling": "weak"}
 
@@ -346,6 +408,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "per_rank_ms_per_step": [v / args.steps * 1e3 for v in per_rank],
+            "rccl_world_size": dist.get_world_size() if distributed else None,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -373,7 +437,7 @@ def main():
     st.destroy()
     del arena, arena_t
     hip.cleanup()
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
     if not decrypt_ok:
         raise SystemExit("decrypt check failed")

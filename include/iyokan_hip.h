@@ -227,14 +227,21 @@ int iyk_hip_timing_log_end(iyk_hip_stream* st, uint64_t* batches, double* blind_
  * integers (forced with the environment variable IYK_HIP_NTT=goldilocks at init, or chosen when a
  * parameter set does not meet the FP64 field's exactness bound).  Both give identical ciphertexts.
  *
- * A/B knob for tests and measurements, read at every batch: IYK_HIP_LATENCY_KERNEL = 0 / 1 / 2 / 3 forces the
- * wave-per-rotation kernel or one of the workgroup-per-rotation kernels (1: wave per level, 2: two waves per
- * level, 3: wave per (polynomial, level) — the default for narrow frontiers); unset = chosen by batch size
- * (DESIGN.md section 6).  IYK_HIP_LATENCY_DEFAULT = 1 / 2 / 3 at init changes which of them the size-based
- * dispatch uses.  IYK_HIP_KS_KERNEL = 0 / 1, also read at every batch, forces the key switch with 16 gates per
- * workgroup (3 words per thread) or the one with 16 gates per wave (whole rows per wave; the default where
- * instantiated); both subtract the same rows mod 2^32, so they agree word for word. */
+ * A/B knobs for tests and measurements.  Read at every batch: IYK_HIP_ROT_KERNEL = t16 / w32 / lat3 forces one
+ * rotation kernel — t16: a wave per rotation, 16 points per lane, 3 waves per SIMD (the default for full rounds);
+ * w32: a wave per rotation, 32 points per lane, 2 waves per SIMD (round 1-2's kernel); lat3: a workgroup of 8 waves
+ * per rotation (the default for narrow frontiers).  Unset = chosen by batch size.
+ * IYK_HIP_LATENCY_KERNEL = 0 / 3 is the older spelling of w32 / lat3.  Read at init: IYK_HIP_TP_KERNEL = t16 / w32,
+ * the wave-per-rotation kernel the size-based dispatch uses.  IYK_HIP_KS_KERNEL = 0 / 1, read at every batch, forces
+ * the key switch with 16 gates per workgroup (3 words per thread) or the one with 16 gates per wave (whole rows per
+ * wave; the default where instantiated); both subtract the same rows mod 2^32, so they agree word for word. */
 int iyk_hip_ntt_path(void);
+
+/* Rotations one full round of the default wave-per-rotation kernel holds on GPU `gpu_index` (resident waves: 11 per
+ * CU for t16, 8 per CU for w32).  A scheduler that can choose its batch sizes does best with multiples of it; the
+ * remainder of a batch goes to the workgroup-per-rotation kernel (<= 1280 rotations) or one more partial round.
+ * < 0 on error.  (cuFHE has no counterpart: it launches one gate per stream, /root/reference/src/iyokan_cufhe.hpp:249-258.) */
+int iyk_hip_rotation_round(int gpu_index);
 
 /* Bytes of device memory holding keys on one GPU (NTT-domain BK + padded KSK + tables). */
 int iyk_hip_resident_key_bytes(uint64_t* out);

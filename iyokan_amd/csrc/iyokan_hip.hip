@@ -25,6 +25,7 @@
 
 #include "../../include/iyokan_hip.h"
 #include "kernels.hpp"
+#include "kernels_t16.hpp"
 
 using namespace iyk;
 
@@ -56,6 +57,7 @@ constexpr int MAX_GPUS = 64;
 
 struct Device {
     int ordinal = -1;
+    int cus = 256;           // compute units (one wave-per-rotation workgroup each)
     u64* bk_ntt = nullptr;   // NTT-domain BK: u64 residues mod 2^64-2^32+1, or doubles mod p = 3*2^48+1097729 (fp path)
     u32* ksk = nullptr;
     u64* tw_fwd = nullptr;   // u64 or double tables, same size
@@ -86,7 +88,7 @@ struct Global {
     int ks_kernel = 1;    // 1: keyswitch_wave_kernel where instantiated, 0: keyswitch_kernel (IYK_HIP_KS_KERNEL)
     bool use_fp = false;          // FP64 path (fp50.hpp) instead of Goldilocks integers
     int lat_threshold = 1280;     // rotations per batch at or below which a workgroup-per-rotation kernel is used
-    int lat_kernel = 3;           // which one: 1 = wave per level, 2 = two waves per level, 3 = wave per (polynomial, level)
+    int tp_kernel = 32;           // wave-per-rotation kernel: 32 = blind_rotate_fp_kernel (2 waves / SIMD), 16 = blind_rotate_fp_t16_kernel (3 waves / SIMD)
     fp::NttConsts fpc{};
     std::vector<Device> devs;
     std::atomic<int> nstreams{0};
@@ -216,54 +218,74 @@ int launch_br_fp(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
     return IYK_OK;
 }
 
-// narrow frontiers: one rotation per workgroup (kernels.hpp).  KIND 1: LV waves, wave = gadget level;
-// KIND 2: 2 LV waves, wave = (level, half of every DIF); KIND 3: 2 LV waves, wave = (polynomial, level).
-template <class DC, int KIND>
-int launch_br_fp_wg(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
+// the three-waves-per-SIMD wave-per-rotation kernel (kernels_t16.hpp): one workgroup of BR_T16_WAVES waves per CU, jobs
+// dealt round-robin to the resident waves
+template <class DC>
+int launch_br_fp_t16(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
 {
     const Device& D = G.devs[st->gpu];
-    constexpr int L = DC::LV;
-    const u32* abar = (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE;
-    if (KIND == 1)
-        hipLaunchKernelGGL(blind_rotate_fp_lat_kernel<DC>, dim3((unsigned)njobs), dim3(64 * L), br_lat_lds_bytes<L>(), st->s,
-                           abar, njobs, (const double*)D.bk_ntt, (const double*)D.tw_fwd, (const double*)D.tw_inv, D.fpc,
-                           o.at(first), G.p.n, G.p.mu, ABAR_STRIDE, o.trlwe, o.idx(first));
-    else if (KIND == 2)
-        hipLaunchKernelGGL(blind_rotate_fp_lat2_kernel<DC>, dim3((unsigned)njobs), dim3(128 * L), BrLat2Lds<L>::BYTES, st->s,
-                           abar, njobs, (const double*)D.bk_ntt, (const double*)D.tw_fwd, (const double*)D.tw_inv, D.fpc,
-                           o.at(first), G.p.n, G.p.mu, ABAR_STRIDE, o.trlwe, o.idx(first));
-    else
-        hipLaunchKernelGGL(blind_rotate_fp_lat3_kernel<DC>, dim3((unsigned)njobs), dim3(BrLat3<DC>::THREADS), BrLat3<DC>::LDS_BYTES,
-                           st->s, abar, njobs, (const double*)D.bk_ntt, (const double*)D.tw_fwd, (const double*)D.tw_inv, D.fpc,
-                           o.at(first), G.p.n, G.p.mu, ABAR_STRIDE, o.trlwe, o.idx(first));
+    typedef BrT16<BR_T16_WAVES> M;
+    const int groups = (njobs + M::WAVES - 1) / M::WAVES;
+    dim3 grid((unsigned)(groups < D.cus ? groups : D.cus)), block(M::THREADS);
+    hipLaunchKernelGGL((blind_rotate_fp_t16_kernel<DC, BR_T16_WAVES>), grid, block, M::LDS_BYTES, st->s,
+                       (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE, njobs, (const double*)D.bk_ntt,
+                       (const double*)D.tw_fwd, (const double*)D.tw_inv + NTT_N, D.fpc, o.at(first), G.p.n, G.p.mu,
+                       ABAR_STRIDE, o.trlwe, o.idx(first));
     HIP_TRY(hipGetLastError());
     return IYK_OK;
 }
+
+// narrow frontiers: one rotation per workgroup of 8 waves (kernels.hpp, blind_rotate_fp_lat3_kernel)
 template <class DC>
-int launch_br_fp_lat_any(iyk_hip_stream* st, int kind, int first, int njobs, const RotOut& o)
+int launch_br_fp_lat3(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
 {
-    if (kind == 1) return launch_br_fp_wg<DC, 1>(st, first, njobs, o);
-    if (kind == 2) return launch_br_fp_wg<DC, 2>(st, first, njobs, o);
-    return launch_br_fp_wg<DC, 3>(st, first, njobs, o);
+    const Device& D = G.devs[st->gpu];
+    const u32* abar = (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE;
+    hipLaunchKernelGGL(blind_rotate_fp_lat3_kernel<DC>, dim3((unsigned)njobs), dim3(BrLat3<DC>::THREADS), BrLat3<DC>::LDS_BYTES,
+                       st->s, abar, njobs, (const double*)D.bk_ntt, (const double*)D.tw_fwd, (const double*)D.tw_inv, D.fpc,
+                       o.at(first), G.p.n, G.p.mu, ABAR_STRIDE, o.trlwe, o.idx(first));
+    HIP_TRY(hipGetLastError());
+    return IYK_OK;
 }
 
-// Dispatch (profiles/*sweep*): full rounds of 2048 rotations (8 per CU on 256 CUs) on the wave-per-rotation
-// kernel, a remainder of up to lat_threshold rotations on a workgroup-per-rotation kernel.
+// which rotation kernel a batch is forced onto: IYK_HIP_ROT_KERNEL = w32 / t16 / lat3 (A/B, tests; read per batch).
+// IYK_HIP_LATENCY_KERNEL = 0 / 3 is the older spelling of w32 / lat3.  0 = no override.
+enum { ROT_AUTO = 0, ROT_W32 = 32, ROT_T16 = 16, ROT_LAT3 = 3 };
+int forced_rot_kernel()
+{
+    if (const char* k = std::getenv("IYK_HIP_ROT_KERNEL")) {
+        const std::string v(k);
+        if (v == "w32") return ROT_W32;
+        if (v == "t16") return ROT_T16;
+        if (v == "lat3") return ROT_LAT3;
+    }
+    if (const char* lat = std::getenv("IYK_HIP_LATENCY_KERNEL")) {
+        if (lat[0] == '0') return ROT_W32;
+        if (lat[0] == '3') return ROT_LAT3;
+    }
+    return ROT_AUTO;
+}
+
+// Dispatch (profiles/*sweep*): full rounds (one job per resident wave: 8 x CUs on blind_rotate_fp_kernel, 11 x CUs on
+// blind_rotate_fp_t16_kernel) on the wave-per-rotation kernel, a remainder of up to lat_threshold rotations on the
+// workgroup-per-rotation kernel: it takes one CU per rotation, 3.6-4.0 ms per 256 rotations, in sequence (7.5 / 11.1 /
+// 14.6 / 18.5 ms for 512 / 768 / 1024 / 1280); above that one more (partial) round of the wave-per-rotation kernel is
+// faster (profiles/r02_sweep_kernels_v7.txt).
 template <class DC>
 int dispatch_fp(iyk_hip_stream* st, int njobs, const RotOut& o)
 {
     int rc;
-    const char* lat = std::getenv("IYK_HIP_LATENCY_KERNEL");  // "0" / "1" / "2" / "3" force one kernel (A/B, tests)
-    if (lat && lat[0] >= '1' && lat[0] <= '3') return launch_br_fp_lat_any<DC>(st, lat[0] - '0', 0, njobs, o);
-    if (lat && lat[0] == '0') return launch_br_fp<DC>(st, 0, njobs, o);
-    const int round = 2048;
+    const int forced = forced_rot_kernel();
+    if (forced == ROT_LAT3) return launch_br_fp_lat3<DC>(st, 0, njobs, o);
+    if (forced == ROT_W32) return launch_br_fp<DC>(st, 0, njobs, o);
+    if (forced == ROT_T16) return launch_br_fp_t16<DC>(st, 0, njobs, o);
+    const bool t16 = G.tp_kernel == 16;
+    const int round = (t16 ? BR_T16_WAVES : BR_WAVES) * G.devs[st->gpu].cus;
     const int rem = njobs % round, full = njobs - rem;
-    if (rem > G.lat_threshold) return launch_br_fp<DC>(st, 0, njobs, o);
-    if (full && (rc = launch_br_fp<DC>(st, 0, full, o))) return rc;
-    // The 8-wave kernel (lat_kernel, default 3) takes one CU per rotation: 3.6-4.0 ms per 256 rotations, in sequence (7.5 /
-    // 11.1 / 14.6 / 18.5 ms for 512 / 768 / 1024 / 1280) — ahead of the 3-wave kernel (6.1 / 9.4 / 13.8 / 17.6 ms) everywhere;
-    // above 1280 a whole round of the wave-per-rotation kernel (19.9 ms) is the fastest (profiles/r02_sweep_kernels_v7.txt).
-    if (rem) return launch_br_fp_lat_any<DC>(st, G.lat_kernel, full, rem, o);
+    auto tp = [&](int first, int count) { return t16 ? launch_br_fp_t16<DC>(st, first, count, o) : launch_br_fp<DC>(st, first, count, o); };
+    if (rem > G.lat_threshold) return tp(0, njobs);
+    if (full && (rc = tp(0, full))) return rc;
+    if (rem) return launch_br_fp_lat3<DC>(st, full, rem, o);
     return IYK_OK;
 }
 
@@ -352,8 +374,7 @@ int set_fp_attrs()
 {
     int rc;
     if ((rc = set_lds(blind_rotate_fp_kernel<DC>, BR_FP_LDS_BYTES))) return rc;
-    if ((rc = set_lds(blind_rotate_fp_lat_kernel<DC>, br_lat_lds_bytes<DC::LV>()))) return rc;
-    if ((rc = set_lds(blind_rotate_fp_lat2_kernel<DC>, BrLat2Lds<DC::LV>::BYTES))) return rc;
+    if ((rc = set_lds(blind_rotate_fp_t16_kernel<DC, BR_T16_WAVES>, BrT16<BR_T16_WAVES>::LDS_BYTES))) return rc;
     return set_lds(blind_rotate_fp_lat3_kernel<DC>, BrLat3<DC>::LDS_BYTES);
 }
 int set_kernel_attrs(const iyk_params& p, bool use_fp)
@@ -441,6 +462,8 @@ int init_devices(std::vector<Device>& devs, const int* device_ids, int avail, co
         if (ord < 0 || ord >= avail) return fail(IYK_ERR_INVALID, "device ordinal out of range");
         D.ordinal = ord;
         HIP_TRY(hipSetDevice(D.ordinal));
+        HIP_TRY(hipDeviceGetAttribute(&D.cus, hipDeviceAttributeMultiprocessorCount, D.ordinal));
+        if (D.cus < 1) return fail(IYK_ERR_HIP, "device reports no compute units");
         int rc = set_kernel_attrs(p, use_fp);
         if (rc) return rc;
         u32* d_bk = nullptr;
@@ -558,6 +581,13 @@ int iyk_hip_get_params(iyk_params* out)
 /* 1 = FP64 field path (p = 3 * 2^48 + 1097729), 0 = Goldilocks integer path */
 int iyk_hip_ntt_path(void) { return G.init.load() ? (G.use_fp ? 1 : 0) : IYK_ERR_STATE; }
 
+int iyk_hip_rotation_round(int gpu_index)
+{
+    if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
+    if (gpu_index < 0 || gpu_index >= (int)G.devs.size()) return fail(IYK_ERR_INVALID, "gpu_index out of range");
+    return (G.use_fp && G.tp_kernel == 16 ? BR_T16_WAVES : BR_WAVES) * G.devs[gpu_index].cus;
+}
+
 int iyk_hip_resident_key_bytes(uint64_t* out)
 {
     if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
@@ -627,10 +657,10 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
         return rc;
     }
     const char* dbg = std::getenv("IYK_HIP_DEBUG");
-    const char* lk = std::getenv("IYK_HIP_LATENCY_DEFAULT");  // 1 / 2 / 3: kernel used for narrow frontiers
+    const char* tk = std::getenv("IYK_HIP_TP_KERNEL");  // w32 / t16: the wave-per-rotation kernel of the size-based dispatch
     G.ks_kernel = 1;
     G.debug = dbg && dbg[0] == '1';
-    G.lat_kernel = (lk && lk[0] >= '1' && lk[0] <= '3') ? lk[0] - '0' : 3;
+    G.tp_kernel = (tk && std::string(tk) == "t16") ? 16 : 32;
     G.p = p;
     G.use_fp = use_fp;
     G.fpc = fpt.c;

@@ -2,10 +2,10 @@
 //
 //   init        bk_ntt_fp_kernel / bk_ntt_kernel     torus-domain BK rows -> NTT domain (once per GPU)
 //   per batch   modswitch_kernel                      linear step + mod-switch of every rotation -> abar[job][n+1]
-//               blind_rotate_fp_kernel<Decomp>        one wavefront per rotation, FP64 field (fp50.hpp): default
+//               blind_rotate_fp_t16_kernel<Decomp,NW> one wavefront per rotation, 16 points per lane, 3 waves / SIMD (kernels_t16.hpp): default
+//               blind_rotate_fp_kernel<Decomp>        one wavefront per rotation, 32 points per lane, 2 waves / SIMD (IYK_HIP_TP_KERNEL=w32)
 //               blind_rotate_fp_lat3_kernel<Decomp>   one rotation per workgroup of 8 wavefronts (16 / 8 points per lane): narrow
 //                                                     frontiers, <= 1024 rotations (3.6-3.9 ms per rotation instead of 20)
-//               blind_rotate_fp_lat_kernel<Decomp>, blind_rotate_fp_lat2_kernel<Decomp>   round 1's 3- and 6-wave variants (A/B)
 //               blind_rotate_kernel<L,BGBIT>          one wavefront per rotation, Goldilocks integers (IYK_HIP_NTT=goldilocks)
 //               sample_extract_kernel                 TRLWE -> TLWE lvl1 (CMUX-memory helper entry point only)
 //               keyswitch_init_kernel + keyswitch_wave_kernel<T,NC,16>   lvl1 -> lvl0 identity key switch, 16 gates and whole rows
@@ -516,335 +516,7 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Low-latency variant for narrow frontiers (netlist levels with a few hundred gates): ONE ROTATION
-// PER WORKGROUP of L wavefronts, wave w owns gadget level w (its two forward transforms + MAC run
-// concurrently with the other levels'), the L partial NTT-domain sums are reduced into wave 0
-// through LDS, wave 0 runs the inverse transform and updates the shared accumulator.
-// Per CMUX step the critical path drops from 3 forward levels + inverse to 1 level + reduce +
-// inverse (~2x).  Same phase functions, same arithmetic, bit-identical results.
-static constexpr size_t BR_LAT_WAVE_WORDS = 2 * XB_WORDS32;  // u32 words of transpose/share buffer per wave
-template <int L>
-constexpr size_t br_lat_lds_bytes()
-{
-    return (2 * NTT_N + fp::ZTAB_ENTRIES) * sizeof(double) + (2 * NTT_N + L * BR_LAT_WAVE_WORDS) * sizeof(u32);
-}
-
-template <class D>
-__global__ __launch_bounds__(64 * D::LV) void blind_rotate_fp_lat_kernel(
-    const u32* __restrict__ abar_all, int njobs, const double* __restrict__ bk_ntt,
-    const double* __restrict__ tw_fwd, const double* __restrict__ tw_inv, const fp::NttConsts* __restrict__ Cp,
-    u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride, int trlwe_mode,
-    const int32_t* __restrict__ out_index)
-{
-    const fp::NttConsts& C = *Cp;
-    constexpr int L = D::LV;  // one wavefront per (virtual) gadget level
-    extern __shared__ __attribute__((aligned(4096))) unsigned char smem[];
-    double* s_twf = reinterpret_cast<double*>(smem);
-    double* s_twi = s_twf + NTT_N;
-    double* s_ztab = s_twi + NTT_N;                          // [j2][digit + 32]
-    u32* acc_lds = reinterpret_cast<u32*>(s_ztab + fp::ZTAB_ENTRIES);  // [2][1024], shared by all waves
-    static_assert(((2 * NTT_N + fp::ZTAB_ENTRIES) * sizeof(double)) % 4096 == 0, "fwd1_pre needs 4 KB aligned accumulators");
-    u32* s_xb = acc_lds + 2 * NTT_N;                         // [L][2][XB_WORDS32]
-
-    for (int e = threadIdx.x; e < NTT_N; e += 64 * L) {
-        const int a = e >> 5, b = e & 31;
-        s_twf[b * 32 + a] = tw_fwd[e];
-        s_twi[b * 32 + a] = tw_inv[e];
-    }
-    for (int e = threadIdx.x; e < fp::ZTAB_ENTRIES; e += 64 * L) s_ztab[e] = fp::ztab_entry(e, C.zf);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // = gadget level of this wave
-    const int lane = threadIdx.x & 63;
-    const int h0 = lane >> 5, t0 = lane & 31;
-    const int job = blockIdx.x;
-    const u32* abar = abar_all + (size_t)job * abar_stride;
-    if (wave == 0) br_init_acc(h0, t0, abar[n], mu, acc_lds + h0 * NTT_N);
-    __syncthreads();
-
-    u32 lo[32];
-    double x[32], accum[32];
-    u32* wave_xb = s_xb + wave * BR_LAT_WAVE_WORDS;
-
-    u32 ab_next = abar[0];
-    for (u32 i = 0; i < n; ++i) {
-        const u32 ab = ab_next;
-        ab_next = abar[i + 1 < n ? i + 1 : i];  // next step's exponent: its scalar-load latency hides behind this step
-        const double* bk_step = bk_ntt + (size_t)i * (2 * L) * 2 * NTT_N;
-        {
-            int t = t0, h = h0;
-            asm volatile("" : "+v"(t), "+v"(h));
-            const u32* acc_h = acc_lds + h * NTT_N;
-            u32* xb = wave_xb + h * XB_WORDS32;
-            double* xb64_own = reinterpret_cast<double*>(xb);
-            const double* xb64_oth = reinterpret_cast<const double*>(wave_xb + (1 - h) * XB_WORDS32);
-            const double* bko = bk_step + (size_t)((h * L + wave) * 2 + h) * NTT_N + (size_t)t * 2;
-            const double* bkt = bk_step + (size_t)(((1 - h) * L + wave) * 2 + h) * NTT_N + (size_t)t * 2;
-            // key rows of the first MAC chunk are fetched now: a lone wave has nothing else to hide their latency with
-            double bo0[8][2], bt0[8][2];
-#pragma unroll
-            for (int mm = 0; mm < 8; ++mm) {
-                bo0[mm][0] = bko[mm * 64]; bo0[mm][1] = bko[mm * 64 + 1];
-                bt0[mm][0] = bkt[mm * 64]; bt0[mm][1] = bkt[mm * 64 + 1];
-            }
-            // forward pass 1 of level `wave`
-            fp::fwd1_pre<D>(t, wave, ab, acc_h, x, s_ztab);
-            fp::ntt32_dif<fp::PASS1>(x, C.w);
-            fp::fwd1_twiddle(t, x, s_twf);
-            fp::xpose_write<false>(t, x, xb, false);
-            lds_sync();
-            fp::xpose_read_words(t, lo, xb);
-            lds_sync();
-            fp::xpose_write<false>(t, x, xb, true);
-            lds_sync();
-            fp::xpose_read_hi(t, x, lo, xb);
-            lds_sync();
-            // forward pass 2 + MAC
-            fp::ntt32_dif<fp::PASS2>(x, C.w);
-#pragma unroll
-            for (int chunk = 0; chunk < 2; ++chunk) {
-                fp::share_write(t, chunk, x, xb64_own);
-                lds_sync();
-#pragma unroll
-                for (int mm = 0; mm < 8; ++mm) {
-                    const int m = chunk * 8 + mm;
-                    const double bo[2] = {chunk ? bko[m * 64] : bo0[mm][0], chunk ? bko[m * 64 + 1] : bo0[mm][1]};
-                    const double bt[2] = {chunk ? bkt[m * 64] : bt0[mm][0], chunk ? bkt[m * 64 + 1] : bt0[mm][1]};
-                    fp::mac_pair<true>(t, m, x, xb64_oth, bo, bt, accum);  // a wave owns one level: its partial sum starts here
-                }
-                lds_sync();
-            }
-        }
-        if (L > 3) {  // L partial sums of <= 2.7 p each could exceed 2^53: reduce each first
-#pragma unroll
-            for (int q = 0; q < 32; ++q) accum[q] = fp::norm(accum[q]);
-        }
-        // reduce the L partial sums into wave 0 (two rounds of 16 values through each wave's buffer)
-#pragma unroll
-        for (int chunk = 0; chunk < 2; ++chunk) {
-            double* mine = reinterpret_cast<double*>(wave_xb);
-            if (wave != 0) {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) mine[q * 64 + lane] = accum[16 * chunk + q];
-            }
-            wg_barrier_lds();
-            if (wave == 0) {
-#pragma unroll
-                for (int w = 1; w < L; ++w) {
-                    const double* other = reinterpret_cast<const double*>(s_xb + w * BR_LAT_WAVE_WORDS);
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) accum[16 * chunk + q] += other[q * 64 + lane];
-                }
-            }
-            wg_barrier_lds();
-        }
-        if (wave == 0) {
-            int t = t0, h = h0;
-            asm volatile("" : "+v"(t), "+v"(h));
-            u32* acc_h = acc_lds + h * NTT_N;
-            u32* xb = wave_xb + h * XB_WORDS32;
-#pragma unroll
-            for (int q = 0; q < 32; ++q) x[q] = fp::norm(accum[q]);
-            fp::ntt32_dif<fp::PASS1>(x, C.w);
-            fp::inv1_twiddle(t, x, s_twi);
-            fp::xpose_write<true>(t, x, xb, false);
-            lds_sync();
-            fp::xpose_read_words(t, lo, xb);
-            lds_sync();
-            fp::xpose_write<true>(t, x, xb, true);
-            lds_sync();
-            fp::xpose_read_hi(t, x, lo, xb);
-            lds_sync();
-            fp::ntt32_dif<fp::PASS2>(x, C.w);
-            fp::inv2_post(t, x, acc_h, C.zi);
-        }
-        wg_barrier_lds();  // accumulator of step i is complete before anyone derives step i+1's digits
-    }
-
-    if (wave == 0) {
-        if (trlwe_mode) {  // raw accumulator: TRLWE (a(X), b(X)), 2N words per job
-            u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (2 * NTT_N);
-            for (int j = lane; j < 2 * NTT_N; j += 64) out[j] = acc_lds[j];
-        }
-        else {
-            u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (NTT_N + 1);
-            for (int j = lane; j < NTT_N; j += 64) out[j] = (j == 0) ? acc_lds[0] : 0u - acc_lds[NTT_N - j];
-            if (lane == 0) out[NTT_N] = acc_lds[NTT_N];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Low-latency variant 2: ONE ROTATION PER WORKGROUP of 2 L wavefronts.  Wave (lvl, half) owns gadget level
-// lvl and one HALF of the outputs of each 32-point DIF of that level's transform (fpntt32.hpp,
-// ntt32_dif_half): it reads all 32 inputs of its column (lane = (h, t) as everywhere), runs stage 0 for its
-// half (the 16 sums, or the 16 twiddled differences) and stages 1..4 inside that 16-block.  So per step a
-// wave issues ~0.6x the instructions of the one-wave-per-level kernel; the price is that the two waves of a
-// level meet in LDS at every transpose (workgroup barriers instead of wave-local fences) and that both derive
-// all 32 digits of a column.  Every wave leaves its partial NTT-domain sum in its own share area; waves
-// (0, half) add them up and run the inverse transform, again one half of every DIF each.  Four workgroup
-// barriers per step.  Same arithmetic, same schedules, same bits.
-//
-// LDS (bytes): twiddles fwd + inv 16 K | twisted digits 16 K | accumulator 8 K (4 KB aligned polynomials) |
-// transposes [L][h][32][33] f64 (8448 each) | MAC share / partial sums [2L waves][h][16][32] f64.
-template <int LV>
-struct BrLat2Lds {
-    static constexpr size_t XPOSE = (size_t)LV * 2 * 32 * XB_STRIDE * sizeof(double);
-    static constexpr size_t SHARE = (size_t)2 * LV * 2 * 16 * 32 * sizeof(double);
-    static constexpr size_t FIXED = (2 * NTT_N + fp::ZTAB_ENTRIES) * sizeof(double) + 2 * NTT_N * sizeof(u32);
-    // the share area is separate when it fits (no barrier between the transposed reads and the share writes),
-    // otherwise it sits on the transpose buffers of its own level
-    static constexpr bool ALIAS_SHARE = FIXED + XPOSE + SHARE > 160 * 1024;
-    static constexpr size_t BYTES = FIXED + (ALIAS_SHARE ? XPOSE : XPOSE + SHARE);
-    static_assert(BYTES <= 160 * 1024, "latency kernel 2 does not fit the CU's LDS");
-    static_assert(!ALIAS_SHARE || 2 * 16 * 32 * sizeof(double) <= 32 * XB_STRIDE * sizeof(double), "share alias too small");
-};
-
-template <class D>
-__global__ __launch_bounds__(128 * D::LV) void blind_rotate_fp_lat2_kernel(
-    const u32* __restrict__ abar_all, int njobs, const double* __restrict__ bk_ntt,
-    const double* __restrict__ tw_fwd, const double* __restrict__ tw_inv, const fp::NttConsts* __restrict__ Cp,
-    u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride, int trlwe_mode,
-    const int32_t* __restrict__ out_index)
-{
-    const fp::NttConsts& C = *Cp;
-    constexpr int L = D::LV;
-    typedef BrLat2Lds<L> M;
-    constexpr int NT = 128 * L;
-    extern __shared__ __attribute__((aligned(4096))) unsigned char smem[];
-    double* s_twf = reinterpret_cast<double*>(smem);                      // [k2][j1]
-    double* s_twi = s_twf + NTT_N;                                        // [j1][k2]
-    double* s_ztab = s_twi + NTT_N;                                       // [j2][digit + 32]
-    u32* acc_lds = reinterpret_cast<u32*>(s_ztab + fp::ZTAB_ENTRIES);     // [2][1024]
-    static_assert(((2 * NTT_N + fp::ZTAB_ENTRIES) * sizeof(double)) % 4096 == 0, "fwd1_pre needs 4 KB aligned accumulators");
-    double* s_scr = reinterpret_cast<double*>(acc_lds + 2 * NTT_N);
-    double* s_xp = s_scr;                                                 // [L][2][32][33]
-
-    for (int e = threadIdx.x; e < NTT_N; e += NT) {
-        const int a = e >> 5, b = e & 31;
-        s_twf[b * 32 + a] = tw_fwd[e];
-        s_twi[b * 32 + a] = tw_inv[e];
-    }
-    for (int e = threadIdx.x; e < fp::ZTAB_ENTRIES; e += NT) s_ztab[e] = fp::ztab_entry(e, C.zf);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lvl = wave >> 1, half = wave & 1;
-    const int lane = threadIdx.x & 63;
-    const int h0 = lane >> 5, t0 = lane & 31;
-    const int job = blockIdx.x;
-    const u32* abar = abar_all + (size_t)job * abar_stride;
-    if (wave == 0) br_init_acc(h0, t0, abar[n], mu, acc_lds + h0 * NTT_N);
-    wg_barrier_lds();
-
-    double x[32], y[16], accum[16];
-
-    for (u32 i = 0; i < n; ++i) {
-        const u32 ab = abar[i];
-        const double* bk_step = bk_ntt + (size_t)i * (2 * L) * 2 * NTT_N;
-        int t = t0, h = h0;
-        asm volatile("" : "+v"(t), "+v"(h));
-        u32* acc_h = acc_lds + h * NTT_N;
-        double* xp = s_xp + (size_t)(lvl * 2 + h) * 32 * XB_STRIDE;      // this level's transpose buffer, polynomial h
-        // MAC share area of this wave: [h][16][32]
-        double* sh = M::ALIAS_SHARE ? s_xp + (size_t)(lvl * 2 + half) * 32 * XB_STRIDE
-                                    : s_scr + M::XPOSE / sizeof(double) + (size_t)wave * 2 * 16 * 32;
-        double* sh_own = sh + h * 16 * 32;
-        const double* sh_oth = sh + (1 - h) * 16 * 32;
-        const double* bko = bk_step + (size_t)((h * L + lvl) * 2 + h) * NTT_N + (size_t)t * 2 + half;
-        const double* bkt = bk_step + (size_t)(((1 - h) * L + lvl) * 2 + h) * NTT_N + (size_t)t * 2 + half;
-
-        // ---- forward transform of level lvl, this wave's half of each pass --------------------------
-        // key rows of this half: k1 = brv5(16 half + q) = 2 brv4(q) + half, at pair index brv4(q) of the device layout
-        double bo[16], bt[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            bo[q] = bko[(brv5(q) >> 1) * 64];
-            bt[q] = bkt[(brv5(q) >> 1) * 64];
-        }
-        fp::fwd1_pre<D>(t, lvl, ab, acc_h, x, s_ztab);
-        if (half == 0) fp::ntt32_dif_half<fp::PASS1, 0>(x, y, C.w);
-        else fp::ntt32_dif_half<fp::PASS1, 1>(x, y, C.w);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int k2 = half ? brv5(16 + q) : brv5(q);
-            xp[k2 * XB_STRIDE + t] = fp::mulmod(y[q], s_twf[k2 * 32 + t]);
-        }
-        wg_barrier_lds();
-#pragma unroll
-        for (int j = 0; j < 32; ++j) x[j] = xp[t * XB_STRIDE + j];
-        if (M::ALIAS_SHARE) wg_barrier_lds();  // both waves have read the transposes before the share area reuses them
-        if (half == 0) fp::ntt32_dif_half<fp::PASS2, 0>(x, y, C.w);
-        else fp::ntt32_dif_half<fp::PASS2, 1>(x, y, C.w);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) sh_own[q * 32 + t] = y[q];
-        lds_sync();  // the other polynomial's spectrum sits in the other half of this same wave
-#pragma unroll
-        for (int q = 0; q < 16; ++q) accum[q] = fp::mulmod(y[q], bo[q]) + fp::mulmod(sh_oth[q * 32 + t], bt[q]);
-        if (L > 3) {  // L partial sums of <= 2.7 p each could exceed 2^53: reduce each first
-#pragma unroll
-            for (int q = 0; q < 16; ++q) accum[q] = fp::norm(accum[q]);
-        }
-        // ---- reduce over the levels + inverse transform (waves (0, half)) ----------------------------
-        // a wave's partial sums replace its own share area ([h][16][32], same shape): no one else touches it
-        lds_sync();
-#pragma unroll
-        for (int q = 0; q < 16; ++q) sh_own[q * 32 + t] = accum[q];
-        wg_barrier_lds();
-        if (lvl == 0) {
-#pragma unroll
-            for (int k1 = 0; k1 < 32; ++k1) {
-                // k1 = brv5(16 hf + q): hf = k1 & 1, q = brv5(k1 & 30); written by waves (l, hf), l = 0 .. L-1
-                const int hf = k1 & 1, q = brv5(k1 & 30);
-                double sum = 0.0;
-#pragma unroll
-                for (int l = 0; l < L; ++l) {
-                    const double* src = M::ALIAS_SHARE ? s_xp + (size_t)(l * 2 + hf) * 32 * XB_STRIDE
-                                                       : s_scr + M::XPOSE / sizeof(double) + (size_t)(l * 2 + hf) * 2 * 16 * 32;
-                    const double v = src[(h * 16 + q) * 32 + t];
-                    sum = l ? sum + v : v;
-                }
-                x[k1] = fp::norm(sum);
-            }
-        }
-        if (M::ALIAS_SHARE) wg_barrier_lds();  // the inverse transpose reuses level 0's buffers = share areas just read
-        double* xpi = s_xp + (size_t)h * 32 * XB_STRIDE;
-        if (lvl == 0) {
-            if (half == 0) fp::ntt32_dif_half<fp::PASS1, 0>(x, y, C.w);
-            else fp::ntt32_dif_half<fp::PASS1, 1>(x, y, C.w);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int j1 = half ? inv_index(16 + q) : inv_index(q);
-                xpi[j1 * XB_STRIDE + t] = fp::mulmod(y[q], s_twi[j1 * 32 + t]);
-            }
-        }
-        wg_barrier_lds();
-        if (lvl == 0) {
-#pragma unroll
-            for (int j = 0; j < 32; ++j) x[j] = xpi[t * XB_STRIDE + j];
-            if (half == 0) fp::ntt32_dif_half<fp::PASS2, 0>(x, y, C.w);
-            else fp::ntt32_dif_half<fp::PASS2, 1>(x, y, C.w);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int j2 = half ? inv_index(16 + q) : inv_index(q);
-                const double v = fp::norm(j2 == 0 ? y[q] : fp::mulmod(y[q], C.zi[j2]));
-                acc_h[t + 32 * j2] += fp::to_torus32(v);
-            }
-        }
-        wg_barrier_lds();  // accumulator of step i is complete before anyone derives step i+1's digits
-    }
-
-    if (wave == 0) {
-        if (trlwe_mode) {  // raw accumulator: TRLWE (a(X), b(X)), 2N words per job
-            u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (2 * NTT_N);
-            for (int j = lane; j < 2 * NTT_N; j += 64) out[j] = acc_lds[j];
-        }
-        else {
-            u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (NTT_N + 1);
-            for (int j = lane; j < NTT_N; j += 64) out[j] = (j == 0) ? acc_lds[0] : 0u - acc_lds[NTT_N - j];
-            if (lane == 0) out[NTT_N] = acc_lds[NTT_N];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Low-latency variant 3: ONE ROTATION PER WORKGROUP of 8 wavefronts; 64-lane transforms with 16 points per lane
+// Low-latency kernel for narrow frontiers: ONE ROTATION PER WORKGROUP of 8 wavefronts; 64-lane transforms with 16 points per lane
 // (blind_rotate_lat3.hpp).  Per CMUX step, four workgroup barriers:
 //   forward   wave w < 2 LV: digits of digit polynomial (h, v) = (w / LV, w % LV) -> 1024-point NTT -> its spectrum into
 //             the wave's own LDS buffer (the transpose matrix, free by then), in the key's device layout;     barrier 1

@@ -32,7 +32,7 @@ EXPORTS = [
     "iyk_hip_bootstrap_trlwe_batch", "iyk_hip_sample_extract_keyswitch_batch",
     "iyk_hip_stream_gpu", "iyk_hip_arena_upload_slots", "iyk_hip_arena_download_slots", "iyk_hip_arena_copy",
     "iyk_hip_arena_sync_slots", "iyk_hip_trlwe_alloc", "iyk_hip_trlwe_free", "iyk_hip_trlwe_upload",
-    "iyk_hip_trlwe_download",
+    "iyk_hip_trlwe_download", "iyk_hip_rotation_round",
 ]
 
 
@@ -123,6 +123,11 @@ def resident_key_bytes():
 def ntt_path():
     """'fp50' (FP64 FMA field, default for the 128-bit set) or 'goldilocks' (64-bit integer field)."""
     return "fp50" if _check(lib().iyk_hip_ntt_path(), "iyk_hip_ntt_path") == 1 else "goldilocks"
+
+
+def rotation_round(gpu=0):
+    """Rotations in one full round of the default wave-per-rotation kernel on GPU `gpu` (resident waves x CUs)."""
+    return _check(lib().iyk_hip_rotation_round(int(gpu)), "iyk_hip_rotation_round")
 
 
 def current_params():

@@ -4,6 +4,7 @@ ranks by bench.shard (strong scaling) with no collective, 
 gap-free, overlap-free split are the whole contract."""
 import hashlib
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -67,3 +68,66 @@ def test_shard_covers_the_batch_exactly():
                 assert lo + c == lo2
             assert max(c for _, c in blocks) - min(c for _, c in blocks) <= 1
     assert bench.shard(65536, 8, 3) == (3 * 8192, 8192)
+
+
+def _bench(args, env_extra=None, drop=("RANK", "WORLD_SIZE", "LOCAL_RANK")):
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=300)
+
+
+def test_gpus_flag_never_runs_on_fewer_gpus():
+    """`bench.py --gpus N` is a complete N-GPU run or a loud failure: stand-alone it refuses when
+    fewer than N devices are visible; under a launcher it refuses when WORLD_SIZE is not N.  Both exit with
+    bench.EXIT_BAD_WORLD before anything is timed, and print no JSON line."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import torch
+
+    visible = torch.cuda.device_count()
+    r = _bench(["--gpus", str(visible + 2), "--steps", "1", "--cpu-sample", "0"])
+    assert r.returncode == bench.EXIT_BAD_WORLD, (r.returncode, r.stderr[-400:])
+    assert "GPU(s) visible" in r.stderr and "{" not in r.stdout
+    r = _bench(["--gpus", "4", "--steps", "1", "--cpu-sample", "0"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}, drop=())
+    assert r.returncode == bench.EXIT_BAD_WORLD, (r.returncode, r.stderr[-400:])
+    assert "WORLD_SIZE=2" in r.stderr and "{" not in r.stdout
+    r = _bench(["--gpus", "0"])
+    assert r.returncode == bench.EXIT_BAD_WORLD
+
+
+def test_launcher_builds_a_torchrun_command(monkeypatch):
+    """Stand-alone `--gpus 2` with two devices visible re-executes under torch.distributed.run with one rank per GPU
+    and a loopback rendezvous; the child's exit status is passed on."""
+    sys.path.insert(0, ROOT)
+    import argparse
+    import bench
+
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    args = argparse.Namespace(gpus=2, spawn=False)
+    try:
+        bench.launcher(args, script="/x/bench.py", argv=["--gpus", "2", "--steps", "5"], visible_gpus=2)
+    except SystemExit as e:
+        assert e.code == 7
+    else:
+        raise AssertionError("launcher returned instead of re-executing")
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-5:] == ["/x/bench.py", "--gpus", "2", "--steps", "5"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # one GPU, no --spawn: no re-execution, no process group
+    assert bench.launcher(argparse.Namespace(gpus=1, spawn=False)) == (0, 1, 0, False)
+    # under a launcher with the right world: this rank's coordinates
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "1")
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    assert bench.launcher(args) == (1, 2, 1, True)

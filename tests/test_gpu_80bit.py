@@ -10,11 +10,11 @@ from iyokan_amd.params import OPS, PLAIN
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("path,kernel,ks", [("fp50", "0", None), ("fp50", "1", None), ("fp50", "2", None), ("fp50", "3", None),
+@pytest.mark.parametrize("path,kernel,ks", [("fp50", "t16", None), ("fp50", "w32", None), ("fp50", "lat3", None),
                                             ("goldilocks", None, None), ("fp50", None, "0")])
 def test_80bit_gates_bit_exact(path, kernel, ks, keys80, oracle80, monkeypatch):
     """Both exact-arithmetic paths at the 80-bit set: FP64 field with split digits (default; each of its
-    four rotation kernels forced in turn) and the 64-bit integer field (IYK_HIP_NTT=goldilocks); the last case
+    three rotation kernels forced in turn) and the 64-bit integer field (IYK_HIP_NTT=goldilocks); the last case
     forces the workgroup-per-16-gates key switch (the default is the wave-per-16-gates one, t = 8 / 4 chunks of 128 words)."""
     from iyokan_amd import hip
 
@@ -23,9 +23,9 @@ def test_80bit_gates_bit_exact(path, kernel, ks, keys80, oracle80, monkeypatch):
     else:
         monkeypatch.setenv("IYK_HIP_KS_KERNEL", ks)
     if kernel is None:
-        monkeypatch.delenv("IYK_HIP_LATENCY_KERNEL", raising=False)
+        monkeypatch.delenv("IYK_HIP_ROT_KERNEL", raising=False)
     else:
-        monkeypatch.setenv("IYK_HIP_LATENCY_KERNEL", kernel)
+        monkeypatch.setenv("IYK_HIP_ROT_KERNEL", kernel)
     old = os.environ.get("IYK_HIP_NTT")
     if path == "goldilocks":
         os.environ["IYK_HIP_NTT"] = "goldilocks"
@@ -74,7 +74,7 @@ def test_80bit_adversarial_rows(path, keys80, oracle80, monkeypatch):
     import oracle_lib
     from iyokan_amd import hip
 
-    monkeypatch.delenv("IYK_HIP_LATENCY_KERNEL", raising=False)
+    monkeypatch.delenv("IYK_HIP_ROT_KERNEL", raising=False)
     monkeypatch.delenv("IYK_HIP_KS_KERNEL", raising=False)
     if path == "goldilocks":
         monkeypatch.setenv("IYK_HIP_NTT", "goldilocks")

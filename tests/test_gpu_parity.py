@@ -241,9 +241,9 @@ def test_full_size_flat_nand_property(gpu128, keys128, oracle128):
 
 
 def test_all_rotation_kernels_agree(gpu128, keys128, oracle128):
-    """The wave-per-rotation kernel and the three workgroup-per-rotation kernels (wave per level, two waves per
-    level, wave per (polynomial, level); IYK_HIP_LATENCY_KERNEL=0/1/2/3 forces one, default picks by batch
-    size) must produce identical ciphertexts, equal to the oracle."""
+    """The two wave-per-rotation kernels (t16: 16 points per lane, 3 waves per SIMD; w32: 32 points per lane, 2 waves
+    per SIMD) and the workgroup-per-rotation kernel (lat3); IYK_HIP_ROT_KERNEL=t16/w32/lat3 forces one, the default
+    picks by batch size.  All must produce identical ciphertexts, equal to the oracle."""
     hip, st = gpu128
     p = keys128.params
     rng = np.random.default_rng(41)
@@ -256,22 +256,20 @@ def test_all_rotation_kernels_agree(gpu128, keys128, oracle128):
     host = np.zeros((nin + ng, p.n + 1), dtype=np.uint32)
     host[:nin] = client.encrypt_bits(keys128, bits, seed=77)
     results = {}
-    old = os.environ.get("IYK_HIP_LATENCY_KERNEL")
+    old = os.environ.get("IYK_HIP_ROT_KERNEL")
     try:
-        for mode in ("0", "1", "2", "3"):
-            os.environ["IYK_HIP_LATENCY_KERNEL"] = mode
+        for mode in ("t16", "w32", "lat3"):
+            os.environ["IYK_HIP_ROT_KERNEL"] = mode
             results[mode] = _run(hip, st, host, ops, in0, in1, in2, out)
     finally:
         if old is None:
-            os.environ.pop("IYK_HIP_LATENCY_KERNEL", None)
+            os.environ.pop("IYK_HIP_ROT_KERNEL", None)
         else:
-            os.environ["IYK_HIP_LATENCY_KERNEL"] = old
-    assert np.array_equal(results["0"], results["1"])
-    assert np.array_equal(results["0"], results["2"])
-    assert np.array_equal(results["0"], results["3"])
+            os.environ["IYK_HIP_ROT_KERNEL"] = old
     ref = host.copy()
     oracle128.gate_batch(ops, in0, in1, in2, out, ref, nthreads=os.cpu_count() or 1)
-    assert np.array_equal(results["0"], ref)
+    for mode in ("t16", "w32", "lat3"):
+        assert np.array_equal(results[mode], ref), mode
 
 
 @pytest.mark.parametrize("ng", [1, 10, 64, 65, 300])
@@ -323,13 +321,13 @@ def test_adversarial_rows_bit_exact_on_every_kernel(gpu128, keys128, oracle128, 
     host[:nin] = rows
     ref = host.copy()
     oracle128.gate_batch(ops, in0, in1, in2, out, ref, nthreads=os.cpu_count() or 1)
-    for lat in ("0", "1", "2", "3"):
+    for lat in ("t16", "w32", "lat3"):
         for ks in ("0", "1"):
-            monkeypatch.setenv("IYK_HIP_LATENCY_KERNEL", lat)
+            monkeypatch.setenv("IYK_HIP_ROT_KERNEL", lat)
             monkeypatch.setenv("IYK_HIP_KS_KERNEL", ks)
             got = _run(hip, st, host, ops, in0, in1, in2, out)
             assert np.array_equal(got, ref), (lat, ks)
-    monkeypatch.delenv("IYK_HIP_LATENCY_KERNEL")
+    monkeypatch.delenv("IYK_HIP_ROT_KERNEL")
     monkeypatch.delenv("IYK_HIP_KS_KERNEL")
 
 
@@ -376,12 +374,13 @@ def test_repeated_batches_are_bit_identical(gpu128, keys128):
 
 @pytest.mark.parametrize("rem", [100, 300, 1200, 1400])
 def test_mid_size_batch_uses_both_kernels(gpu128, keys128, rem):
-    """2048 + rem rotations: full round on the wave-per-rotation kernel, a remainder of up to 1280 on the
-    workgroup-per-rotation kernel (one to five passes of 256), a larger one as a second wave-per-rotation round; every
-    output must decrypt correctly (size-independent property) and inputs stay untouched."""
+    """round + rem rotations (round = hip.rotation_round(): one job per resident wave): full round on the wave-per-rotation
+    kernel, a remainder of up to 1280 on the workgroup-per-rotation kernel (one to five passes of 256), a larger one as a
+    second wave-per-rotation round; every output must decrypt correctly (size-independent property) and inputs stay
+    untouched."""
     hip, st = gpu128
     rng = np.random.default_rng(43)
-    nin, ng = 512, 2048 + rem
+    nin, ng = 512, hip.rotation_round() + rem
     bits = rng.integers(0, 2, size=nin).astype(np.uint8)
     ia = rng.integers(0, nin, size=ng).astype(np.int32)
     ib = rng.integers(0, nin, size=ng).astype(np.int32)
@@ -395,13 +394,14 @@ def test_mid_size_batch_uses_both_kernels(gpu128, keys128, rem):
 
 
 def test_dispatch_split_bit_exact_vs_oracle(gpu128, keys128, oracle128):
-    """2048 + 150 rotations: the full round runs on the wave-per-rotation kernel, the remainder on the
+    """round + 150 rotations: the full round runs on the wave-per-rotation kernel, the remainder on the
     workgroup-per-rotation kernel with a non-zero job offset (`first`).  64 gates from EACH side of the split
     are compared word for word with the oracle (the other tests of the split only decrypt)."""
     hip, st = gpu128
     p = keys128.params
     rng = np.random.default_rng(4321)
-    nin, ng = 300, 2048 + 150
+    full = hip.rotation_round()
+    nin, ng = 300, full + 150
     bits = rng.integers(0, 2, size=nin).astype(np.uint8)
     ia = rng.integers(0, nin, size=ng).astype(np.int32)
     ib = rng.integers(0, nin, size=ng).astype(np.int32)
@@ -409,7 +409,7 @@ def test_dispatch_split_bit_exact_vs_oracle(gpu128, keys128, oracle128):
     host = np.zeros((nin + ng, p.n + 1), dtype=np.uint32)
     host[:nin] = client.encrypt_bits(keys128, bits, seed=79)
     got = _run(hip, st, host, ops, ia, ib, np.full(ng, -1, dtype=np.int32), np.arange(nin, nin + ng, dtype=np.int32))
-    sample = np.concatenate([rng.choice(2048, size=64, replace=False), 2048 + rng.choice(150, size=64, replace=False)])
+    sample = np.concatenate([rng.choice(full, size=64, replace=False), full + rng.choice(150, size=64, replace=False)])
     ref = np.zeros((nin + len(sample), p.n + 1), dtype=np.uint32)
     ref[:nin] = host[:nin]
     oracle128.gate_batch(ops[sample], ia[sample], ib[sample], [-1] * len(sample),
@@ -418,13 +418,14 @@ def test_dispatch_split_bit_exact_vs_oracle(gpu128, keys128, oracle128):
 
 
 def test_mux_batch_straddles_the_dispatch_split(gpu128, keys128, oracle128):
-    """1400 MUX gates = 2800 rotations: 2048 on the wave-per-rotation kernel, 752 on the workgroup-per-rotation kernel
-    (three passes of <= 256), and some gates have their two rotations on DIFFERENT kernels; an empty batch is a no-op.
-    96 gates around the split and 32 random ones are compared word for word with the oracle, all of them by decryption."""
+    """round / 2 + 376 MUX gates = round + 752 rotations: a full round on the wave-per-rotation kernel, 752 on the
+    workgroup-per-rotation kernel (three passes of <= 256); an empty batch is a no-op.  96 gates around the split and
+    32 random ones are compared word for word with the oracle, all of them by decryption."""
     hip, st = gpu128
     p = keys128.params
     rng = np.random.default_rng(2468)
-    nin, ng = 200, 1400
+    full = hip.rotation_round()
+    nin, ng = 200, full // 2 + 376
     bits = rng.integers(0, 2, size=nin).astype(np.uint8)
     a, b, s_ = (rng.integers(0, nin, size=ng).astype(np.int32) for _ in range(3))
     host = np.zeros((nin + ng, p.n + 1), dtype=np.uint32)
@@ -438,7 +439,7 @@ def test_mux_batch_straddles_the_dispatch_split(gpu128, keys128, oracle128):
     arena.free()
     assert np.array_equal(got[:nin], host[:nin])
     assert np.array_equal(client.decrypt_bits(keys128, got[nin:]), np.where(bits[s_] == 1, bits[b], bits[a]))
-    sample = np.concatenate([np.arange(976, 1072), rng.choice(ng, size=32, replace=False)])   # gate 1024 = rotations 2048, 2049
+    sample = np.concatenate([np.arange(full // 2 - 48, full // 2 + 48), rng.choice(ng, size=32, replace=False)])   # gate full / 2 = first of the remainder
     ref = np.zeros((nin + len(sample), p.n + 1), dtype=np.uint32)
     ref[:nin] = host[:nin]
     oracle128.gate_batch([OPS["MUX"]] * len(sample), a[sample], b[sample], s_[sample], list(range(nin, nin + len(sample))), ref,

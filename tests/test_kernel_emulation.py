@@ -66,6 +66,11 @@ def test_emulated_fp64_path_bit_exact(which, request):
         assert em.iyk_emul_blind_rotate_fp_lat3(ctypes.byref(p), lin.ctypes.data_as(u32p), bk.ctypes.data_as(dp),
                                                 got3.ctypes.data_as(u32p)) == 0
         assert np.array_equal(ref, got3)
+        # wave-per-rotation kernel at three waves per SIMD: polynomial-sequential, 16 points per lane, one swap round per pass
+        got16 = np.zeros(p.N + 1, dtype=np.uint32)
+        assert em.iyk_emul_blind_rotate_fp_t16(ctypes.byref(p), lin.ctypes.data_as(u32p), bk.ctypes.data_as(dp),
+                                               got16.ctypes.data_as(u32p)) == 0
+        assert np.array_equal(ref, got16)
     assert em.iyk_emul_fp_max_magnitude() < 0.95 * 2.0 ** 53 / 844424931229697
 
 
@@ -88,7 +93,7 @@ def test_emulated_kernels_on_adversarial_rows(which, request):
     for r in (0, 3, 6, 7):
         lin = np.ascontiguousarray(rows[r])
         ref = orc.bootstrap_lvl1(lin)
-        for fn in (em.iyk_emul_blind_rotate_fp, em.iyk_emul_blind_rotate_fp_lat3):
+        for fn in (em.iyk_emul_blind_rotate_fp, em.iyk_emul_blind_rotate_fp_lat3, em.iyk_emul_blind_rotate_fp_t16):
             got = np.zeros(p.N + 1, dtype=np.uint32)
             assert fn(ctypes.byref(p), lin.ctypes.data_as(u32p), bk.ctypes.data_as(dp), got.ctypes.data_as(u32p)) == 0
             assert np.array_equal(ref, got), (r, fn)

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Clock-latency benchmark of a whole netlist through the frontier-sharded executor
-(BASELINE configs #3 / #4 shape).  Single GPU: `python tools/bench_netlist.py --net mux-ram`;
-N GPUs: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
-tools/bench_netlist.py --net mux-ram`.  Inputs are fresh encryptions; every output bit is checked
-against the plaintext simulator after the timed clocks.  Prints one JSON line on rank 0."""
+(BASELINE configs #3 / #4 shape).  `python tools/bench_netlist.py --net mux-ram --gpus N`: with N > 1 (or --spawn) it
+re-executes itself under torch.distributed.run, one rank per GPU (bench.launcher: refuses to run when fewer than N
+devices are visible or the launcher's WORLD_SIZE is not N).  Keys are generated on rank 0 and broadcast once over RCCL
+(the north_star's "bootstrapping key broadcast once"); inputs are fresh encryptions; every output bit is checked against
+the plaintext simulator after the timed clocks.  Prints one JSON line on rank 0."""
 import argparse
 import json
 import os
@@ -28,7 +29,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--net", default="mux-ram", choices=sorted(NETS))
     ap.add_argument("--clocks", type=int, default=2)
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--spawn", action="store_true", help="go through torch.distributed.run even for one GPU (RCCL with one rank)")
     args = ap.parse_args()
+    import bench
+
+    rank, world, local, distributed = bench.launcher(args, script=os.path.abspath(__file__))
     import torch
     import torch.distributed as dist
 
@@ -38,11 +44,13 @@ def main():
     from iyokan_amd.params import params_128bit
     from netlist_util import gold, drive_cycle, input_streams, load_packet
 
-    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.device_count() <= local:
+        print(f"bench_netlist: rank {rank} wants cuda:{local} but {torch.cuda.device_count()} device(s) are visible", file=sys.stderr)
+        sys.exit(bench.EXIT_BAD_WORLD)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
     fname, kind, pkt = NETS[args.net]
@@ -54,11 +62,15 @@ def main():
         nl = (N.load_iyokanl1_json if kind == "l1" else N.load_yosys_json)(gold(fname))
     streams = input_streams(load_packet(gold(pkt))) if pkt else {}
     p = params_128bit()
-    keys = client.keygen(p, seed=1)   # deterministic: every rank derives identical keys (bench.py shows the RCCL broadcast)
+    keys = client.keygen(p, seed=1) if rank == 0 else bench.empty_keys(p)
+    if distributed:
+        keys = bench.broadcast_keys(keys, dist, dev, rank)   # rank 0's key material, once, over RCCL
     hip.initialize(keys, device_ids=(local,))
     plan = FrontierPlan(nl, world)
     be = HipBackend(plan.num_slots, p, dev)
     ex = FrontierExecutor(plan, be, rank, world, dist if world > 1 else None)
+    if distributed and world == 1:
+        dist.barrier()   # one-rank RCCL communicator (--spawn): at least one collective on it
     sim = N.PlainSimulator(nl)
     zero = client.trivial(p, 0)
     rng = np.random.default_rng(5)
@@ -101,12 +113,12 @@ def main():
     if rank == 0:
         rot = nl.rotations()
         best = min(times[1:])
-        print(json.dumps({"net": args.net, "n_gpus": world, "levels": len(plan.levels), "rotations_per_clock": rot,
+        print(json.dumps({"net": args.net, "n_gpus": world, "rccl_world_size": dist.get_world_size() if distributed else None, "levels": len(plan.levels), "rotations_per_clock": rot,
                           "s_per_clock": best, "rotations_per_s": rot / best, "collectives_per_clock": len(plan.levels) if world > 1 else 0,
                           "outputs_match_plaintext": ok, "ntt_path": hip.ntt_path()}))
     be.close()
     hip.cleanup()
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
     if not ok:
         raise SystemExit("output mismatch")
