@@ -149,6 +149,18 @@ int iyk_hip_arena_sync_slots(iyk_hip_stream* st_src, const uint32_t* d_src, uint
                              iyk_hip_stream* st_dst, uint32_t* d_dst, uint64_t dst_slots, uint64_t count,
                              const int32_t* slots);
 
+/* The same exchange with ONE gather on the source and ndst destinations (the level boundary of an in-process multi-GPU
+ * run: every other replica needs the rows this GPU produced).  Destination streams must be distinct and differ from
+ * st_src.  Copies between different devices are hipMemcpyPeerAsync: direct over xGMI where iyk_hip_init enabled peer
+ * access (iyk_hip_peer_access), staged through host memory by the runtime otherwise — same result either way. */
+int iyk_hip_arena_sync_slots_multi(iyk_hip_stream* st_src, const uint32_t* d_src, uint64_t src_slots, int ndst,
+                                   iyk_hip_stream* const* st_dst, uint32_t* const* d_dst, const uint64_t* dst_slots,
+                                   uint64_t count, const int32_t* slots);
+
+/* 1: GPU gpu_a reads GPU gpu_b's memory directly (hipDeviceEnablePeerAccess succeeded in iyk_hip_init, or same device);
+ * 0: copies between them go through host memory; < 0: error.  Indices are positions in iyk_hip_init's device list. */
+int iyk_hip_peer_access(int gpu_a, int gpu_b);
+
 /* TRLWE lvl1 buffers (a(X) then b(X), 2N words each) for the CMUX-memory tasks: replaces
  * cufhe::cuFHETRLWElvl1 (/root/reference/src/iyokan_cufhe.hpp:592-661).  upload / download move a
  * contiguous range; the host side holds TFHEpp::TRLWE<lvl1param> in the same word order. */

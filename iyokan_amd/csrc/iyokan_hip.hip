@@ -91,6 +91,7 @@ struct Global {
     int tp_kernel = 32;           // wave-per-rotation kernel: 32 = blind_rotate_fp_kernel (2 waves / SIMD), 16 = blind_rotate_fp_t16_kernel (3 waves / SIMD)
     fp::NttConsts fpc{};
     std::vector<Device> devs;
+    std::vector<char> peer;       // [a * ngpu + b]: device a reads device b's memory directly (peer access enabled)
     std::atomic<int> nstreams{0};
     uint64_t key_bytes = 0;
 } G;
@@ -656,6 +657,23 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
         g_last_error = keep;
         return rc;
     }
+    // peer access between every pair of distinct devices (the in-process multi-GPU exchange, iyk_hip_arena_sync_slots):
+    // enabled where the topology allows it, recorded either way — without it the runtime stages peer copies through host
+    // memory, which is correct and slower (iyk_hip_peer_access reports which).
+    std::vector<char> peer((size_t)ngpu * ngpu, 0);
+    for (int a = 0; a < ngpu; ++a)
+        for (int b = 0; b < ngpu; ++b) {
+            if (devs[a].ordinal == devs[b].ordinal) {
+                peer[(size_t)a * ngpu + b] = 1;
+                continue;
+            }
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devs[a].ordinal, devs[b].ordinal) != hipSuccess || !can) continue;
+            if (hipSetDevice(devs[a].ordinal) != hipSuccess) continue;
+            const hipError_t e = hipDeviceEnablePeerAccess(devs[b].ordinal, 0);
+            if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) peer[(size_t)a * ngpu + b] = 1;
+            (void)hipGetLastError();
+        }
     const char* dbg = std::getenv("IYK_HIP_DEBUG");
     const char* tk = std::getenv("IYK_HIP_TP_KERNEL");  // w32 / t16: the wave-per-rotation kernel of the size-based dispatch
     G.ks_kernel = 1;
@@ -666,6 +684,7 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
     G.fpc = fpt.c;
     G.ksk_stride = stride;
     G.devs = devs;
+    G.peer = peer;
     G.key_bytes = bk_words * sizeof(u64) * (use_fp ? split : 1) + ksk_pad.size() * sizeof(u32) + 2 * NTT_N * sizeof(u64);
     G.init.store(true);
     return IYK_OK;
@@ -853,21 +872,34 @@ int iyk_hip_arena_download_slots(iyk_hip_stream* st, const uint32_t* d_arena, ui
     IYK_API_END
 }
 
-int iyk_hip_arena_sync_slots(iyk_hip_stream* st_src, const uint32_t* d_src, uint64_t src_slots, iyk_hip_stream* st_dst,
-                             uint32_t* d_dst, uint64_t dst_slots, uint64_t count, const int32_t* slots)
+// One source replica, ndst destination replicas: gather the listed slots ONCE into the source's staging buffer, then every
+// destination pulls the rows (peer copy over xGMI where iyk_hip_init could enable peer access, else the runtime stages
+// the copy through host memory) and scatters them into its arena.  Event-ordered, never blocks the host.
+int iyk_hip_arena_sync_slots_multi(iyk_hip_stream* st_src, const uint32_t* d_src, uint64_t src_slots, int ndst,
+                                   iyk_hip_stream* const* st_dst, uint32_t* const* d_dst, const uint64_t* dst_slots,
+                                   uint64_t count, const int32_t* slots)
 {
     IYK_API_BEGIN
     if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
-    if (!st_src || !st_dst || !d_src || !d_dst || !slots) return fail(IYK_ERR_INVALID, "null argument");
-    if (st_src == st_dst) return fail(IYK_ERR_INVALID, "source and destination streams must differ");
-    if (count == 0) return IYK_OK;
+    if (!st_src || !d_src || !slots || ndst < 0 || (ndst > 0 && (!st_dst || !d_dst || !dst_slots)))
+        return fail(IYK_ERR_INVALID, "null argument");
+    if (ndst > MAX_GPUS) return fail(IYK_ERR_INVALID, "too many destinations");
+    uint64_t min_slots = src_slots;
+    for (int d = 0; d < ndst; ++d) {
+        if (!st_dst[d] || !d_dst[d]) return fail(IYK_ERR_INVALID, "null argument");
+        if (st_dst[d] == st_src) return fail(IYK_ERR_INVALID, "source and destination streams must differ");
+        for (int e = 0; e < d; ++e)
+            if (st_dst[e] == st_dst[d]) return fail(IYK_ERR_INVALID, "destination streams must be distinct");
+        if (dst_slots[d] < min_slots) min_slots = dst_slots[d];
+    }
+    if (count == 0 || ndst == 0) return IYK_OK;
     if (count > (1u << 24)) return fail(IYK_ERR_INVALID, "too many slots in one transfer");
-    int rc = check_slot_list(count, slots, src_slots < dst_slots ? src_slots : dst_slots);
+    int rc = check_slot_list(count, slots, min_slots);
     if (rc) return rc;
     const size_t n1 = (size_t)G.p.n + 1;
     const size_t idx_bytes = (count * sizeof(int32_t) + 15) & ~(size_t)15, row_bytes = count * n1 * sizeof(u32);
-    // source GPU: gather the listed slots into its staging buffer
-    size_t so = 0, dof = 0;
+    // source GPU: gather the listed slots into its staging buffer, once
+    size_t so = 0;
     if ((rc = set_device(st_src->gpu))) return rc;
     if ((rc = acquire_stage(st_src, idx_bytes + row_bytes, &so))) return rc;
     std::memcpy(st_src->h_stage + so, slots, count * sizeof(int32_t));
@@ -876,24 +908,50 @@ int iyk_hip_arena_sync_slots(iyk_hip_stream* st_src, const uint32_t* d_src, uint
                        (const int32_t*)(st_src->d_stage + so), (u32*)(st_src->d_stage + so + idx_bytes), G.p.n);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(st_src->xfer, st_src->s));
-    // destination GPU: wait for the gather, pull the rows over the fabric (xGMI peer copy), scatter
-    if ((rc = set_device(st_dst->gpu))) return rc;
-    if ((rc = acquire_stage(st_dst, idx_bytes + row_bytes, &dof))) return rc;
-    std::memcpy(st_dst->h_stage + dof, slots, count * sizeof(int32_t));
-    HIP_TRY(hipMemcpyAsync(st_dst->d_stage + dof, st_dst->h_stage + dof, idx_bytes, hipMemcpyHostToDevice, st_dst->s));
-    HIP_TRY(hipStreamWaitEvent(st_dst->s, st_src->xfer, 0));
-    HIP_TRY(hipMemcpyAsync(st_dst->d_stage + dof + idx_bytes, st_src->d_stage + so + idx_bytes, row_bytes, hipMemcpyDefault,
-                           st_dst->s));
-    HIP_TRY(hipEventRecord(st_dst->xfer2, st_dst->s));
-    hipLaunchKernelGGL(scatter_slots_kernel, dim3((unsigned)count), dim3(256), 0, st_dst->s, d_dst,
-                       (const int32_t*)(st_dst->d_stage + dof), (const u32*)(st_dst->d_stage + dof + idx_bytes), G.p.n);
-    HIP_TRY(hipGetLastError());
-    if ((rc = release_stage(st_dst))) return rc;
-    // the source staging half is reusable once the peer copy has read it
+    const int src_ord = G.devs[st_src->gpu].ordinal;
+    for (int d = 0; d < ndst; ++d) {
+        // destination GPU: wait for the gather, pull the rows over the fabric, scatter
+        iyk_hip_stream* sd = st_dst[d];
+        size_t dof = 0;
+        if ((rc = set_device(sd->gpu))) return rc;
+        if ((rc = acquire_stage(sd, idx_bytes + row_bytes, &dof))) return rc;
+        std::memcpy(sd->h_stage + dof, slots, count * sizeof(int32_t));
+        HIP_TRY(hipMemcpyAsync(sd->d_stage + dof, sd->h_stage + dof, idx_bytes, hipMemcpyHostToDevice, sd->s));
+        HIP_TRY(hipStreamWaitEvent(sd->s, st_src->xfer, 0));
+        const int dst_ord = G.devs[sd->gpu].ordinal;
+        if (dst_ord == src_ord)
+            HIP_TRY(hipMemcpyAsync(sd->d_stage + dof + idx_bytes, st_src->d_stage + so + idx_bytes, row_bytes,
+                                   hipMemcpyDeviceToDevice, sd->s));
+        else
+            HIP_TRY(hipMemcpyPeerAsync(sd->d_stage + dof + idx_bytes, dst_ord, st_src->d_stage + so + idx_bytes, src_ord,
+                                       row_bytes, sd->s));
+        HIP_TRY(hipEventRecord(sd->xfer2, sd->s));
+        hipLaunchKernelGGL(scatter_slots_kernel, dim3((unsigned)count), dim3(256), 0, sd->s, d_dst[d],
+                           (const int32_t*)(sd->d_stage + dof), (const u32*)(sd->d_stage + dof + idx_bytes), G.p.n);
+        HIP_TRY(hipGetLastError());
+        if ((rc = release_stage(sd))) return rc;
+    }
+    // the source staging half is reusable once every peer copy has read it
     if ((rc = set_device(st_src->gpu))) return rc;
-    HIP_TRY(hipStreamWaitEvent(st_src->s, st_dst->xfer2, 0));
+    for (int d = 0; d < ndst; ++d) HIP_TRY(hipStreamWaitEvent(st_src->s, st_dst[d]->xfer2, 0));
     return release_stage(st_src);
     IYK_API_END
+}
+
+int iyk_hip_arena_sync_slots(iyk_hip_stream* st_src, const uint32_t* d_src, uint64_t src_slots, iyk_hip_stream* st_dst,
+                             uint32_t* d_dst, uint64_t dst_slots, uint64_t count, const int32_t* slots)
+{
+    return iyk_hip_arena_sync_slots_multi(st_src, d_src, src_slots, 1, &st_dst, &d_dst, &dst_slots, count, slots);
+}
+
+/* 1 when GPU `src` can read GPU `dst`'s memory directly (peer access enabled by iyk_hip_init), 0 when copies between
+ * them are staged through the host by the runtime, < 0 on error */
+int iyk_hip_peer_access(int gpu_a, int gpu_b)
+{
+    if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
+    const int n = (int)G.devs.size();
+    if (gpu_a < 0 || gpu_a >= n || gpu_b < 0 || gpu_b >= n) return fail(IYK_ERR_INVALID, "gpu_index out of range");
+    return G.peer[gpu_a * n + gpu_b] ? 1 : 0;
 }
 
 /* ---- the hot path ------------------------------------------------------------------------ */
@@ -914,7 +972,10 @@ int iyk_hip_gate_batch(iyk_hip_stream* st, uint32_t* d_arena, uint64_t arena_slo
     std::vector<RotJob> rot;
     std::vector<KsJob> ks;
     std::vector<EwJob> ew;
-    rot.reserve(count);
+    size_t nmux = 0;
+    for (uint64_t g = 0; g < count; ++g) nmux += (ops[g] == IYK_OP_MUX);
+    if (count + nmux > (size_t)INT32_MAX) return fail(IYK_ERR_INVALID, "batch too large: more than 2^31 - 1 rotations");
+    rot.reserve(count + nmux);
     ks.reserve(count);
     for (uint64_t g = 0; g < count; ++g) {
         const int op = ops[g];
@@ -1157,25 +1218,35 @@ int iyk_hip_timing_log_end(iyk_hip_stream* st, uint64_t* batches, double* blind_
     IYK_API_BEGIN
     if (!st) return fail(IYK_ERR_INVALID, "null stream");
     if (!st->log_on) return fail(IYK_ERR_STATE, "timing log not active");
-    HIP_TRY(hipStreamSynchronize(st->s));
+    // Whatever happens below, the log is torn down before returning: a batch that failed half way leaves events that were
+    // never recorded (their elapsed-time query fails), and an early return used to leave log_on set, the events leaked and
+    // every later timing_log_begin answering "already active".
+    const hipError_t sync_err = hipStreamSynchronize(st->s);
     double br = 0.0, ks = 0.0;
-    const size_t nb = st->log_events.size() / 3;
-    for (size_t b = 0; b < nb; ++b) {
+    size_t nb = 0, broken = 0;
+    for (size_t b = 0; 3 * b + 2 < st->log_events.size(); ++b) {
         float t0 = 0.f, t1 = 0.f;
-        HIP_TRY(hipEventElapsedTime(&t0, st->log_events[3 * b], st->log_events[3 * b + 1]));
-        HIP_TRY(hipEventElapsedTime(&t1, st->log_events[3 * b + 1], st->log_events[3 * b + 2]));
+        if (hipEventElapsedTime(&t0, st->log_events[3 * b], st->log_events[3 * b + 1]) != hipSuccess ||
+            hipEventElapsedTime(&t1, st->log_events[3 * b + 1], st->log_events[3 * b + 2]) != hipSuccess) {
+            ++broken;  // a triple of a batch whose launches did not all happen: skipped
+            continue;
+        }
         br += t0;
         ks += t1;
+        ++nb;
     }
+    (void)hipGetLastError();
     for (hipEvent_t e : st->log_events) (void)hipEventDestroy(e);
     st->log_events.clear();
     st->log_on = false;
     // the stream's standing events were replaced by logged ones: make fresh ones
     st->ev_br0 = st->ev_br1 = st->ev_ks1 = nullptr;
+    st->timing_valid = false;
     HIP_TRY(hipEventCreate(&st->ev_br0));
     HIP_TRY(hipEventCreate(&st->ev_br1));
     HIP_TRY(hipEventCreate(&st->ev_ks1));
-    st->timing_valid = false;
+    if (sync_err != hipSuccess) return fail(IYK_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(sync_err));
+    (void)broken;
     if (batches) *batches = nb;
     if (blind_rotate_ms) *blind_rotate_ms = br;
     if (keyswitch_ms) *keyswitch_ms = ks;

@@ -32,7 +32,7 @@ EXPORTS = [
     "iyk_hip_bootstrap_trlwe_batch", "iyk_hip_sample_extract_keyswitch_batch",
     "iyk_hip_stream_gpu", "iyk_hip_arena_upload_slots", "iyk_hip_arena_download_slots", "iyk_hip_arena_copy",
     "iyk_hip_arena_sync_slots", "iyk_hip_trlwe_alloc", "iyk_hip_trlwe_free", "iyk_hip_trlwe_upload",
-    "iyk_hip_trlwe_download", "iyk_hip_rotation_round",
+    "iyk_hip_trlwe_download", "iyk_hip_rotation_round", "iyk_hip_arena_sync_slots_multi", "iyk_hip_peer_access",
 ]
 
 
@@ -69,6 +69,9 @@ def lib():
         L.iyk_hip_arena_download_slots.argtypes = [_vp, _vp, u64, u64, _i32p, _u32p]
         L.iyk_hip_arena_copy.argtypes = [_vp, _vp, u64, u64, _vp, u64, u64, u64]
         L.iyk_hip_arena_sync_slots.argtypes = [_vp, _vp, u64, _vp, _vp, u64, u64, _i32p]
+        L.iyk_hip_arena_sync_slots_multi.argtypes = [_vp, _vp, u64, ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                                                     ctypes.POINTER(u64), u64, _i32p]
+        L.iyk_hip_peer_access.argtypes = [ctypes.c_int, ctypes.c_int]
         L.iyk_hip_trlwe_alloc.argtypes = [ctypes.c_int, u64, ctypes.POINTER(_vp)]
         L.iyk_hip_trlwe_free.argtypes = [ctypes.c_int, _vp]
         L.iyk_hip_trlwe_upload.argtypes = [_vp, _vp, u64, u64, u64, _u32p]
@@ -123,6 +126,11 @@ def resident_key_bytes():
 def ntt_path():
     """'fp50' (FP64 FMA field, default for the 128-bit set) or 'goldilocks' (64-bit integer field)."""
     return "fp50" if _check(lib().iyk_hip_ntt_path(), "iyk_hip_ntt_path") == 1 else "goldilocks"
+
+
+def peer_access(gpu_a, gpu_b):
+    """True when GPU a reads GPU b's memory directly (peer access enabled at init), False when copies are host-staged."""
+    return _check(lib().iyk_hip_peer_access(int(gpu_a), int(gpu_b)), "iyk_hip_peer_access") == 1
 
 
 def rotation_round(gpu=0):
@@ -233,6 +241,17 @@ class Stream:
         _check(lib().iyk_hip_arena_sync_slots(self.h, src_arena.ptr, src_arena.slots, dst_stream.h, dst_arena.ptr,
                                               dst_arena.slots, len(slots), slots.ctypes.data_as(_i32p)),
                "iyk_hip_arena_sync_slots")
+
+    def sync_slots_to_many(self, src_arena, dst_streams, dst_arenas, slots):
+        """The same with ONE gather on this stream's GPU and several destination replicas (iyk_hip_arena_sync_slots_multi)."""
+        slots = _i32(slots)
+        n = len(dst_streams)
+        assert n == len(dst_arenas)
+        sts = (_vp * n)(*[s.h for s in dst_streams])
+        ptrs = (_vp * n)(*[a.ptr for a in dst_arenas])
+        caps = (ctypes.c_uint64 * n)(*[a.slots for a in dst_arenas])
+        _check(lib().iyk_hip_arena_sync_slots_multi(self.h, src_arena.ptr, src_arena.slots, n, sts, ptrs, caps, len(slots),
+                                                    slots.ctypes.data_as(_i32p)), "iyk_hip_arena_sync_slots_multi")
 
     def gate_batch(self, arena, ops, in0, in1, in2, out):
         """`len(ops)` independent gates on arena slots; asynchronous (poll query() / sync())."""

@@ -495,13 +495,23 @@ public:
                 inflight_.push_back(id);
             }
             for (int g = 0; g < G; ++g) wi_[g].flush();
-            for (int g = 0; g < G && G > 1; ++g)
+            for (int g = 0; g < G && G > 1; ++g) {
+                if (produced[g].empty()) continue;
+                // one gather on GPU g, fanned out to every other replica
+                std::vector<iyk_hip_stream*> dst_streams;
+                std::vector<uint32_t*> dst_arenas;
+                std::vector<uint64_t> dst_slots;
                 for (int o = 0; o < G; ++o)
-                    if (o != g && !produced[g].empty())
-                        hipCheck(iyk_hip_arena_sync_slots(*wi_[g].stream, wi_[g].arena->device(g), wi_[g].arena->slots(), *wi_[o].stream,
-                                                          wi_[o].arena->device(o), wi_[o].arena->slots(), produced[g].size(),
-                                                          produced[g].data()),
-                                 "iyk_hip_arena_sync_slots");
+                    if (o != g) {
+                        dst_streams.push_back(*wi_[o].stream);
+                        dst_arenas.push_back(wi_[o].arena->device(o));
+                        dst_slots.push_back(wi_[o].arena->slots());
+                    }
+                hipCheck(iyk_hip_arena_sync_slots_multi(*wi_[g].stream, wi_[g].arena->device(g), wi_[g].arena->slots(),
+                                                        (int)dst_streams.size(), dst_streams.data(), dst_arenas.data(),
+                                                        dst_slots.data(), produced[g].size(), produced[g].data()),
+                         "iyk_hip_arena_sync_slots_multi");
+            }
         }
         if (!inflight_.empty()) {
             bool idle = true;

@@ -226,20 +226,36 @@ public:
 class Reader {
     std::istream& is_;
     bool swap_ = false;  // archive written big-endian
+    uint64_t left_ = ~0ull;  // bytes between the read position and the end of the stream (~0: the stream cannot seek)
 
     [[noreturn]] void bad(const char* what) { die(std::string("Invalid archive: ") + what); }
+    // A size tag promises `bytes` more bytes of payload: refuse it BEFORE allocating when the stream does not hold them
+    // (a truncated or hostile packet used to reach std::vector with a 4 GiB request and end in bad_alloc / OOM).
+    void need(uint64_t bytes)
+    {
+        if (bytes > left_) bad("size tag exceeds the remaining bytes");
+    }
 
 public:
     explicit Reader(std::istream& is) : is_(is)
     {
+        const std::istream::pos_type here = is_.tellg();
+        if (here != std::istream::pos_type(-1) && is_.seekg(0, std::ios::end)) {
+            const std::istream::pos_type end = is_.tellg();
+            is_.seekg(here);
+            if (end != std::istream::pos_type(-1) && end >= here) left_ = (uint64_t)(end - here);
+        }
+        is_.clear();
         const uint8_t little = u8();
         if (little > 1) bad("bad endianness flag");
         swap_ = little == 0;
     }
     void raw(void* p, size_t n)
     {
+        if (n > left_) bad("truncated");
         is_.read(static_cast<char*>(p), (std::streamsize)n);
         if ((size_t)is_.gcount() != n) bad("truncated");
+        if (left_ != ~0ull) left_ -= n;
     }
     template <class T>
     T scalar()
@@ -270,7 +286,9 @@ public:
     }
     std::string str()
     {
-        std::string s((size_t)size(1u << 20), '\0');
+        const uint64_t len = size(1u << 20);
+        need(len);
+        std::string s((size_t)len, '\0');
         if (!s.empty()) raw(&s[0], s.size());
         return s;
     }
@@ -283,6 +301,8 @@ public:
     }
     void words(std::vector<uint32_t>& v, size_t n)
     {
+        if (n > (~0ull) / sizeof(uint32_t)) bad("implausible size tag");
+        need((uint64_t)n * sizeof(uint32_t));
         v.resize(n);
         if (n) raw(v.data(), n * sizeof(uint32_t));
         if (swap_)
@@ -291,9 +311,12 @@ public:
     void bitMap(std::map<std::string, std::vector<Bit>>& m)
     {
         const uint64_t n = size(1u << 20);
+        need(n * 16);  // every entry carries at least two 8-byte size tags
         for (uint64_t e = 0; e < n; ++e) {
             std::string key = str();
-            std::vector<Bit> v((size_t)size(1ull << 32));
+            const uint64_t nbits = size(1ull << 32);
+            need(nbits);
+            std::vector<Bit> v((size_t)nbits);
             if (!v.empty()) raw(v.data(), v.size());
             for (Bit& b : v)
                 if (b > 1) bad("Bit value out of range");
@@ -303,6 +326,7 @@ public:
     void arrayMap(std::map<std::string, std::vector<uint32_t>>& m, size_t wordsPer)
     {
         const uint64_t n = size(1u << 20);
+        need(n * 16);
         for (uint64_t e = 0; e < n; ++e) {
             std::string key = str();
             const uint64_t count = size((1ull << 34) / wordsPer);
@@ -316,7 +340,7 @@ public:
     {
         char c;
         is_.read(&c, 1);
-        if (is_.gcount() != 0) bad("trailing bytes");
+        if (is_.gcount() != 0 || (left_ != ~0ull && left_ != 0)) bad("trailing bytes");
     }
 };
 

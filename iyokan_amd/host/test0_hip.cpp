@@ -17,6 +17,7 @@
 //                                   C++ blueprint + packet + clocking protocol on the plain backend; result TOML on stdout
 //   test0_hip --packet-selftest IN.toml [ARCHIVE_OUT]
 //                                   packet.hpp: TOML and cereal PortableBinary round trips (+ a hand-assembled archive)
+//   test0_hip --packet-read ARCHIVE   read a PlainPacket archive: "ok ..." or die("Invalid archive: ...") — never bad_alloc
 //   test0_hip --genkey SK.bin EK.bin | --enc SK.bin IN.toml REQ.bin | --dec SK.bin RES.bin
 //                                   file-based key / packet tools in the shape of `iyokan-packet genkey / genevalkey / enc / dec`
 //                                   (/root/reference/src/iyokan-packet.cpp:144-178) on this repository's KeyArchive
@@ -634,6 +635,10 @@ int main(int argc, char** argv)
         else if (a == "--out" && i + 1 < argc) outFile = argv[++i];
         else if (a == "--snapshot" && i + 1 < argc) snapshotFile = argv[++i];
         else if (a == "--resume" && i + 1 < argc) resumeFile = argv[++i];
+        else if (a == "--packet-read" && i + 1 < argc) {  // read a PlainPacket archive (hostile-input tests): "ok" or die()
+            mode = a;
+            inFile = argv[++i];
+        }
         else if (a == "--packet-selftest" && i + 1 < argc) {
             mode = a;
             inFile = argv[++i];
@@ -695,6 +700,11 @@ int main(int argc, char** argv)
         return 0;
     }
     if (mode == "--packet-selftest") return packetSelfTest(inFile, expect);
+    if (mode == "--packet-read") {
+        const PlainPacket pkt = readFromArchiveFile<PlainPacket>(inFile);
+        std::printf("ok %zu %zu %zu\n", pkt.ram.size(), pkt.rom.size(), pkt.bits.size());
+        return 0;
+    }
     if (mode == "--plain-run") return plainRun(bpFile, inFile, cycles, skipReset, muxRamDir);
     if (mode == "--hip-run") {
         if (cycles < 0) die("--hip-run needs -c N");

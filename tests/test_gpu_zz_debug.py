@@ -79,3 +79,64 @@ def test_two_gpu_replicas_on_one_device(keys128, oracle128):
             st.destroy()
     finally:
         hip.cleanup()
+
+
+@pytest.mark.parametrize("ids", [(0, 0, 0), "distinct"])
+def test_replica_exchange_fan_out(keys128, oracle128, ids):
+    """iyk_hip_arena_sync_slots_multi: ONE gather on the producing replica, fanned out to every other replica.  Three
+    replicas aliased to device 0 run everywhere; the `distinct` case needs >= 2 visible GPUs (skipped on a 1-GPU box —
+    run it on the multi-GPU node before advertising numGPU > 1): there the copies are hipMemcpyPeerAsync
+    between different devices, over xGMI when iyk_hip_peer_access says 1, host-staged by the runtime when it says 0;
+    the result must be the oracle's either way."""
+    import torch
+
+    from iyokan_amd import hip
+
+    if ids == "distinct":
+        n = min(torch.cuda.device_count(), 4)
+        if n < 2:
+            pytest.skip("needs at least two visible GPUs")
+        ids = tuple(range(n))
+    G = len(ids)
+    hip.initialize(keys128, device_ids=ids)
+    try:
+        assert hip.lib().iyk_hip_num_gpus() == G
+        for a in range(G):
+            for b in range(G):
+                assert hip.peer_access(a, b) in (True, False)
+                if ids[a] == ids[b]:
+                    assert hip.peer_access(a, b)
+        p = keys128.params
+        rng = np.random.default_rng(9)
+        nin, ng = 24, 30
+        bits = rng.integers(0, 2, size=nin).astype(np.uint8)
+        host = np.zeros((nin + ng, p.n + 1), dtype=np.uint32)
+        host[:nin] = client.encrypt_bits(keys128, bits, seed=29)
+        ops = rng.choice([OPS["NAND"], OPS["XNOR"], OPS["MUX"]], size=ng).astype(np.int32)
+        in0, in1, in2 = (rng.integers(0, nin, size=ng).astype(np.int32) for _ in range(3))
+        in2 = np.where(ops == OPS["MUX"], in2, -1).astype(np.int32)
+        out = np.arange(nin, nin + ng, dtype=np.int32)
+        streams = [hip.Stream(g) for g in range(G)]
+        arenas = [hip.Arena(nin + ng, gpu_index=g) for g in range(G)]
+        for st, ar in zip(streams, arenas):
+            st.upload(ar, 0, host)
+        mine = [np.arange(g, ng, G) for g in range(G)]
+        for g in range(G):
+            sel = mine[g]
+            streams[g].gate_batch(arenas[g], ops[sel], in0[sel], in1[sel], in2[sel], out[sel])
+        for g in range(G):
+            others = [o for o in range(G) if o != g]
+            streams[g].sync_slots_to_many(arenas[g], [streams[o] for o in others], [arenas[o] for o in others], out[mine[g]])
+        got = [st.download(ar, 0, nin + ng) for st, ar in zip(streams, arenas)]
+        ref = host.copy()
+        oracle128.gate_batch(ops, in0, in1, in2, out, ref, nthreads=os.cpu_count() or 1)
+        for g in range(G):
+            assert np.array_equal(got[g], ref), g
+        with pytest.raises(hip.IykHipError, match="distinct"):
+            streams[0].sync_slots_to_many(arenas[0], [streams[1], streams[1]], [arenas[1], arenas[1]], out[:2])
+        for ar in arenas:
+            ar.free()
+        for st in streams:
+            st.destroy()
+    finally:
+        hip.cleanup()

@@ -106,3 +106,28 @@ def test_tfhe_packet_archive_round_trip(keys80):
     assert back.to_archive() == data
     assert back.decrypt(keys80).same_content(plain)
     assert set(back.ramInTLWE) == {"ram"} and back.ramInTLWE["ram"].shape == (16, keys80.params.n + 1)
+
+
+def test_hostile_size_tags_are_refused_before_allocation(tmp_path):
+    """a size tag is checked against the bytes the stream still holds BEFORE anything is allocated — a
+    truncated or hostile archive ends in die("Invalid archive: ..."), not in a 4 GiB vector, bad_alloc or std::terminate."""
+    import struct
+
+    def u64(v):
+        return struct.pack("<Q", v)
+
+    good = b"\x01" + u64(0) + u64(0) + u64(1) + u64(1) + b"x" + u64(2) + b"\x01\x00" + b"\x01"   # bits = {x: [1, 0]}, no cycles
+    cases = {
+        "good": (good, 0, "ok 0 0 1"),
+        "huge bit vector": (b"\x01" + u64(1) + u64(3) + b"abc" + u64(1 << 31), 1, "size tag exceeds the remaining bytes"),
+        "huge key": (b"\x01" + u64(1) + u64((1 << 20) - 1), 1, "size tag exceeds the remaining bytes"),
+        "million entries": (b"\x01" + u64(1 << 20), 1, "size tag exceeds the remaining bytes"),
+        "trailing": (good + b"\x00", 1, "trailing bytes"),
+        "truncated": (good[:-3], 1, "Invalid archive"),
+    }
+    for name, (data, rc, text) in cases.items():
+        f = tmp_path / "a.bin"
+        f.write_bytes(data)
+        out = subprocess.run([_exe(), "--packet-read", str(f)], capture_output=True, text=True, timeout=60)
+        assert out.returncode == rc, (name, out.returncode, out.stdout, out.stderr)
+        assert text in out.stdout + out.stderr, (name, out.stdout, out.stderr)
