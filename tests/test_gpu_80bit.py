@@ -135,6 +135,9 @@ def test_80bit_full_size_flat_nand_property(keys80, oracle80):
     finally:
         hip.cleanup()
     assert np.array_equal(client.decrypt_bits(keys80, got), 1 - (bits[ia] & bits[ib]))
+    import numpy_tfhe
+
+    numpy_tfhe.check_noise_against_cggi(keys80, got, 1 - (bits[ia] & bits[ib]), rel_tol=0.05)   # noise KAT, 65 536 outputs
     sample = rng.choice(G, size=32, replace=False)
     ref = np.zeros((nin + 32, p.n + 1), dtype=np.uint32)
     ref[:nin] = enc

@@ -232,6 +232,11 @@ def test_full_size_flat_nand_property(gpu128, keys128, oracle128):
     arena.free()
     want = 1 - (bits[ia] & bits[ib])
     assert np.array_equal(client.decrypt_bits(keys128, got), want)
+    # noise KAT over all 65 536 outputs: mean and variance of the phase error as CGGI predicts for this key (5 % = 9 sigma
+    # of the variance estimate; tests/numpy_tfhe.py)
+    import numpy_tfhe
+
+    numpy_tfhe.check_noise_against_cggi(keys128, got, want, rel_tol=0.05)
     sample = rng.choice(G, size=64, replace=False)
     ref = np.zeros((nin + 64, p.n + 1), dtype=np.uint32)
     ref[:nin] = enc
