@@ -16,7 +16,7 @@ lib: $(LIBDIR)/libiyokan_hip.so
 
 $(LIBDIR)/libiyokan_hip.so: $(CSRC)/iyokan_hip.hip $(HDRS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -shared -o $@ $<
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -shared -DIYK_BUILD_ID='"$(shell python3 tools/src_hash.py)"' -o $@ $<
 $(LIBDIR)/libiyokan_client.so: $(CSRC)/client.cpp $(HDRS)
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(HOST_FLAGS) -o $@ $<

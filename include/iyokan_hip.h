@@ -249,6 +249,11 @@ int iyk_hip_timing_log_end(iyk_hip_stream* st, uint64_t* batches, double* blind_
  * wave; the default where instantiated); both subtract the same rows mod 2^32, so they agree word for word. */
 int iyk_hip_ntt_path(void);
 
+/* Identity of the build: 16 hex digits of the SHA-256 over the sources the library was compiled from (tools/src_hash.py;
+ * "unknown" when built without -DIYK_BUILD_ID).  Measurement tooling stamps counter files with it, so that an
+ * instruction count is never paired with a duration of a different kernel build. */
+const char* iyk_hip_build_id(void);
+
 /* Rotations one full round of the default wave-per-rotation kernel holds on GPU `gpu_index` (resident waves: 11 per
  * CU for t16, 8 per CU for w32).  A scheduler that can choose its batch sizes does best with multiples of it; the
  * remainder of a batch goes to the workgroup-per-rotation kernel (<= 1280 rotations) or one more partial round.

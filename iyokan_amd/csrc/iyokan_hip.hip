@@ -582,6 +582,12 @@ int iyk_hip_get_params(iyk_params* out)
 /* 1 = FP64 field path (p = 3 * 2^48 + 1097729), 0 = Goldilocks integer path */
 int iyk_hip_ntt_path(void) { return G.init.load() ? (G.use_fp ? 1 : 0) : IYK_ERR_STATE; }
 
+#ifndef IYK_BUILD_ID
+#define IYK_BUILD_ID "unknown"
+#endif
+/* first 16 hex digits of the SHA-256 over the sources this library was built from (tools/src_hash.py) */
+const char* iyk_hip_build_id(void) { return IYK_BUILD_ID; }
+
 int iyk_hip_rotation_round(int gpu_index)
 {
     if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");

@@ -33,6 +33,7 @@ EXPORTS = [
     "iyk_hip_stream_gpu", "iyk_hip_arena_upload_slots", "iyk_hip_arena_download_slots", "iyk_hip_arena_copy",
     "iyk_hip_arena_sync_slots", "iyk_hip_trlwe_alloc", "iyk_hip_trlwe_free", "iyk_hip_trlwe_upload",
     "iyk_hip_trlwe_download", "iyk_hip_rotation_round", "iyk_hip_arena_sync_slots_multi", "iyk_hip_peer_access",
+    "iyk_hip_build_id",
 ]
 
 
@@ -126,6 +127,13 @@ def resident_key_bytes():
 def ntt_path():
     """'fp50' (FP64 FMA field, default for the 128-bit set) or 'goldilocks' (64-bit integer field)."""
     return "fp50" if _check(lib().iyk_hip_ntt_path(), "iyk_hip_ntt_path") == 1 else "goldilocks"
+
+
+def build_id():
+    """Source hash the loaded libiyokan_hip.so was built from (tools/src_hash.py), or 'unknown'."""
+    f = lib().iyk_hip_build_id
+    f.restype = ctypes.c_char_p
+    return f().decode()
 
 
 def peer_access(gpu_a, gpu_b):

@@ -131,3 +131,28 @@ def test_launcher_builds_a_torchrun_command(monkeypatch):
     monkeypatch.setenv("RANK", "1")
     monkeypatch.setenv("LOCAL_RANK", "1")
     assert bench.launcher(args) == (1, 2, 1, True)
+
+
+def test_counters_are_tied_to_the_build(tmp_path, monkeypatch):
+    """bench.counters(): a committed counter file prices a live duration only when it was measured on the build that is
+    loaded now (VERDICT r02 weak #7): same workload + same build_id -> used; another build -> dropped, with the reason."""
+    import argparse
+    import json
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    (tmp_path / "profiles").mkdir()
+    rec = {"workload": {"gates_per_launch": 65536, "params": "128bit", "op": "NAND"}, "build_id": "aaaa", "valu_insts_per_launch": 1.0}
+    (tmp_path / "profiles" / "c.json").write_text(json.dumps(rec))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "COUNTER_FILES", ("missing.json", "c.json"))
+    args = argparse.Namespace(params="128bit", op="NAND")
+    got, why = bench.counters(args, 65536, "aaaa")
+    assert got["valu_insts_per_launch"] == 1.0 and got["_file"] == "profiles/c.json" and why is None
+    got, why = bench.counters(args, 65536, "bbbb")
+    assert got is None and "build aaaa" in why and "bbbb" in why
+    got, why = bench.counters(args, 8192, "aaaa")
+    assert got is None and "no counter file" in why
+    got, why = bench.counters(argparse.Namespace(params="80bit", op="NAND"), 65536, "aaaa")
+    assert got is None

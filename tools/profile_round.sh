@@ -2,35 +2,41 @@
 # One-shot profile of the headline workload on the GPU box (run through gpurun):
 #   bash tools/profile_round.sh <tag>
 # writes gpurun_out/<tag>_bench.json, <tag>_kernel_trace.txt, <tag>_pmc.txt, <tag>_counters.json
-# (copy the ones to keep into profiles/; bench.py reads profiles/r02_counters.json).  Counters are collected
-# in their own --pmc passes, never together with trace domains.
-tag=${1:-r02}
+# (copy the ones to keep into profiles/; bench.py reads profiles/r03_counters.json and uses it only while its build_id —
+# the hash of the kernel sources, tools/src_hash.py — equals the loaded library's).  Counters are collected in their own
+# --pmc passes, never together with trace domains.  PARAMS=80bit profiles the 80-bit set.
+tag=${1:-r03}
+PARAMS=${PARAMS:-128bit}
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
 mkdir -p gpurun_out
 if [ -z "$PMC_ONLY" ]; then
-timeout 600 python bench.py 2>/dev/null | tail -1 > gpurun_out/${tag}_bench.json
-rm -rf /tmp/prof_kt && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python bench.py --cpu-sample 0 > /tmp/kt.log 2>&1
+timeout 600 python bench.py --params $PARAMS 2>/dev/null | tail -1 > gpurun_out/${tag}_bench.json
+rm -rf /tmp/prof_kt && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python bench.py --params $PARAMS --cpu-sample 0 > /tmp/kt.log 2>&1
 python tools/rocprof_summary.py $(find /tmp/prof_kt -name "*.db" | head -1) > gpurun_out/${tag}_kernel_trace.txt
 fi
 {
   echo "# rocprofv3 --pmc passes, 65536 NAND / launch (bench.py --steps 1 --warmup 0); FETCH/WRITE in KiB (gfx950: double FETCH_SIZE)"
   for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD" \
              "GRBM_GUI_ACTIVE" "SQ_BUSY_CYCLES SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
-    rm -rf /tmp/prof_pmc; timeout 300 rocprofv3 --pmc $grp -d /tmp/prof_pmc -o pmc -- python bench.py --steps 1 --warmup 0 --cpu-sample 0 > /tmp/pmc.log 2>&1
+    rm -rf /tmp/prof_pmc; timeout 300 rocprofv3 --pmc $grp -d /tmp/prof_pmc -o pmc -- python bench.py --params $PARAMS --steps 1 --warmup 0 --cpu-sample 0 > /tmp/pmc.log 2>&1
     db=$(find /tmp/prof_pmc -name "*.db" 2>/dev/null | head -1)
     if [ -n "$db" ]; then
       python tools/rocprof_summary.py $db --pmc | grep -v "^#\|^ calls" | grep "blind_rotate\|keyswitch\|^ *[0-9]" | grep -v "copyBuffer\|at::native"
     else echo "# pass failed: $grp"; tail -5 /tmp/pmc.log | sed 's/^/#   /'; fi
   done
 } > gpurun_out/${tag}_pmc.txt
-python - "$tag" <<'PY'
+python - "$tag" "$PARAMS" <<'PY'
 import json, re, sys
-tag = sys.argv[1]
+sys.path.insert(0, ".")
+from iyokan_amd import hip
+tag, params_name = sys.argv[1], sys.argv[2]
+kname = None
 vals, durs = {}, []
 for line in open(f"gpurun_out/{tag}_pmc.txt"):
     m = re.match(r"(\w+)\s+([\d.]+)\s+n=\d+\s+(.*)", line)
     if m and "blind_rotate" in m.group(3):
         vals[m.group(1)] = float(m.group(2))
+        kname = m.group(3).strip().split("(")[0].replace("void ", "")
     m = re.match(r"\s*(\d+)\s+(\d+)\s+(\d+)\s+[\d.]+\s+(.*)", line)   # calls total_ns avg_ns pct kernel
     if m and "blind_rotate" in m.group(4):
         durs.append(float(m.group(3)))
@@ -41,9 +47,11 @@ if "FETCH_SIZE" in vals:
                 "FETCH_SIZE correction prescribed by MI355X_MICROARCH.md (HBM section).  valu_insts_per_launch = "
                 "SQ_INSTS_VALU (wave-instructions, deterministic for a given kernel build and workload).  "
                 "sustained_clock_ghz = GRBM_GUI_ACTIVE / 8 XCDs / kernel duration of that pass.  bench.py reads this "
-                "file for roofline.traffic and roofline.valu when the workload matches.",
-        "kernel": "blind_rotate_fp_kernel<Decomp<3,6,1>>",
-        "workload": {"gates_per_launch": 65536, "params": "128bit", "op": "NAND"},
+                "file for roofline.traffic and roofline.valu when the workload AND build_id (tools/src_hash.py: hash of "
+                "the kernel sources the profiled library was built from) match the loaded library.",
+        "kernel": kname,
+        "build_id": hip.build_id(),
+        "workload": {"gates_per_launch": 65536, "params": params_name, "op": "NAND"},
         "FETCH_SIZE_KiB": vals["FETCH_SIZE"], "WRITE_SIZE_KiB": vals.get("WRITE_SIZE", 0.0),
         "traffic_bytes_per_launch": int((2 * vals["FETCH_SIZE"] + vals.get("WRITE_SIZE", 0.0)) * 1024),
     }
@@ -62,7 +70,7 @@ if "FETCH_SIZE" in vals:
             if 0.5 < clk < 3.0:
                 out["sustained_clock_ghz"] = round(clk, 3)
     try:  # micro-benchmark ceilings (tools/ubench/valu_occ.hip) are measured separately: carry them over
-        prev = json.load(open("profiles/r02_counters.json"))
+        prev = json.load(open("profiles/r02_counters.json"))  # the stream ceilings do not depend on the kernel build
         if "issue_ceiling" in prev:
             out["issue_ceiling"] = prev["issue_ceiling"]
     except (OSError, ValueError):
