@@ -33,6 +33,7 @@
 #pragma once
 #include <cstdint>
 #include <cstring>
+#include <cmath>
 #include <fstream>
 #include <istream>
 #include <map>
@@ -419,6 +420,123 @@ inline void readFromArchive(KeyArchive& k, std::istream& is)
         (!k.ksk.empty() && k.ksk.size() != iyk_ksk_words(&p)))
         die("Invalid archive: key sizes do not match the parameter set");
     r.expectEnd();
+}
+
+// ---- import of TFHEpp's OWN key archives (the files stock `iyokan-packet genkey / genevalkey` write) -----------------
+// Twin of iyokan_amd/tfhepp_keys.py — read its header for what is fixed by cereal and by the reference's call sites
+// (/root/reference/src/iyokan_cufhe.cpp:546-549, /root/reference/src/iyokan-packet.cpp:150-160), what is ASSUMED (binary
+// keys, one uint32 per bit; key.lvl0 then key.lvl1 right behind the endianness byte) and why the EvalKey reader SEARCHES
+// for the two blobs instead of walking a struct whose member order cannot be read here.  UNVERIFIED against real TFHEpp.
+namespace tfhepp_import {
+inline uint32_t u32le(const std::vector<unsigned char>& d, size_t o)
+{
+    return (uint32_t)d[o] | ((uint32_t)d[o + 1] << 8) | ((uint32_t)d[o + 2] << 16) | ((uint32_t)d[o + 3] << 24);
+}
+inline bool plausibleNext(const std::vector<unsigned char>& d, size_t o)
+{
+    if (o == d.size()) return true;
+    if (o + 4 > d.size()) return false;
+    const uint32_t w = u32le(d, o);
+    if (w == 0 || ((w & 0x80000000u) && (w & 0x7FFFFFFFu) <= 64)) return true;
+    if (o + 8 <= d.size()) return w <= 4096 && u32le(d, o + 4) == 0;   // u64 size tag of a small unordered_map
+    return false;
+}
+// offset of the unique `nbytes` blob that sits behind an "object follows" pointer id and before a plausible cereal item;
+// 0 = none or ambiguous
+inline size_t findBlob(const std::vector<unsigned char>& d, size_t nbytes)
+{
+    size_t found = 0, count = 0;
+    for (size_t h = 0; h + 4 + nbytes <= d.size(); ++h) {
+        if (d[h + 3] != 0x80 || d[h + 2] != 0 || d[h + 1] != 0 || d[h] < 1 || d[h] > 64) continue;
+        if (!plausibleNext(d, h + 4 + nbytes)) continue;
+        found = h + 4;
+        ++count;
+    }
+    return count == 1 ? found : 0;
+}
+inline std::vector<unsigned char> slurp(const std::string& path)
+{
+    std::ifstream ifs(path, std::ios::binary);
+    if (!ifs) die("Can't open the file to read from; Maybe not found?: " + path);
+    ifs.seekg(0, std::ios::end);
+    const std::streamoff n = ifs.tellg();
+    ifs.seekg(0);
+    std::vector<unsigned char> d((size_t)(n < 0 ? 0 : n));
+    if (!d.empty()) ifs.read(reinterpret_cast<char*>(d.data()), (std::streamsize)d.size());
+    if ((size_t)ifs.gcount() != d.size()) die("Invalid archive: short read: " + path);
+    return d;
+}
+inline void words(const std::vector<unsigned char>& d, size_t o, size_t n, std::vector<uint32_t>& out)
+{
+    out.resize(n);
+    for (size_t i = 0; i < n; ++i) out[i] = u32le(d, o + 4 * i);
+}
+}  // namespace tfhepp_import
+
+// bk<lvl01param> + iksk<lvl10param> of a TFHEpp::EvalKey archive for parameter set `p`; false when this archive does not
+// hold exactly one blob of each size (another parameter set, a truncated file, not an EvalKey)
+inline bool readTFHEppEvalKey(const std::vector<unsigned char>& d, const iyk_params& p, KeyArchive& out)
+{
+    if (d.empty() || d[0] != 1) return false;   // little-endian archives only
+    const size_t bkw = iyk_bk_words(&p), kw = iyk_ksk_words(&p);
+    const size_t ob = tfhepp_import::findBlob(d, 4 * bkw), ok = tfhepp_import::findBlob(d, 4 * kw);
+    if (!ob || !ok) return false;
+    if (!(ob + 4 * bkw + 4 <= ok || ok + 4 * kw + 4 <= ob)) return false;
+    out = KeyArchive{};
+    out.params = p;
+    tfhepp_import::words(d, ob, bkw, out.bk);
+    tfhepp_import::words(d, ok, kw, out.ksk);
+    return true;
+}
+// key.lvl0 + key.lvl1 of a TFHEpp::SecretKey archive: n + N binary words right behind the endianness byte
+inline bool readTFHEppSecretKey(const std::vector<unsigned char>& d, const iyk_params& p, KeyArchive& out)
+{
+    const size_t need = 1 + 4 * ((size_t)p.n + (size_t)p.k * p.N);
+    if (d.size() < need || d[0] != 1) return false;
+    KeyArchive k;
+    k.params = p;
+    tfhepp_import::words(d, 1, p.n, k.s0);
+    tfhepp_import::words(d, 1 + 4 * (size_t)p.n, (size_t)p.k * p.N, k.s1);
+    for (uint32_t v : k.s0)
+        if (v > 1) return false;
+    for (uint32_t v : k.s1)
+        if (v > 1) return false;
+    out = k;
+    return true;
+}
+// sample rows of both keys must decrypt under the secret key (message + noise within 6 sigma): the one check that does
+// not depend on any recollection of TFHEpp's layout
+inline bool verifyImportedKeys(const KeyArchive& sk, const KeyArchive& ek)
+{
+    const iyk_params& p = ek.params;
+    const size_t n1 = (size_t)p.n + 1, nb = (1u << p.basebit) - 1;
+    uint64_t state = 0x9E3779B97F4A7C15ull;
+    auto next = [&](uint64_t m) {
+        state = state * 6364136223846793005ull + 1442695040888963407ull;
+        return (state >> 33) % m;
+    };
+    auto centred = [](uint32_t d) { return (double)(int32_t)d / 4294967296.0; };
+    for (int s = 0; s < 64; ++s) {
+        const size_t i = next(p.N), j = next(p.t), v = next(nb);
+        const uint32_t* row = ek.ksk.data() + ((i * p.t + j) * nb + v) * n1;
+        uint32_t ph = row[p.n];
+        for (uint32_t x = 0; x < p.n; ++x) ph -= row[x] * sk.s0[x];
+        const uint32_t msg = (sk.s1[i] * (uint32_t)(v + 1)) << (32 - (j + 1) * p.basebit);
+        if (std::fabs(centred(ph - msg)) > 6 * p.alpha0 + 1e-9) return false;
+    }
+    const size_t rows = (size_t)(p.k + 1) * p.l;
+    for (int s = 0; s < 64; ++s) {
+        const size_t i = next(p.n), r = next(rows);
+        const uint32_t* a = ek.bk.data() + ((i * rows + r) * 2) * p.N;
+        const uint32_t* b = a + p.N;
+        uint32_t as0 = a[0] * sk.s1[0];
+        for (uint32_t x = 1; x < p.N; ++x) as0 -= a[x] * sk.s1[p.N - x];   // (a * s1)[0] mod X^N + 1
+        const size_t c = r / p.l, j = r % p.l;
+        const uint32_t m = sk.s0[i] << (32 - (j + 1) * p.Bgbit);
+        const uint32_t want = c == 1 ? m : (0u - m * sk.s1[0]);
+        if (std::fabs(centred(b[0] - as0 - want)) > 6 * p.alpha1 + 1e-9) return false;
+    }
+    return true;
 }
 
 template <class T, class... A>

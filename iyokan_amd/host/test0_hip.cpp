@@ -17,6 +17,9 @@
 //                                   C++ blueprint + packet + clocking protocol on the plain backend; result TOML on stdout
 //   test0_hip --packet-selftest IN.toml [ARCHIVE_OUT]
 //                                   packet.hpp: TOML and cereal PortableBinary round trips (+ a hand-assembled archive)
+//   test0_hip --import-tfhepp SK.tfhepp EK.tfhepp SK.bin EK.bin
+//                                   TFHEpp::SecretKey / TFHEpp::EvalKey archives of stock iyokan-packet -> KeyArchive pair
+//                                   (host/packet.hpp readTFHEpp*; unverified against real TFHEpp, verified cryptographically)
 //   test0_hip --packet-read ARCHIVE   read a PlainPacket archive: "ok ..." or die("Invalid archive: ...") — never bad_alloc
 //   test0_hip --genkey SK.bin EK.bin | --enc SK.bin IN.toml REQ.bin | --dec SK.bin RES.bin
 //                                   file-based key / packet tools in the shape of `iyokan-packet genkey / genevalkey / enc / dec`
@@ -635,6 +638,13 @@ int main(int argc, char** argv)
         else if (a == "--out" && i + 1 < argc) outFile = argv[++i];
         else if (a == "--snapshot" && i + 1 < argc) snapshotFile = argv[++i];
         else if (a == "--resume" && i + 1 < argc) resumeFile = argv[++i];
+        else if (a == "--import-tfhepp" && i + 4 < argc) {  // SK.tfhepp EK.tfhepp SK_OUT EK_OUT
+            mode = a;
+            bpFile = argv[++i];
+            inFile = argv[++i];
+            expect = argv[++i];
+            outFile = argv[++i];
+        }
         else if (a == "--packet-read" && i + 1 < argc) {  // read a PlainPacket archive (hostile-input tests): "ok" or die()
             mode = a;
             inFile = argv[++i];
@@ -700,6 +710,24 @@ int main(int argc, char** argv)
         return 0;
     }
     if (mode == "--packet-selftest") return packetSelfTest(inFile, expect);
+    if (mode == "--import-tfhepp") {
+        // stock `iyokan-packet genkey / genevalkey` archives -> this repository's KeyArchive pair (the parameter set is
+        // whichever of the two known sets the archives fit); keys are checked against each other before anything is written
+        const std::vector<unsigned char> skd = tfhepp_import::slurp(bpFile), ekd = tfhepp_import::slurp(inFile);
+        const iyk_params sets[2] = {IYK_PARAMS_128BIT_INIT, IYK_PARAMS_80BIT_INIT};
+        const char* names[2] = {"128bit", "80bit"};
+        for (int k = 0; k < 2; ++k) {
+            KeyArchive sk, ek;
+            if (!readTFHEppEvalKey(ekd, sets[k], ek) || !readTFHEppSecretKey(skd, sets[k], sk)) continue;
+            if (!verifyImportedKeys(sk, ek)) die("TFHEpp import: the evaluation key does not decrypt under this secret key");
+            writeToArchiveFile(expect, sk);
+            writeToArchiveFile(outFile, ek);
+            std::printf("imported %s keys, verified against the secret key\n", names[k]);
+            return 0;
+        }
+        die("TFHEpp import: expected exactly one bk<lvl01param> and one iksk<lvl10param> blob of a known parameter set "
+            "behind cereal pointer ids, and a binary SecretKey (see host/packet.hpp)");
+    }
     if (mode == "--packet-read") {
         const PlainPacket pkt = readFromArchiveFile<PlainPacket>(inFile);
         std::printf("ok %zu %zu %zu\n", pkt.ram.size(), pkt.rom.size(), pkt.bits.size());

@@ -30,9 +30,11 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <fstream>
 #include <random>
 #include <vector>
 
+#include <cereal/archives/portable_binary.hpp>
 #include <tfhe++.hpp>
 
 #include "../include/iyokan_hip.h"
@@ -122,6 +124,24 @@ int main(int argc, char** argv)
                   "KeySwitchingKey<lvl10param> is not the flat u32[kN][t][2^basebit-1][n+1] array iyk_hip_init expects");
     static_assert(sizeof(TLWE0) == sizeof(uint32_t) * (lvl0param::n + 1), "TLWE<lvl0param> is not u32[n+1]");
     CK(iyk_hip_init(1, nullptr, &p, reinterpret_cast<const uint32_t*>(&bk), reinterpret_cast<const uint32_t*>(&iksk)));
+
+    // ---- the same keys as stock `iyokan-packet genkey / genevalkey` would store them (cereal PortableBinary,
+    // /root/reference/src/packet.hpp:325-344): feed the pair to `test0_hip --import-tfhepp crosscheck_sk.tfhepp
+    // crosscheck_ek.tfhepp SK.bin EK.bin` (iyokan_amd/host/packet.hpp readTFHEpp*, iyokan_amd/tfhepp_keys.py) — it must
+    // find both key blobs, verify them against the secret key, and EK.bin must then hold exactly `bk` and `iksk` above.
+    // That validates the key-archive reader against real TFHEpp + cereal in the same run that validates the oracle.
+    {
+        std::ofstream fsk("crosscheck_sk.tfhepp", std::ios::binary), fek("crosscheck_ek.tfhepp", std::ios::binary);
+        {
+            cereal::PortableBinaryOutputArchive ar(fsk);
+            ar(sk);
+        }
+        {
+            cereal::PortableBinaryOutputArchive ar(fek);
+            ar(ek);
+        }
+        std::printf("wrote crosscheck_sk.tfhepp / crosscheck_ek.tfhepp (TFHEpp::SecretKey / TFHEpp::EvalKey, cereal PortableBinary)\n");
+    }
     iyk_hip_stream* st = nullptr;
     CK(iyk_hip_stream_create(0, &st));
 
