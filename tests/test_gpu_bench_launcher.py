@@ -1,0 +1,40 @@
+"""GPU: the benches through their own launcher.  `--spawn` makes `--gpus 1` take the same path as
+`--gpus 8`: re-execution under torch.distributed.run, an RCCL process group (one rank), key broadcast over it, barrier and
+all-reduce / all-gather of the timings — the N > 1 code with N = 1, on the one GPU this box has."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(cmd, timeout):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable] + cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_one_gpu_through_the_launcher():
+    r = _run(["bench.py", "--gpus", "1", "--spawn", "--steps", "1", "--warmup", "0", "--gates", "4096", "--cpu-sample", "0"], 900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["rccl_world_size"] == 1 and len(line["per_rank_ms_per_step"]) == 1
+    assert line["config"]["decrypt_check"] is True and line["value"] > 0
+    assert line["roofline"]["build_id"] and line["roofline"]["contract"]["unit"] == "GB/s"
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    import torch
+
+    r = _run(["bench.py", "--gpus", str(torch.cuda.device_count() + 1), "--steps", "1", "--cpu-sample", "0"], 300)
+    assert r.returncode == 3 and "GPU(s) visible" in r.stderr and "{" not in r.stdout
+
+
+def test_netlist_bench_one_gpu_through_the_launcher():
+    r = _run(["tools/bench_netlist.py", "--net", "counter", "--clocks", "1", "--gpus", "1", "--spawn"], 900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["rccl_world_size"] == 1 and line["outputs_match_plaintext"] is True
