@@ -227,7 +227,7 @@ public:
     }
 
     // ---- snapshot / resume ---------------------------------------------------------------------------------------------
-    static constexpr uint64_t SNAPSHOT_MAGIC = 0x4e5350494859494bull;  // "KIYHIPSN"
+    static constexpr uint64_t SNAPSHOT_MAGIC = 0x325350494859494bull;  // "KIYHIPS2" (format 2: + device ids)
     void writeSnapshot(const std::string& path)
     {
         std::ofstream ofs(path, std::ios::binary);
@@ -239,6 +239,7 @@ public:
             w.str(pr_.bkeyFile);
             w.str(pr_.muxRamDir);
             w.i32(pr_.numGPU);
+            w.u32vec(std::vector<uint32_t>(pr_.deviceIds.begin(), pr_.deviceIds.end()));   // which devices the replicas live on
             w.optInt(pr_.numCycles);
             w.i32(currentCycle_);
             w.u32vec(f_->arena.image());
@@ -260,6 +261,11 @@ public:
             opt.bkeyFile = r.str();
             opt.muxRamDir = r.str();
             opt.numGPU = r.i32();
+            {
+                std::vector<uint32_t> ids;
+                r.u32vec(ids, 64);
+                opt.deviceIds.assign(ids.begin(), ids.end());
+            }
             opt.numCycles = r.optInt();
             cycle = r.i32();
             r.u32vec(image, 1ull << 36);
