@@ -241,6 +241,34 @@ def test_cpp_do_hip_from_files(gpu, keys128, tmp_path):
     assert got2.same_content(expected), got2.diff(expected)
 
 
+def test_cpp_do_hip_from_imported_tfhepp_archives(gpu, keys128, tmp_path):
+    """The deployment path of SURVEY 8(f3): key files in TFHEpp's OWN archive format (as `iyokan-packet genkey /
+    genevalkey` store them; here assembled by cereal's rules around this session's key material, extra members and all)
+    -> `test0_hip --import-tfhepp` (blob search + cryptographic verification) -> `doHIP` on the GPU with the imported
+    evaluation key -> result decrypted with the imported secret key == the reference's expected packet."""
+    import numpy as np
+
+    from iyokan_amd import tfhepp_keys as K
+    from iyokan_amd.packet import PlainPacket
+    from netlist_util import gold
+
+    rng = np.random.default_rng(11)
+    p = keys128.params
+    fft_like = K._ptr(2) + rng.standard_normal(1 << 14).astype("<f8").tobytes()
+    ek_tf, sk_tf = tmp_path / "ek.tfhepp", tmp_path / "sk.tfhepp"
+    ek_tf.write_bytes(K.write_eval_key_like(p, keys128.bk, keys128.ksk, rng.bytes(93), [K.NULL], [fft_like, K.NULL], [K.NULL]))
+    sk_tf.write_bytes(K.write_secret_key_like(p, keys128.s0, keys128.s1, tail=rng.bytes(2048 * 8 + 40)))
+    sk, ek, req, res = (str(tmp_path / n) for n in ("sk.bin", "ek.bin", "req.bin", "res.bin"))
+    out = _cpp(gpu, keys128, ["--import-tfhepp", str(sk_tf), str(ek_tf), sk, ek])
+    assert "imported 128bit keys, verified" in out
+    _cpp(gpu, keys128, ["--enc", sk, gold("test13.in"), req])
+    _cpp(gpu, keys128, ["--do-hip", gold("counter-4bit.toml"), "--bkey", ek, "--in", req, "--out", res, "-c", "3"])
+    (tmp_path / "res.toml").write_text(_cpp(gpu, keys128, ["--dec", sk, res]))
+    expected = PlainPacket.load(gold("test13.out"))
+    got = PlainPacket.load(str(tmp_path / "res.toml"))
+    assert got.same_content(expected), got.diff(expected)
+
+
 def _two_rank_worker(rank, world, port, q):
     """One of two processes sharing GPU 0: the frontier-sharded executor with real ciphertexts and kernels."""
     import hashlib
