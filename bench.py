@@ -378,9 +378,19 @@ def main():
                 "source": pmc["_file"],
                 "build_id": pmc.get("build_id"),
             }
-            for k in ("all_insts_per_launch", "lds_insts_per_launch", "vmem_rd_insts_per_launch", "salu_insts_per_launch"):
+            for k in ("lds_insts_per_launch", "vmem_rd_insts_per_launch", "salu_insts_per_launch", "smem_insts_per_launch"):
                 if pmc.get(k):
                     valu[k] = pmc[k]
+            if pmc.get("all_insts_per_launch"):
+                # Issue view: a SIMD issues one instruction of ANY kind per ~4 cycles, so what a
+                # rotation costs is the TOTAL instruction count (SQ_INSTS: VALU, LDS, VMEM, SALU, SMEM, s_waitcnt, branches)
+                allc = pmc["all_insts_per_launch"]
+                ns_all = br_avg_s * 1e9 / (allc / N_SIMDS)
+                valu["issue"] = {
+                    "all_insts_per_step_per_wave": allc / steps_per_launch,
+                    "ns_per_instruction_per_simd": ns_all,
+                    "frac_of_one_per_4_cycles_at_2.4GHz": VALU_PEAK_NS / ns_all,
+                }
             if pmc.get("sustained_clock_ghz"):               # busy cycles / duration of the profiled launch
                 clk = pmc["sustained_clock_ghz"]
                 valu["sustained_clock_ghz"] = clk

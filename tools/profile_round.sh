@@ -17,7 +17,8 @@ fi
 {
   echo "# rocprofv3 --pmc passes, 65536 NAND / launch (bench.py --steps 1 --warmup 0); FETCH/WRITE in KiB (gfx950: double FETCH_SIZE)"
   for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD" \
-             "GRBM_GUI_ACTIVE" "SQ_BUSY_CYCLES SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
+             "GRBM_GUI_ACTIVE" "SQ_BUSY_CYCLES SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
+             "SQ_INSTS SQ_INSTS_SMEM SQ_INSTS_BRANCH" "SQ_WAVE_CYCLES"; do
     rm -rf /tmp/prof_pmc; timeout 300 rocprofv3 --pmc $grp -d /tmp/prof_pmc -o pmc -- python bench.py --params $PARAMS --steps 1 --warmup 0 --cpu-sample 0 > /tmp/pmc.log 2>&1
     db=$(find /tmp/prof_pmc -name "*.db" 2>/dev/null | head -1)
     if [ -n "$db" ]; then
@@ -59,6 +60,10 @@ if "FETCH_SIZE" in vals:
         out["l2_hit_rate"] = round(vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"]), 4)
     for k_src, k_dst in (("SQ_INSTS_VALU", "valu_insts_per_launch"), ("SQ_INSTS_LDS", "lds_insts_per_launch"),
                          ("SQ_INSTS_SALU", "salu_insts_per_launch"), ("SQ_INSTS_VMEM_RD", "vmem_rd_insts_per_launch"),
+                         ("SQ_INSTS", "all_insts_per_launch"), ("SQ_INSTS_SMEM", "smem_insts_per_launch"),
+                         ("SQ_INSTS_BRANCH", "branch_insts_per_launch"), ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VALU"),
+                         ("SQ_WAIT_ANY", "SQ_WAIT_ANY"), ("SQ_WAIT_INST_ANY", "SQ_WAIT_INST_ANY"),
+                         ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_ANY"), ("SQ_WAVE_CYCLES", "SQ_WAVE_CYCLES"),
                          ("GRBM_GUI_ACTIVE", "GRBM_GUI_ACTIVE"), ("SQ_BUSY_CYCLES", "SQ_BUSY_CYCLES"),
                          ("SQ_WAVES", "SQ_WAVES")):
         if k_src in vals:
