@@ -85,8 +85,10 @@ def test_mux_ram_config3_two_clocks(gpu, keys128):
 
 
 def test_cahp_system_config4_on_gpu(gpu, keys128):
-    """BASELINE config #4: CAHP-ruby core + MUX ROM + MUX RAM from the reference blueprint, program and
-    RAM image of test09.in encrypted, 7 clocks on the GPU -> @reg_x0 = 42, @finflag = 1 (test09-ruby.out)."""
+    """BASELINE config #4: CAHP-ruby core + MUX ROM + MUX RAM from the reference blueprint, program and RAM
+    image of test09.in encrypted, TEN clocks after the reset cycle on the GPU.  After 7 clocks the outputs must be the
+    reference's test09-ruby.out (@reg_x0 = 42, @finflag = 1); after 10, every output port AND every register / memory
+    cell must equal the plaintext evaluator run in lockstep under the same protocol."""
     import torch
 
     from test_system import load_cahp, packet_memories
@@ -104,22 +106,44 @@ def test_cahp_system_config4_on_gpu(gpu, keys128):
     def write_bits(nodes, bits, seed):
         be.write_many([plan.slot[i] for i in nodes], client.encrypt_bits(keys128, bits, seed=seed))
 
+    sim = N.PlainSimulator(nl)
+
+    def write_plain(nodes, bits):
+        for i, b in zip(nodes, bits):
+            sim.val[i] = b
+
     srcs = plan.sources
     write_bits(srcs, [mem.get(i, 0) for i in srcs], seed=500)           # ROM image + every other input = enc(0)
+    write_plain(srcs, [mem.get(i, 0) for i in srcs])
     write_bits(plan.dffs, [0] * len(plan.dffs), seed=501)
+    write_plain(plan.dffs, [0] * len(plan.dffs))
     ex.set_input("reset", 0, client.encrypt_bits(keys128, [1], seed=502)[0])
+    sim.set_input("reset", 0, 1)
     ex.run()
-    for c in range(want["cycles"]):
+    sim.evaluate()
+    assert want["cycles"] == 7
+    for c in range(10):
         ex.tick()
+        sim.tick()
         if c == 0:
             ex.set_input("reset", 0, client.encrypt_bits(keys128, [0], seed=503)[0])
+            sim.set_input("reset", 0, 0)
             ram_nodes = [i for i in mem if i not in rom_nodes]
             write_bits(ram_nodes, [mem[i] for i in ram_nodes], seed=504)  # setInitialRAM after the first tick
+            write_plain(ram_nodes, [mem[i] for i in ram_nodes])
         ex.run()
-    for entry in want["bits"]:
-        keys_ = [(entry["name"], b) for b in range(entry["size"])]
-        got = client.decrypt_bits(keys128, be.read_many([plan.slot[nl.outputs[k]] for k in keys_]))
-        assert N.bytes_from_bits(list(got)) == entry["bytes"], entry["name"]
+        sim.evaluate()
+        if c + 1 == want["cycles"]:   # the reference's own known answer
+            for entry in want["bits"]:
+                keys_ = [(entry["name"], b) for b in range(entry["size"])]
+                got = client.decrypt_bits(keys128, be.read_many([plan.slot[nl.outputs[k]] for k in keys_]))
+                assert N.bytes_from_bits(list(got)) == entry["bytes"], entry["name"]
+    outs = sorted(nl.outputs)
+    got = client.decrypt_bits(keys128, be.read_many([plan.slot[nl.outputs[k]] for k in outs]))
+    assert list(got) == [sim.get_output(*k) for k in outs]
+    state = sorted(set(plan.dffs) | set(plan.sources))                    # registers, RAM / ROM cells, inputs
+    got = client.decrypt_bits(keys128, be.read_many([plan.slot[i] for i in state]))
+    assert list(got) == [int(sim.val[i]) for i in state]
     be.close()
 
 
