@@ -199,8 +199,10 @@ def test_timing_log_covers_rotation_only_calls(gpu, keys128):
     st.destroy()
 
 
-def test_cmux_memory_entry_points_256_jobs(gpu, keys128, oracle128):
-    """the two GPU pieces of the CMUX memories composed on 300 jobs —
+@pytest.mark.parametrize("kernel", [None, "t16", "w32", "lat3"])
+def test_cmux_memory_entry_points_256_jobs(gpu, keys128, oracle128, kernel, monkeypatch):
+    """Every rotation kernel (default dispatch, then each one forced) through the TRLWE output mode and the output
+    indirection.  VERDICT r01 item 6: the two GPU pieces of the CMUX memories composed on 300 jobs —
     GateBootstrappingTLWE2TRLWElvl01NTT into scattered TRLWE cells (trlwe_out indirection), then
     SampleExtractAndKeySwitch of those cells into arena slots — against the oracle: every TLWE word of every job, and
     the TRLWE words of a sample of cells."""
@@ -210,6 +212,10 @@ def test_cmux_memory_entry_points_256_jobs(gpu, keys128, oracle128):
     import oracle_lib
     import torch
 
+    if kernel is None:
+        monkeypatch.delenv("IYK_HIP_ROT_KERNEL", raising=False)
+    else:
+        monkeypatch.setenv("IYK_HIP_ROT_KERNEL", kernel)
     st = gpu.Stream(0)
     p = keys128.params
     rng = np.random.default_rng(66)
