@@ -318,8 +318,7 @@ void blind_rotate_fp_lat3(const iyk_params* p, const u32* lin, const double* bk_
             for (double v : R[wave * 64 + lane].x) track1(v);
     };
 #define WAVE_LANES(w) for (int lane = 0; lane < 64; ++lane)
-    auto dif16 = [&](int wave, int pass) {
-        swap16(wave);
+    auto dif16p = [&](int wave, int pass) {
         WAVE_LANES(wave)
         {
             Lane& r = R[wave * 64 + lane];
@@ -360,16 +359,23 @@ void blind_rotate_fp_lat3(const iyk_params* p, const u32* lin, const double* bk_
         for (int wave = 0; wave < XF; ++wave) {
             const int h = wave / LV, v = wave % LV;
             double* wxb = xb.data() + (size_t)wave * 32 * XB_STRIDE;
-            WAVE_LANES(wave) fp::fwd1_pre16<D>(lane >> 5, lane & 31, v, ab, acc.data() + h * NTT_N, R[wave * 64 + lane].x, ztab.data());
-            dif16(wave, 1);
+            WAVE_LANES(wave)
+            {   // digits straight into arrangement P
+                u32 tb[16];
+                fp::t16_diff<D>(lane >> 5, lane & 31, ab, acc.data() + h * NTT_N, tb);
+                fp::t16_digits<D>(lane >> 5, v, tb, R[wave * 64 + lane].x, ztab.data());
+            }
+            dif16p(wave, 1);
             WAVE_LANES(wave) fp::xpose16_write<false>(lane >> 5, lane & 31, R[wave * 64 + lane].x, wxb);
             WAVE_LANES(wave)
             {   // part B: transposed read, then the inter-pass twiddle of element j1 = 16 half + r of row k2 = t
                 const int half = lane >> 5, t = lane & 31;
-                fp::xpose16_read(half, t, R[wave * 64 + lane].x, wxb);
-                for (int r = 0; r < 16; ++r) R[wave * 64 + lane].x[r] = fp::mulmod(R[wave * 64 + lane].x[r], T.twf_t[t * 32 + 16 * half + r]);
+                for (int e = 0; e < 16; ++e) {
+                    const int j1 = fp::t16_pair_elem(half, e);
+                    R[wave * 64 + lane].x[e] = fp::mulmod(wxb[t * XB_STRIDE + j1], T.twf_t[t * 32 + j1]);
+                }
             }
-            dif16(wave, 2);
+            dif16p(wave, 2);
             WAVE_LANES(wave)
             {
                 const int half = lane >> 5, t = lane & 31;

@@ -21,6 +21,7 @@
 #include "blind_rotate_core.hpp"
 #include "blind_rotate_fp.hpp"
 #include "blind_rotate_lat3.hpp"
+#include "blind_rotate_t16.hpp"
 
 namespace iyk {
 
@@ -577,6 +578,15 @@ __device__ __forceinline__ void dif16(double (&a)[16], int half, const double (&
     fp::dif16_stages14<PASS>(a, w);
 }
 
+// the same pass from arrangement P (a lane already holds the pairs of stage 0): one swap round instead of two
+template <int PASS>
+__device__ __forceinline__ void dif16p(double (&a)[16], int half, const double (&tw0)[8], const double* w)
+{
+    fp::dif16_stage0<PASS>(a, half, tw0);
+    swap16(a);
+    fp::dif16_stages14<PASS>(a, w);
+}
+
 // Phase stamps for tools/ubench/lat3_trace.hip only (compiled with -DIYK_LAT3_TRACE=<step>): s_memtime at the phase
 // boundaries of ONE step, written per wave to the buffer passed in place of out_index.  Not part of the product build.
 #ifdef IYK_LAT3_TRACE
@@ -653,7 +663,7 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
     // product on the same element either side; after it, the 96 instructions sit with the lighter part of a split transform.)
     double twf16[16], twi8[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) twf16[r] = s_twf[t0 * 32 + 16 * half0 + r];
+    for (int r = 0; r < 16; ++r) twf16[r] = s_twf[t0 * 32 + fp::t16_pair_elem(half0, r)];   // arrangement P of part B's input
 #pragma unroll
     for (int q = 0; q < 8; ++q) twi8[q] = s_twi[fp::inv8(g_inv, half0, q) * 32 + t0];
 
@@ -703,9 +713,13 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
         // ---- forward, part A: digits -> pass 1 -> twiddle -> transpose write
         if (doA) {
             if (SPLIT && wave >= 6) __builtin_amdgcn_s_setprio(3);
-            fp::fwd1_pre16<D>(half, t, vA, ab, acc_lds + hA * NTT_N, x, s_ztab);
+            {   // digits straight into arrangement P (the pairs of stage 0): no swap-in round (blind_rotate_t16.hpp)
+                u32 tb[16];
+                fp::t16_diff<D>(half, t, ab, acc_lds + hA * NTT_N, tb);
+                fp::t16_digits<D>(half, vA, tb, x, s_ztab);
+            }
             IYK_TRACE(1);
-            dif16<fp::PASS1>(x, half, tw0, C.w);
+            dif16p<fp::PASS1>(x, half, tw0, C.w);
             IYK_TRACE(2);
             fp::xpose16_write<false>(half, t, x, xbA);
             lds_sync();
@@ -720,12 +734,13 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
                 while (__hip_atomic_load(&s_handoff[wave - 4], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != i + 1)
                     __builtin_amdgcn_s_sleep(1);
             }
-            fp::xpose16_read(half, t, x, xb);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) x[e] = xb[t * XB_STRIDE + fp::t16_pair_elem(half, e)];   // arrangement P of row t
             lds_sync();
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = fp::mulmod(x[r], twf16[r]);
             IYK_TRACE(3);
-            dif16<fp::PASS2>(x, half, tw0, C.w);
+            dif16p<fp::PASS2>(x, half, tw0, C.w);
             // frequency k = t + 32 k1, k1 = 2 brv4(q) + half, at device-layout offset brv4(q) * 64 + 2 t + half
 #pragma unroll
             for (int q = 0; q < 16; ++q) xb[fp::brv4(q) * 64 + 2 * t + half] = x[q];
