@@ -710,6 +710,10 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
         int t = t0, half = half0;
         asm volatile("" : "+v"(t), "+v"(half));  // keep lane-dependent address math inside the iteration (no hoisting)
         IYK_TRACE(0);
+        // waves 4, 5 run the LONGER branch of both inverse passes (the twiddled differences): their key rows are fetched here,
+        // while they wait for the helpers' hand-off anyway, instead of inside the inverse (-24 VMEM issues on the step's
+        // critical path: 3.54 -> 3.46 ms per rotation, profiles/r03_lat3_k45_ab.txt)
+        if (SPLIT && (wave == 4 || wave == 5) && i > 0) load_bk(i);
         // ---- forward, part A: digits -> pass 1 -> twiddle -> transpose write
         if (doA) {
             if (SPLIT && wave >= 6) __builtin_amdgcn_s_setprio(3);
@@ -806,7 +810,7 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
 #pragma unroll
             for (int q = 0; q < 8; ++q) xbI[fp::inv8(g_inv, half, q) * XB_STRIDE + t] = fp::mulmod(e[q], twi8[q]);
             IYK_TRACE(8);
-            if (i + 1 < n) load_bk(i + 1);  // the other waves' loads (issued after barrier 2) have drained by now
+            if ((!SPLIT || wave >= 6) && i + 1 < n) load_bk(i + 1);  // the other waves' loads (issued after barrier 2) have drained by now
         }
         wg_barrier_lds();  // both waves of a polynomial have written its transposed matrix
         if (inv) {
