@@ -45,14 +45,46 @@ IYK_HD void t16_diff(int half, int t, u32 abar, const u32* acc_h, u32 (&tb)[16])
     typedef const __attribute__((address_space(3))) u32* lds_u32;
     const u32 acc_base = (u32)(size_t)(lds_u32)acc_h;
     const u32 base4 = (((u32)t - abar) << 2) + 128u * (u32)half;
-    const u32* own = acc_h + t + 32 * half;
+    // All 32 words in ONE assembly block with one s_waitcnt: 16 rotated words (an address register each) and the 16 own
+    // words as 8 pairs 2 KiB apart (ds_read2st64_b32: e = 2m at st64 unit m, e = 2m + 1 at unit m + 8).  Left to the
+    // compiler every read drags its own wait along, and on the narrow-frontier kernel's critical wave every instruction
+    // is ~8 cycles.
+    const u32 own_base = acc_base + (((u32)t + 32u * (u32)half) << 2);
+    u32 addr[16], neg[16], rot[16];
+    u64 own[8];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int j2c = 2 * (e >> 1) + 16 * (e & 1);             // j2 - half
         const u32 idx4 = base4 + 128u * (u32)j2c;
-        const u32 neg = (u32)((i32)(idx4 << 19) >> 31);           // bit 12 of 4 idx = bit 10 of idx
-        const u32 a = *(lds_u32)(size_t)((idx4 & 0xFFCu) | acc_base);
-        tb[e] = (a ^ neg) + ((C::offset_plus_round() - own[32 * j2c]) - neg);
+        neg[e] = (u32)((i32)(idx4 << 19) >> 31);                  // bit 12 of 4 idx = bit 10 of idx
+        addr[e] = (idx4 & 0xFFCu) | acc_base;
+    }
+    asm volatile(
+        "ds_read_b32 %0, %24\n" "ds_read_b32 %1, %25\n" "ds_read_b32 %2, %26\n" "ds_read_b32 %3, %27\n"
+        "ds_read_b32 %4, %28\n" "ds_read_b32 %5, %29\n" "ds_read_b32 %6, %30\n" "ds_read_b32 %7, %31\n"
+        "ds_read_b32 %8, %32\n" "ds_read_b32 %9, %33\n" "ds_read_b32 %10, %34\n" "ds_read_b32 %11, %35\n"
+        "ds_read_b32 %12, %36\n" "ds_read_b32 %13, %37\n" "ds_read_b32 %14, %38\n" "ds_read_b32 %15, %39\n"
+        "ds_read2st64_b32 %16, %40 offset0:0 offset1:8\n"
+        "ds_read2st64_b32 %17, %40 offset0:1 offset1:9\n"
+        "ds_read2st64_b32 %18, %40 offset0:2 offset1:10\n"
+        "ds_read2st64_b32 %19, %40 offset0:3 offset1:11\n"
+        "ds_read2st64_b32 %20, %40 offset0:4 offset1:12\n"
+        "ds_read2st64_b32 %21, %40 offset0:5 offset1:13\n"
+        "ds_read2st64_b32 %22, %40 offset0:6 offset1:14\n"
+        "ds_read2st64_b32 %23, %40 offset0:7 offset1:15\n"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(rot[0]), "=&v"(rot[1]), "=&v"(rot[2]), "=&v"(rot[3]), "=&v"(rot[4]), "=&v"(rot[5]), "=&v"(rot[6]), "=&v"(rot[7]),
+          "=&v"(rot[8]), "=&v"(rot[9]), "=&v"(rot[10]), "=&v"(rot[11]), "=&v"(rot[12]), "=&v"(rot[13]), "=&v"(rot[14]), "=&v"(rot[15]),
+          "=&v"(own[0]), "=&v"(own[1]), "=&v"(own[2]), "=&v"(own[3]), "=&v"(own[4]), "=&v"(own[5]), "=&v"(own[6]), "=&v"(own[7])
+        : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]), "v"(addr[6]), "v"(addr[7]),
+          "v"(addr[8]), "v"(addr[9]), "v"(addr[10]), "v"(addr[11]), "v"(addr[12]), "v"(addr[13]), "v"(addr[14]), "v"(addr[15]),
+          "v"(own_base)
+        : "memory");
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const u64 w = own[e >> 1];
+        const u32 o = (e & 1) ? (u32)(w >> 32) : (u32)w;
+        tb[e] = (rot[e] ^ neg[e]) + ((C::offset_plus_round() - o) - neg[e]);
     }
 #else
     const u32 base = (u32)t - abar;
