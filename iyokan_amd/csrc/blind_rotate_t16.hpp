@@ -99,6 +99,67 @@ IYK_HD void t16_diff(int half, int t, u32 abar, const u32* acc_h, u32 (&tb)[16])
 #endif
 }
 
+// The narrow-frontier kernel keeps every accumulator polynomial DOUBLED in LDS: acc2[0 .. N) = acc, acc2[N .. 2N) = -acc
+// (8 KiB, 8 KiB aligned; the kernel has the room, the wave-per-rotation kernels do not).  (X^abar acc)[x] is then
+// acc2[(x - abar) mod 2N] — one v_and_or for the address and no sign arithmetic: 4 vector instructions per coefficient of
+// the rotated difference instead of 8, on the waves that bound the forward phase.  The price is one more LDS atomic per
+// coefficient in the accumulator update (ds_sub_u32 on the mirrored half).
+// tb[e] = ((X^abar - 1) acc)[t + 32 j2] + offset_plus_round for j2 = t16_pair_elem(half, e) (arrangement P), all 32 words in
+// one assembly block with one wait (see t16_diff).
+template <class D>
+IYK_HD void lat3_diff2(int half, int t, u32 abar, const u32* acc2, u32 (&tb)[16])
+{
+    typedef BrConsts<D::L, D::BGBIT> C;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(3))) u32* lds_u32;
+    const u32 acc_base = (u32)(size_t)(lds_u32)acc2;             // PRECONDITION: 8 KB aligned
+    const u32 base4 = (((u32)t - abar) << 2) + 128u * (u32)half;
+    const u32 own_base = acc_base + (((u32)t + 32u * (u32)half) << 2);
+    u32 addr[16], rot[16];
+    u64 own[8];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int j2c = 2 * (e >> 1) + 16 * (e & 1);             // j2 - half
+        addr[e] = ((base4 + 128u * (u32)j2c) & 0x1FFCu) | acc_base;
+    }
+    asm volatile(
+        "ds_read_b32 %0, %24\n" "ds_read_b32 %1, %25\n" "ds_read_b32 %2, %26\n" "ds_read_b32 %3, %27\n"
+        "ds_read_b32 %4, %28\n" "ds_read_b32 %5, %29\n" "ds_read_b32 %6, %30\n" "ds_read_b32 %7, %31\n"
+        "ds_read_b32 %8, %32\n" "ds_read_b32 %9, %33\n" "ds_read_b32 %10, %34\n" "ds_read_b32 %11, %35\n"
+        "ds_read_b32 %12, %36\n" "ds_read_b32 %13, %37\n" "ds_read_b32 %14, %38\n" "ds_read_b32 %15, %39\n"
+        "ds_read2st64_b32 %16, %40 offset0:0 offset1:8\n"
+        "ds_read2st64_b32 %17, %40 offset0:1 offset1:9\n"
+        "ds_read2st64_b32 %18, %40 offset0:2 offset1:10\n"
+        "ds_read2st64_b32 %19, %40 offset0:3 offset1:11\n"
+        "ds_read2st64_b32 %20, %40 offset0:4 offset1:12\n"
+        "ds_read2st64_b32 %21, %40 offset0:5 offset1:13\n"
+        "ds_read2st64_b32 %22, %40 offset0:6 offset1:14\n"
+        "ds_read2st64_b32 %23, %40 offset0:7 offset1:15\n"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(rot[0]), "=&v"(rot[1]), "=&v"(rot[2]), "=&v"(rot[3]), "=&v"(rot[4]), "=&v"(rot[5]), "=&v"(rot[6]), "=&v"(rot[7]),
+          "=&v"(rot[8]), "=&v"(rot[9]), "=&v"(rot[10]), "=&v"(rot[11]), "=&v"(rot[12]), "=&v"(rot[13]), "=&v"(rot[14]), "=&v"(rot[15]),
+          "=&v"(own[0]), "=&v"(own[1]), "=&v"(own[2]), "=&v"(own[3]), "=&v"(own[4]), "=&v"(own[5]), "=&v"(own[6]), "=&v"(own[7])
+        : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]), "v"(addr[6]), "v"(addr[7]),
+          "v"(addr[8]), "v"(addr[9]), "v"(addr[10]), "v"(addr[11]), "v"(addr[12]), "v"(addr[13]), "v"(addr[14]), "v"(addr[15]),
+          "v"(own_base)
+        : "memory");
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const u64 w = own[e >> 1];
+        const u32 o = (e & 1) ? (u32)(w >> 32) : (u32)w;
+        tb[e] = rot[e] + (C::offset_plus_round() - o);
+    }
+#else
+    const u32 base = (u32)t - abar;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int j2 = t16_pair_elem(half, e);
+        const u32 idx = (base + 32u * (u32)j2) & (2 * NTT_N - 1);
+        tb[e] = acc2[idx] - acc2[t + 32 * j2] + C::offset_plus_round();
+    }
+#endif
+}
+
 // signed digit of virtual level v from the biased word (tb = td + offset_plus_round)
 template <class D>
 IYK_HD i32 t16_digit(u32 tb, int v)

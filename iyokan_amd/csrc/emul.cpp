@@ -298,7 +298,7 @@ void blind_rotate_fp_lat3(const iyk_params* p, const u32* lin, const double* bk_
     const fp::NttConsts& C = T.t.c;
     std::vector<double> ztab(fp::ZTAB_ENTRIES);
     for (int e = 0; e < fp::ZTAB_ENTRIES; ++e) ztab[e] = fp::ztab_entry(e, C.zf);
-    std::vector<u32> acc(2 * NTT_N);
+    std::vector<u32> acc(4 * NTT_N);   // [2][2048]: every polynomial followed by its negation (lat3_diff2)
     std::vector<double> sum(2 * NTT_N, 0.0), xb((size_t)XF * 32 * XB_STRIDE);
     struct Lane {
         double x[16], tw0[8], zi16[16];
@@ -348,7 +348,9 @@ void blind_rotate_fp_lat3(const iyk_params* p, const u32* lin, const double* bk_
                 for (int rr = 0; rr < 16; ++rr) {
                     const int j = t + 32 * (16 * half + rr);
                     const u32 idx = ((u32)j - bbar) & (2 * NTT_N - 1);
-                    acc[c_inv * NTT_N + j] = c_inv ? ((idx & NTT_N) ? 0u - p->mu : p->mu) : 0u;
+                    const u32 v0 = c_inv ? ((idx & NTT_N) ? 0u - p->mu : p->mu) : 0u;
+                    acc[c_inv * 2 * NTT_N + j] = v0;
+                    acc[c_inv * 2 * NTT_N + NTT_N + j] = 0u - v0;
                 }
         }
     }
@@ -362,7 +364,7 @@ void blind_rotate_fp_lat3(const iyk_params* p, const u32* lin, const double* bk_
             WAVE_LANES(wave)
             {   // digits straight into arrangement P
                 u32 tb[16];
-                fp::t16_diff<D>(lane >> 5, lane & 31, ab, acc.data() + h * NTT_N, tb);
+                fp::lat3_diff2<D>(lane >> 5, lane & 31, ab, acc.data() + h * 2 * NTT_N, tb);
                 fp::t16_digits<D>(lane >> 5, v, tb, R[wave * 64 + lane].x, ztab.data());
             }
             dif16p(wave, 1);
@@ -495,7 +497,9 @@ void blind_rotate_fp_lat3(const iyk_params* p, const u32* lin, const double* bk_
                 const int half = lane >> 5, t = lane & 31;
                 for (int q = 0; q < 8; ++q) {
                     const int j2 = fp::inv8(g, half, q);
-                    acc[c * NTT_N + t + 32 * j2] += fp::inv2_post16(E[wave * 64 + lane].e[q], C.zi[j2]);
+                    const u32 d = fp::inv2_post16(E[wave * 64 + lane].e[q], C.zi[j2]);
+                    acc[c * 2 * NTT_N + t + 32 * j2] += d;
+                    acc[c * 2 * NTT_N + NTT_N + t + 32 * j2] -= d;
                 }
             }
         }
@@ -503,7 +507,7 @@ void blind_rotate_fp_lat3(const iyk_params* p, const u32* lin, const double* bk_
 #undef WAVE_LANES
     tlwe1[0] = acc[0];
     for (u32 j = 1; j < (u32)NTT_N; ++j) tlwe1[j] = 0u - acc[NTT_N - j];
-    tlwe1[NTT_N] = acc[NTT_N];
+    tlwe1[NTT_N] = acc[2 * NTT_N];
 }
 // ---------------------------------------------------------------------------------------------
 // Lane-by-lane emulation of kernels_t16.hpp::blind_rotate_fp_t16_kernel (blind_rotate_t16.hpp): one wave per rotation,

@@ -533,7 +533,7 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
 // were run-time byte loads (+1 ms per rotation).  With 2 LV = 6 transform waves the helpers 6, 7 — alone on their
 // SIMDs during the forward phase — are the inverse waves.
 //
-// LDS (bytes): twiddles fwd + inv 16 K | twisted digits 16 K | accumulator 8 K | sums f64 [2][1024] 16 K (device
+// LDS (bytes): twiddles fwd + inv 16 K | twisted digits 16 K | accumulator 16 K (each polynomial + its negation) | sums f64 [2][1024] 16 K (device
 // layout) | per transform wave one f64 [32][33] transpose matrix (8448), reused for its spectrum (8192).
 template <class D>
 struct BrLat3 {
@@ -541,7 +541,7 @@ struct BrLat3 {
     static constexpr int WAVES = 8, THREADS = 64 * WAVES;
     static_assert(XF <= WAVES, "more digit polynomials than waves");
     static constexpr size_t XB_DOUBLES = 32 * XB_STRIDE;
-    static constexpr size_t LDS_BYTES = (2 * NTT_N + fp::ZTAB_ENTRIES) * sizeof(double) + 2 * NTT_N * sizeof(u32) +
+    static constexpr size_t LDS_BYTES = (2 * NTT_N + fp::ZTAB_ENTRIES) * sizeof(double) + 4 * NTT_N * sizeof(u32) +
                                         2 * NTT_N * sizeof(double) + (size_t)XF * XB_DOUBLES * sizeof(double) + 16;
     static_assert(LDS_BYTES <= 160 * 1024, "latency kernel 3 does not fit the CU's LDS");
 };
@@ -610,12 +610,13 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
     typedef BrLat3<D> M;
     constexpr int LV = M::LV, XF = M::XF, NT = M::THREADS;
     const fp::NttConsts& C = *Cp;
-    extern __shared__ __attribute__((aligned(4096))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(8192))) unsigned char smem[];
     double* s_twf = reinterpret_cast<double*>(smem);                    // [k2][j1]
     double* s_twi = s_twf + NTT_N;                                      // [j1][k2]
     double* s_ztab = s_twi + NTT_N;                                     // [j2][digit + 32]
-    u32* acc_lds = reinterpret_cast<u32*>(s_ztab + fp::ZTAB_ENTRIES);   // [2][1024]
-    double* s_sum = reinterpret_cast<double*>(acc_lds + 2 * NTT_N);     // [c][device layout of k]
+    u32* acc_lds = reinterpret_cast<u32*>(s_ztab + fp::ZTAB_ENTRIES);   // [2][2048]: every polynomial followed by its negation
+    static_assert(((2 * NTT_N + fp::ZTAB_ENTRIES) * sizeof(double)) % 8192 == 0, "lat3_diff2 needs 8 KB aligned accumulators");
+    double* s_sum = reinterpret_cast<double*>(acc_lds + 4 * NTT_N);     // [c][device layout of k]
     double* s_xb = s_sum + 2 * NTT_N;                                   // [XF][32][33]: transposes, then spectra
 
     for (int e = threadIdx.x; e < NTT_N; e += NT) {
@@ -637,12 +638,14 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
     const u32* abar = abar_all + (size_t)job * abar_stride;
     if (wave >= 6) {  // initial accumulator (0, X^bbar * sum_j mu X^j): each lane its 16 coefficients
         const u32 bbar = abar[n];
-        u32* acc_c = acc_lds + c_inv * NTT_N;
+        u32* acc_c = acc_lds + c_inv * 2 * NTT_N;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = t0 + 32 * (16 * half0 + r);
             const u32 idx = ((u32)j - bbar) & (2 * NTT_N - 1);
-            acc_c[j] = c_inv ? ((idx & NTT_N) ? 0u - mu : mu) : 0u;
+            const u32 v = c_inv ? ((idx & NTT_N) ? 0u - mu : mu) : 0u;
+            acc_c[j] = v;
+            acc_c[NTT_N + j] = 0u - v;   // the mirrored half (lat3_diff2)
         }
     }
     // lane constants.  Forward (16 points per lane): stage-0 twiddles w^(2m + half).  Inverse (8 points per lane, wave g):
@@ -719,7 +722,7 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
             if (SPLIT && wave >= 6) __builtin_amdgcn_s_setprio(3);
             {   // digits straight into arrangement P (the pairs of stage 0): no swap-in round (blind_rotate_t16.hpp)
                 u32 tb[16];
-                fp::t16_diff<D>(half, t, ab, acc_lds + hA * NTT_N, tb);
+                fp::lat3_diff2<D>(half, t, ab, acc_lds + hA * 2 * NTT_N, tb);
                 fp::t16_digits<D>(half, vA, tb, x, s_ztab);
             }
             IYK_TRACE(1);
@@ -815,7 +818,7 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
         wg_barrier_lds();  // both waves of a polynomial have written its transposed matrix
         if (inv) {
             asm volatile("" : "+v"(t), "+v"(half));
-            u32* acc_c = acc_lds + c_inv * NTT_N;
+            u32* acc_c = acc_lds + c_inv * 2 * NTT_N;
             double u[8], vv[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -830,9 +833,12 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
             fp::dif8_stages24<fp::PASS2>(e, C.w);
             IYK_TRACE(10);
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                __hip_atomic_fetch_add(acc_c + t + 32 * fp::inv8(g_inv, half, q), fp::inv2_post16(e[q], zi8[q]), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WAVEFRONT);
+            for (int q = 0; q < 8; ++q) {
+                const u32 d = fp::inv2_post16(e[q], zi8[q]);
+                u32* cell = acc_c + t + 32 * fp::inv8(g_inv, half, q);
+                __hip_atomic_fetch_add(cell, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_sub(cell + NTT_N, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // the mirrored half
+            }
             IYK_TRACE(11);
         }
         wg_barrier_lds();  // accumulator of step i is complete before anyone derives step i+1's digits
@@ -849,12 +855,12 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
     if (wave == 0) {
         if (trlwe_mode) {  // raw accumulator: TRLWE (a(X), b(X)), 2N words per job
             u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (2 * NTT_N);
-            for (int j = lane; j < 2 * NTT_N; j += 64) out[j] = acc_lds[j];
+            for (int j = lane; j < 2 * NTT_N; j += 64) out[j] = acc_lds[j < NTT_N ? j : j + NTT_N];   // skip the mirrored halves
         }
         else {
             u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (NTT_N + 1);
             for (int j = lane; j < NTT_N; j += 64) out[j] = (j == 0) ? acc_lds[0] : 0u - acc_lds[NTT_N - j];
-            if (lane == 0) out[NTT_N] = acc_lds[NTT_N];
+            if (lane == 0) out[NTT_N] = acc_lds[2 * NTT_N];
         }
     }
 }
