@@ -404,6 +404,15 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
         const u32 ab = ab_next;
         ab_next = abar[i + 1 < n ? i + 1 : i];  // next step's exponent: its scalar-load latency hides behind this step
         const double* bk_step = bk_ntt + (size_t)i * (2 * L) * 2 * NTT_N;
+        // Every 16 steps the eight waves of the workgroup meet at a barrier.  Nothing is handed over between them — each owns
+        // its rotation — but all eight walk the SAME key rows, and only while they do so within a few hundred cycles of each
+        // other does the CU's 32 KiB vector L1 serve seven of the eight requests per row; left alone they drift apart over
+        // the 636 steps and every wave streams its rows from L2 (a timing-only variant with L1-resident keys is 5.5 % faster,
+        // profiles/r03_w32_stall_exp.txt).  Re-aligning them: 660 -> 630 ms per 65 536 rotations at either parameter set;
+        // every 4 .. 16 steps measure the same, every 64 loses a third of the gain, every level costs more than it brings
+        // (profiles/r03_w32_barrier_ab.txt).  All eight waves run all n steps (spare waves repeat the last job), so the
+        // barrier cannot hang.
+        if ((i & 15u) == 0u) asm volatile("s_barrier" ::: "memory");
         // ((X^abar - 1) acc)[t + 32 j2] is the same for every gadget level of this step: derived once
         u32 td[32];
         {
