@@ -51,6 +51,9 @@ def parse_args():
     ap.add_argument("--gates", type=int, default=65536, help="gates per step, whole job (sharded over the GPUs)")
     ap.add_argument("--no-weak", action="store_true", help="skip the extra weak-scaling measurement at N > 1")
     ap.add_argument("--params", default="128bit", choices=["128bit", "80bit"])
+    ap.add_argument("--decomp", default=None, choices=["split", "direct"],
+                    help="80-bit set: gadget decomposition on the FP64 path (IYK_HIP_DECOMP; default split = exact "
+                         "unconditionally, direct = 10-bit digits as they are, include/iyokan_hip.h)")
     ap.add_argument("--op", default="NAND", choices=["AND", "NAND", "ANDNOT", "OR", "NOR", "ORNOT", "XOR", "XNOR"],
                     help="binary gate of the flat batch (BASELINE config #2 is NAND)")
     ap.add_argument("--cpu-sample", type=int, default=-1,
@@ -62,10 +65,12 @@ def parse_args():
     return ap.parse_args()
 
 
-COUNTER_FILES = ("r03_counters.json", "r03_counters_80bit.json", "r02_counters.json", "r01_traffic.json")  # newest first
+COUNTER_FILES = ("r03_counters.json", "r03_counters_80bit.json", "r03_counters_80bit_direct.json", "r02_counters.json",
+                 "r01_traffic.json")  # newest first
+DEFAULT_LEVELS = {"128bit": 3, "80bit": 4}   # iyk_hip_decomposition_levels of counter files older than the field
 
 
-def counters(args, gates, build_id):
+def counters(args, gates, build_id, levels):
     """PMC results of the dominant kernel for this workload (separate rocprofv3 --pmc passes, committed under
     profiles/ by tools/profile_round.sh): HBM traffic, VALU instruction count, busy cycles.
 
@@ -78,7 +83,8 @@ def counters(args, gates, build_id):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
             w = t["workload"]
-            if not (w["gates_per_launch"] == gates and w["params"] == args.params and w["op"] == args.op):
+            if not (w["gates_per_launch"] == gates and w["params"] == args.params and w["op"] == args.op
+                    and w.get("decomposition_levels", DEFAULT_LEVELS[args.params]) == levels):
                 continue
             if t.get("build_id") != build_id:
                 why = (f"profiles/{name} was measured on build {t.get('build_id', 'unstamped')}, the loaded library is "
@@ -287,6 +293,8 @@ def main():
     keys = client.keygen(params, seed=1) if rank == 0 else empty_keys(params)
     if distributed:
         keys = broadcast_keys(keys, dist, dev, rank)
+    if args.decomp:
+        os.environ["IYK_HIP_DECOMP"] = args.decomp
     hip.initialize(keys, device_ids=(local_rank,))
 
     # ---- synthetic inputs: fresh encryptions, distinct per rank (seeded); layout [in0 | in1 | out] ----
@@ -358,7 +366,7 @@ def main():
             + 2 * (params.n + 1) * 4 + (params.N + 1) * 4
         br_avg_s = (br_ms / max(nb, 1)) * 1e-3
         achieved = br_bytes_per_gate * G_mine / br_avg_s if br_avg_s > 0 else 0.0
-        pmc, pmc_why = counters(args, G_mine, hip.build_id())
+        pmc, pmc_why = counters(args, G_mine, hip.build_id(), hip.decomposition_levels())
         traffic = args.traffic_bytes if args.traffic_bytes is not None else (pmc or {}).get("traffic_bytes_per_launch")
         contract = {   # algorithmic key bytes of the dominant kernel / its launch time against the HBM peak
             "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
@@ -456,6 +464,7 @@ def main():
                 "workload": f"{G_total} independent Hom{args.op} gates per step (flat DAG), {args.params} params, "
                             f"fresh encryptions, keys+ciphertexts resident in HBM; sharded {G_mine} per GPU",
                 "params": {k: v for k, v in params.as_dict().items() if k not in ("alpha0", "alpha1")},
+                "decomposition_levels": hip.decomposition_levels(),
                 "gates_per_step": G_total,
                 "gates_per_step_per_gpu": G_mine,
                 "parallelism": f"frontier sharded over {world} GPU(s), no data-path collective (flat DAG)",

@@ -239,15 +239,24 @@ int iyk_hip_timing_log_end(iyk_hip_stream* st, uint64_t* batches, double* blind_
  * integers (forced with the environment variable IYK_HIP_NTT=goldilocks at init, or chosen when a
  * parameter set does not meet the FP64 field's exactness bound).  Both give identical ciphertexts.
  *
- * A/B knobs for tests and measurements.  Read at every batch: IYK_HIP_ROT_KERNEL = t16 / w32 / lat3 forces one
- * rotation kernel — t16: a wave per rotation, 16 points per lane, 3 waves per SIMD (the default for full rounds);
- * w32: a wave per rotation, 32 points per lane, 2 waves per SIMD (round 1-2's kernel); lat3: a workgroup of 8 waves
- * per rotation (the default for narrow frontiers).  Unset = chosen by batch size.
+ * A/B knobs for tests and measurements.  Read at every batch: IYK_HIP_ROT_KERNEL = w32 / t16 / lat3 forces one
+ * rotation kernel — w32: a wave per rotation, 32 points per lane, 2 waves per SIMD (the default for full rounds);
+ * t16: a wave per rotation, 16 points per lane, 3 waves per SIMD (measured slower, kept selectable); lat3: a workgroup
+ * of 8 waves per rotation (the default for narrow frontiers).  Unset = chosen by batch size.
  * IYK_HIP_LATENCY_KERNEL = 0 / 3 is the older spelling of w32 / lat3.  Read at init: IYK_HIP_TP_KERNEL = t16 / w32,
  * the wave-per-rotation kernel the size-based dispatch uses.  IYK_HIP_KS_KERNEL = 0 / 1, read at every batch, forces
  * the key switch with 16 gates per workgroup (3 words per thread) or the one with 16 gates per wave (whole rows per
  * wave; the default where instantiated); both subtract the same rows mod 2^32, so they agree word for word. */
 int iyk_hip_ntt_path(void);
+
+/* Digit polynomials per accumulator polynomial and CMUX step.  l on the integer path and for the 128-bit set; 2 l = 4 for
+ * the 80-bit set on the FP64 path, whose 10-bit digits are split into 5-bit halves so that every integer sum stays below
+ * p/2 UNCONDITIONALLY (the default).  IYK_HIP_DECOMP=direct at iyk_hip_init (80-bit set only, opt-in) uses the digits as
+ * they are: l = 2, half the transforms and half the key stream, and the same ciphertexts unless an integer sum of 4096
+ * digit x key-word products reaches p/2 — for real (uniform) key rows an event of probability <= 7e-24 per sum, 2e-17 per
+ * gate whatever the digits (csrc/blind_rotate_fp.hpp has the bound), far below the scheme's own decryption-failure rate,
+ * but not zero: a measured option, not the default.  There is no upstream counterpart (cuFHE's FFT is approximate anyway). */
+int iyk_hip_decomposition_levels(void);
 
 /* Identity of the build: 16 hex digits of the SHA-256 over the sources the library was compiled from (tools/src_hash.py;
  * "unknown" when built without -DIYK_BUILD_ID).  Measurement tooling stamps counter files with it, so that an

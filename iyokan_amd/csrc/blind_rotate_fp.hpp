@@ -31,6 +31,16 @@ IYK_HD double u2d(u64 u)
 // and paired with the keys 2^HB * BK_j (mod 2^32) and BK_j: LV = 2L "virtual levels" with 5-bit
 // digits, so that |sum| <= (k+1) LV N 2^(HB-1) 2^31 stays below p/2 (80-bit set: L = 2, Bgbit = 10
 // -> LV = 4, |sum| <= 2^48).  Virtual level v = 2*lvl + part, part 0 = hi, part 1 = lo.
+//
+// DIRECT decomposition of the 80-bit set (Decomp<2, 10, 1>, opt-in: IYK_HIP_DECOMP=direct at iyk_hip_init): the 10-bit
+// digits as they are, 2 levels — 2 forward double-transforms per CMUX step instead of 4 and half the key stream.  The
+// worst case of an integer sum, (k+1) L N 2^9 2^31 = 2^52, is ABOVE p/2 = 2^48.58: the result is the exact one iff every
+// |sum| < p/2, which holds with overwhelming probability rather than always.  A sum is sum_i d_i k_i over 4096 key words
+// k_i that are uniform on [-2^31, 2^31) (masks of fresh TRLWE rows; the b-parts under the RLWE assumption the scheme rests
+// on anyway), so for ANY digits it is sub-Gaussian with sigma^2 <= (2^62 / 3) sum d_i^2 <= 2^92 / 3 and
+// P(|sum| >= p/2) <= 2 exp(-(p/2)^2 / (2 sigma^2)) = 2 e^-54 = 7e-24 per coefficient, 2e-17 per gate (500 steps x 2048 sums)
+// in the worst case over digits; for typical (uniform) digits sigma is 2^44.4, p/2 is 18 sigma and the bound is 1e-70 — far
+// below the gate's own decryption-failure rate.  The default (SPLIT = 2) remains exact unconditionally.
 template <int L_, int BGBIT_, int SPLIT_>
 struct Decomp {
     static constexpr int L = L_, BGBIT = BGBIT_, SPLIT = SPLIT_;
@@ -95,20 +105,30 @@ IYK_HD void fwd1_diff(int t, u32 abar, const u32* acc_h, u32 (&td)[32])
     }
 #endif
 }
+// zf = NttConsts::zf (the twists zeta^j2): read only when the digits are wider than the table (DIRECT decompositions),
+// where the entry is computed by the very expression that fills the table (ztab_entry) — wave-uniform operands.
 template <class D>
-IYK_HD void fwd1_digits(int v, const u32 (&td)[32], double (&x)[32], const double* ztab)
+IYK_HD void fwd1_digits(int v, const u32 (&td)[32], double (&x)[32], const double* ztab, const double* zf)
 {
-    static_assert(D::max_digit() <= ZTAB_DIGITS / 2, "digit range exceeds the twist table");
+    if constexpr (D::max_digit() <= ZTAB_DIGITS / 2) {
 #pragma unroll
-    for (int j2 = 0; j2 < 32; ++j2) x[j2] = ztab[j2 * ZTAB_DIGITS + (D::digit(td[j2], v) + ZTAB_DIGITS / 2)];
+        for (int j2 = 0; j2 < 32; ++j2) x[j2] = ztab[j2 * ZTAB_DIGITS + (D::digit(td[j2], v) + ZTAB_DIGITS / 2)];
+    }
+    else {
+#pragma unroll
+        for (int j2 = 0; j2 < 32; ++j2) {
+            const double d = (double)D::digit(td[j2], v);
+            x[j2] = j2 ? mulmod(d, zf[j2]) : d;
+        }
+    }
 }
 // both parts in one go (low-latency kernels: a wave owns one level, nothing to share)
 template <class D>
-IYK_HD void fwd1_pre(int t, int v, u32 abar, const u32* acc_h, double (&x)[32], const double* ztab)
+IYK_HD void fwd1_pre(int t, int v, u32 abar, const u32* acc_h, double (&x)[32], const double* ztab, const double* zf)
 {
     u32 td[32];
     fwd1_diff(t, abar, acc_h, td);
-    fwd1_digits<D>(v, td, x, ztab);
+    fwd1_digits<D>(v, td, x, ztab, zf);
 }
 
 IYK_HD void fwd1_twiddle(int t, double (&x)[32], const double* twf_t)

@@ -175,15 +175,26 @@ IYK_HD i32 t16_digit(u32 tb, int v)
 }
 
 // x (arrangement P) = digit of level v times zeta^j2, from the twisted-digit table
+// (zf: the twists themselves, for decompositions whose digits are wider than the table — see fwd1_digits)
 template <class D>
-IYK_HD void t16_digits(int half, int v, const u32 (&tb)[16], double (&x)[16], const double* ztab)
+IYK_HD void t16_digits(int half, int v, const u32 (&tb)[16], double (&x)[16], const double* ztab, const double* zf)
 {
-    static_assert(D::max_digit() <= ZTAB_DIGITS / 2, "digit range exceeds the twist table");
-    const double* zt = ztab + half * ZTAB_DIGITS + ZTAB_DIGITS / 2;
+    if constexpr (D::max_digit() <= ZTAB_DIGITS / 2) {
+        const double* zt = ztab + half * ZTAB_DIGITS + ZTAB_DIGITS / 2;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int j2c = 2 * (e >> 1) + 16 * (e & 1);
-        x[e] = zt[j2c * ZTAB_DIGITS + t16_digit<D>(tb[e], v)];
+        for (int e = 0; e < 16; ++e) {
+            const int j2c = 2 * (e >> 1) + 16 * (e & 1);
+            x[e] = zt[j2c * ZTAB_DIGITS + t16_digit<D>(tb[e], v)];
+        }
+    }
+    else {
+        const double* zh = zf + half;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int j2c = 2 * (e >> 1) + 16 * (e & 1);
+            const double d = (double)t16_digit<D>(tb[e], v);
+            x[e] = mulmod(d, zh[j2c]);   // zeta^0 = 1.0 and mulmod(d, 1.0) = d exactly: the table's "j2 ? ... : d" is the same value
+        }
     }
 }
 

@@ -225,7 +225,7 @@ void blind_rotate_fp(const iyk_params* p, const u32* lin, const double* bk_ntt, 
             {
                 Lane& r = R[lane];
                 if (first) {
-                    if (fwd) fp::fwd1_pre<D>(lane & 31, lvl, abar, acc_h(lane), r.x, ztab.data());
+                    if (fwd) fp::fwd1_pre<D>(lane & 31, lvl, abar, acc_h(lane), r.x, ztab.data(), C.zf);
                     else
                         for (int q = 0; q < 32; ++q) r.x[q] = fp::norm(r.accum[q]);
                 }
@@ -365,7 +365,7 @@ void blind_rotate_fp_lat3(const iyk_params* p, const u32* lin, const double* bk_
             {   // digits straight into arrangement P
                 u32 tb[16];
                 fp::lat3_diff2<D>(lane >> 5, lane & 31, ab, acc.data() + h * 2 * NTT_N, tb);
-                fp::t16_digits<D>(lane >> 5, v, tb, R[wave * 64 + lane].x, ztab.data());
+                fp::t16_digits<D>(lane >> 5, v, tb, R[wave * 64 + lane].x, ztab.data(), C.zf);
             }
             dif16p(wave, 1);
             WAVE_LANES(wave) fp::xpose16_write<false>(lane >> 5, lane & 31, R[wave * 64 + lane].x, wxb);
@@ -591,7 +591,7 @@ void blind_rotate_fp_t16(const iyk_params* p, const u32* lin, const double* bk_n
             for (int lane = 0; lane < 64; ++lane) fp::t16_diff<D>(lane >> 5, lane & 31, ab, acc.data() + h * NTT_N, R[lane].tb);
             for (int lvl = 0; lvl < L; ++lvl) {
                 const int row = h * L + lvl;
-                for (int lane = 0; lane < 64; ++lane) fp::t16_digits<D>(lane >> 5, lvl, R[lane].tb, R[lane].x, ztab.data());
+                for (int lane = 0; lane < 64; ++lane) fp::t16_digits<D>(lane >> 5, lvl, R[lane].tb, R[lane].x, ztab.data(), C.zf);
                 pass(1);
                 for (int lane = 0; lane < 64; ++lane) fp::t16_fwd_twiddle(lane >> 5, lane & 31, R[lane].x, T.twf_t.data());
                 trackw();
@@ -645,13 +645,17 @@ void blind_rotate_fp_t16(const iyk_params* p, const u32* lin, const double* bk_n
 }
 }  // namespace
 
+static int g_direct = 0;  // 80-bit set: Decomp<2, 10, 1> (IYK_HIP_DECOMP=direct on the device) instead of the split digits
+
 extern "C" {
 
+void iyk_emul_set_direct(int on) { g_direct = on; }
+
 // FP64 path: NTT of every (virtual) BK row polynomial, device layout, balanced doubles.
-// Output size: n * 2*LV * 2 * N doubles, LV = l (128-bit set) or 2l (80-bit set, split digits).
+// Output size: n * 2*LV * 2 * N doubles, LV = l (128-bit set; 80-bit set, direct) or 2l (80-bit set, split digits).
 int iyk_emul_bk_ntt_fp(const iyk_params* p, const uint32_t* bk, double* bk_ntt)
 {
-    const int split = (p->l == 2 && p->Bgbit == 10) ? 2 : 1;
+    const int split = (p->l == 2 && p->Bgbit == 10 && !g_direct) ? 2 : 1;
     const int L = (int)p->l, LV = L * split, hb = (int)p->Bgbit / 2;
     const size_t vpolys = (size_t)p->n * 2 * LV * 2;
     std::vector<double> in(NTT_N);
@@ -670,6 +674,7 @@ int iyk_emul_blind_rotate_fp(const iyk_params* p, const uint32_t* lin, const dou
 {
     if (p->N != 1024 || p->k != 1) return -1;
     if (p->l == 3 && p->Bgbit == 6) blind_rotate_fp<fp::Decomp<3, 6, 1>>(p, lin, bk_ntt, tlwe1);
+    else if (p->l == 2 && p->Bgbit == 10 && g_direct) blind_rotate_fp<fp::Decomp<2, 10, 1>>(p, lin, bk_ntt, tlwe1);
     else if (p->l == 2 && p->Bgbit == 10) blind_rotate_fp<fp::Decomp<2, 10, 2>>(p, lin, bk_ntt, tlwe1);
     else return -1;
     return 0;
@@ -679,6 +684,7 @@ int iyk_emul_blind_rotate_fp_lat3(const iyk_params* p, const uint32_t* lin, cons
 {
     if (p->N != 1024 || p->k != 1) return -1;
     if (p->l == 3 && p->Bgbit == 6) blind_rotate_fp_lat3<fp::Decomp<3, 6, 1>>(p, lin, bk_ntt, tlwe1);
+    else if (p->l == 2 && p->Bgbit == 10 && g_direct) blind_rotate_fp_lat3<fp::Decomp<2, 10, 1>>(p, lin, bk_ntt, tlwe1);
     else if (p->l == 2 && p->Bgbit == 10) blind_rotate_fp_lat3<fp::Decomp<2, 10, 2>>(p, lin, bk_ntt, tlwe1);
     else return -1;
     return 0;
@@ -688,6 +694,7 @@ int iyk_emul_blind_rotate_fp_t16(const iyk_params* p, const uint32_t* lin, const
 {
     if (p->N != 1024 || p->k != 1) return -1;
     if (p->l == 3 && p->Bgbit == 6) blind_rotate_fp_t16<fp::Decomp<3, 6, 1>>(p, lin, bk_ntt, tlwe1);
+    else if (p->l == 2 && p->Bgbit == 10 && g_direct) blind_rotate_fp_t16<fp::Decomp<2, 10, 1>>(p, lin, bk_ntt, tlwe1);
     else if (p->l == 2 && p->Bgbit == 10) blind_rotate_fp_t16<fp::Decomp<2, 10, 2>>(p, lin, bk_ntt, tlwe1);
     else return -1;
     return 0;

@@ -87,6 +87,7 @@ struct Global {
     u32 ksk_stride = 0;
     int ks_kernel = 1;    // 1: keyswitch_wave_kernel where instantiated, 0: keyswitch_kernel (IYK_HIP_KS_KERNEL)
     bool use_fp = false;          // FP64 path (fp50.hpp) instead of Goldilocks integers
+    int split = 1;                // FP64 path: digit polynomials per gadget level (blind_rotate_fp.hpp Decomp::SPLIT)
     int lat_threshold = 1280;     // rotations per batch at or below which a workgroup-per-rotation kernel is used
     int tp_kernel = 32;           // wave-per-rotation kernel: 32 = blind_rotate_fp_kernel (2 waves / SIMD), 16 = blind_rotate_fp_t16_kernel (3 waves / SIMD)
     fp::NttConsts fpc{};
@@ -301,6 +302,7 @@ int launch_blind_rotate(iyk_hip_stream* st, const u32* d_arena, const RotJob* d_
     HIP_TRY(hipGetLastError());
     if (G.use_fp) {
         if (p.l == 3) return dispatch_fp<fp::Decomp<3, 6, 1>>(st, njobs, o);
+        if (G.split == 1) return dispatch_fp<fp::Decomp<2, 10, 1>>(st, njobs, o);
         return dispatch_fp<fp::Decomp<2, 10, 2>>(st, njobs, o);
     }
     if (p.l == 3 && p.Bgbit == 6) return launch_br<3, 6>(st, njobs, o);
@@ -378,10 +380,10 @@ int set_fp_attrs()
     if ((rc = set_lds(blind_rotate_fp_t16_kernel<DC, BR_T16_WAVES>, BrT16<BR_T16_WAVES>::LDS_BYTES))) return rc;
     return set_lds(blind_rotate_fp_lat3_kernel<DC>, BrLat3<DC>::LDS_BYTES);
 }
-int set_kernel_attrs(const iyk_params& p, bool use_fp)
+int set_kernel_attrs(const iyk_params& p, bool use_fp, int split)
 {
     int rc;
-    if (use_fp) rc = (p.l == 3) ? set_fp_attrs<fp::Decomp<3, 6, 1>>() : set_fp_attrs<fp::Decomp<2, 10, 2>>();
+    if (use_fp) rc = (p.l == 3) ? set_fp_attrs<fp::Decomp<3, 6, 1>>() : split == 1 ? set_fp_attrs<fp::Decomp<2, 10, 1>>() : set_fp_attrs<fp::Decomp<2, 10, 2>>();
     else rc = (p.l == 3) ? set_lds(blind_rotate_kernel<3, 6>, BR_LDS_BYTES) : set_lds(blind_rotate_kernel<2, 10>, BR_LDS_BYTES);
     if (rc) return rc;
     const size_t ks_lds = (size_t)KS_G * NTT_N * 2;
@@ -465,7 +467,7 @@ int init_devices(std::vector<Device>& devs, const int* device_ids, int avail, co
         HIP_TRY(hipSetDevice(D.ordinal));
         HIP_TRY(hipDeviceGetAttribute(&D.cus, hipDeviceAttributeMultiprocessorCount, D.ordinal));
         if (D.cus < 1) return fail(IYK_ERR_HIP, "device reports no compute units");
-        int rc = set_kernel_attrs(p, use_fp);
+        int rc = set_kernel_attrs(p, use_fp, split);
         if (rc) return rc;
         u32* d_bk = nullptr;
         HIP_TRY(hipMalloc((void**)&D.bk_ntt, bk_words * sizeof(u64) * (use_fp ? split : 1)));
@@ -582,6 +584,9 @@ int iyk_hip_get_params(iyk_params* out)
 /* 1 = FP64 field path (p = 3 * 2^48 + 1097729), 0 = Goldilocks integer path */
 int iyk_hip_ntt_path(void) { return G.init.load() ? (G.use_fp ? 1 : 0) : IYK_ERR_STATE; }
 
+/* digit polynomials per accumulator polynomial and CMUX step: l, or 2 l where the FP64 path splits every digit */
+int iyk_hip_decomposition_levels(void) { return G.init.load() ? (int)G.p.l * (G.use_fp ? G.split : 1) : IYK_ERR_STATE; }
+
 #ifndef IYK_BUILD_ID
 #define IYK_BUILD_ID "unknown"
 #endif
@@ -628,12 +633,20 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
     // (fp50.hpp).  128-bit set: 3 levels of 6-bit digits; 80-bit set: each 10-bit digit split into two 5-bit
     // halves, 4 virtual levels (blind_rotate_fp.hpp Decomp).  IYK_HIP_NTT=goldilocks forces the 64-bit
     // integer path (kept as the cross-check and for A/B measurements).
-    const int split = (p.l == 2 && p.Bgbit == 10) ? 2 : 1;
+    // IYK_HIP_DECOMP=direct (80-bit set only, opt-in): the 10-bit digits as they are, 2 levels — exact iff every integer
+    // sum stays below p/2, which holds with probability >= 1 - 2e-17 per gate instead of always (blind_rotate_fp.hpp).
+    const char* dec = std::getenv("IYK_HIP_DECOMP");
+    const char* force = std::getenv("IYK_HIP_NTT");
+    const bool goldilocks = force && std::string(force) == "goldilocks";
+    const bool direct = dec && std::string(dec) == "direct";
+    if (dec && !direct && std::string(dec) != "split") return fail(IYK_ERR_INVALID, "IYK_HIP_DECOMP must be 'split' or 'direct'");
+    if (direct && (goldilocks || !(p.l == 2 && p.Bgbit == 10)))
+        return fail(IYK_ERR_INVALID, "IYK_HIP_DECOMP=direct applies to the FP64 path of the (l, Bgbit) = (2, 10) set only");
+    const int split = (p.l == 2 && p.Bgbit == 10 && !direct) ? 2 : 1;
     const int LV = (int)p.l * split;
     const double dmax = split == 1 ? (double)(1u << (p.Bgbit - 1)) : (double)(1u << (p.Bgbit / 2 - 1));
     const double worst = 2.0 * (p.k + 1) * LV * p.N * dmax * 2147483648.0;
-    const char* force = std::getenv("IYK_HIP_NTT");
-    const bool use_fp = worst < fp::P && !(force && std::string(force) == "goldilocks");
+    const bool use_fp = (worst < fp::P || direct) && !goldilocks;
     std::vector<u64> twf(NTT_N), twi(2 * NTT_N);  // twi: [k2][j1], then the transposed copy [j1][k2]
     fp::HostTables fpt{};
     if (use_fp) {
@@ -687,6 +700,7 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
     G.tp_kernel = (tk && std::string(tk) == "t16") ? 16 : 32;
     G.p = p;
     G.use_fp = use_fp;
+    G.split = split;
     G.fpc = fpt.c;
     G.ksk_stride = stride;
     G.devs = devs;

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fp_kernel(
             const double* bkt = bk_step + (size_t)(((1 - h) * L + lvl) * 2 + h) * NTT_N + (size_t)t * 2;
             double b0o[2], b0t[2], b1o[2], b1t[2];
 
-            fp::fwd1_digits<D>(lvl, td, x, s_ztab);
+            fp::fwd1_digits<D>(lvl, td, x, s_ztab, C.zf);
             fp::ntt32_dif<fp::PASS1>(x, C.w);
             fp::fwd1_twiddle(t, x, s_twf);
             xpose64<false>(t, x, xb64_own);
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(BrLat3<D>::THREADS) void blind_rotate_fp_lat3_kerne
             {   // digits straight into arrangement P (the pairs of stage 0): no swap-in round (blind_rotate_t16.hpp)
                 u32 tb[16];
                 fp::lat3_diff2<D>(half, t, ab, acc_lds + hA * 2 * NTT_N, tb);
-                fp::t16_digits<D>(half, vA, tb, x, s_ztab);
+                fp::t16_digits<D>(half, vA, tb, x, s_ztab, C.zf);
             }
             IYK_TRACE(1);
             dif16p<fp::PASS1>(x, half, tw0, C.w);

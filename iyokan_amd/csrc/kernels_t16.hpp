@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64 * NW, 3) void blind_rotate_fp_t16_kernel(
                     double kb[fp::T16_KBUF][fp::T16_KCH][2];  // key rows, a ring of chunks
                     constexpr int NCH = 16 / fp::T16_KCH;
 
-                    fp::t16_digits<D>(half, lvl, tb, x, s_ztab);
+                    fp::t16_digits<D>(half, lvl, tb, x, s_ztab, C.zf);
                     t16_pass<fp::PASS1>(x, half, tw0, C.w);
                     fp::t16_fwd_twiddle(half, t, x, s_twf);
                     t16_xpose<false>(half, t, x, xb);

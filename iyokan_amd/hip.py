@@ -28,7 +28,7 @@ EXPORTS = [
     "iyk_hip_stream_query", "iyk_hip_stream_sync", "iyk_hip_arena_alloc", "iyk_hip_arena_free",
     "iyk_hip_arena_upload", "iyk_hip_arena_download", "iyk_hip_gate_batch", "iyk_hip_gate_host",
     "iyk_hip_blind_rotate_batch", "iyk_hip_last_batch_timing", "iyk_hip_resident_key_bytes",
-    "iyk_hip_timing_log_begin", "iyk_hip_timing_log_end", "iyk_hip_ntt_path",
+    "iyk_hip_timing_log_begin", "iyk_hip_timing_log_end", "iyk_hip_ntt_path", "iyk_hip_decomposition_levels",
     "iyk_hip_bootstrap_trlwe_batch", "iyk_hip_sample_extract_keyswitch_batch",
     "iyk_hip_stream_gpu", "iyk_hip_arena_upload_slots", "iyk_hip_arena_download_slots", "iyk_hip_arena_copy",
     "iyk_hip_arena_sync_slots", "iyk_hip_trlwe_alloc", "iyk_hip_trlwe_free", "iyk_hip_trlwe_upload",
@@ -127,6 +127,12 @@ def resident_key_bytes():
 def ntt_path():
     """'fp50' (FP64 FMA field, default for the 128-bit set) or 'goldilocks' (64-bit integer field)."""
     return "fp50" if _check(lib().iyk_hip_ntt_path(), "iyk_hip_ntt_path") == 1 else "goldilocks"
+
+
+def decomposition_levels():
+    """Digit polynomials per accumulator polynomial and CMUX step (include/iyokan_hip.h: 3 for the 128-bit set; 80-bit set
+    4 by default, 2 with IYK_HIP_DECOMP=direct at init)."""
+    return _check(lib().iyk_hip_decomposition_levels(), "iyk_hip_decomposition_levels")
 
 
 def build_id():

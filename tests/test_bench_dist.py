@@ -148,11 +148,18 @@ def test_counters_are_tied_to_the_build(tmp_path, monkeypatch):
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     monkeypatch.setattr(bench, "COUNTER_FILES", ("missing.json", "c.json"))
     args = argparse.Namespace(params="128bit", op="NAND")
-    got, why = bench.counters(args, 65536, "aaaa")
+    got, why = bench.counters(args, 65536, "aaaa", 3)
     assert got["valu_insts_per_launch"] == 1.0 and got["_file"] == "profiles/c.json" and why is None
-    got, why = bench.counters(args, 65536, "bbbb")
+    got, why = bench.counters(args, 65536, "bbbb", 3)
     assert got is None and "build aaaa" in why and "bbbb" in why
-    got, why = bench.counters(args, 8192, "aaaa")
+    got, why = bench.counters(args, 8192, "aaaa", 3)
     assert got is None and "no counter file" in why
-    got, why = bench.counters(argparse.Namespace(params="80bit", op="NAND"), 65536, "aaaa")
+    got, why = bench.counters(argparse.Namespace(params="80bit", op="NAND"), 65536, "aaaa", 4)
+    assert got is None
+    # counters of the 80-bit set's split decomposition (files older than the field: 4 levels) never price the direct one
+    rec["workload"]["params"] = "80bit"
+    (tmp_path / "profiles" / "c.json").write_text(json.dumps(rec))
+    got, why = bench.counters(argparse.Namespace(params="80bit", op="NAND"), 65536, "aaaa", 4)
+    assert got is not None
+    got, why = bench.counters(argparse.Namespace(params="80bit", op="NAND"), 65536, "aaaa", 2)
     assert got is None

@@ -144,3 +144,102 @@ def test_80bit_full_size_flat_nand_property(keys80, oracle80):
     oracle80.gate_batch([OPS["NAND"]] * 32, ia[sample], ib[sample], [-1] * 32, list(range(nin, nin + 32)), ref,
                         nthreads=os.cpu_count() or 1)
     assert np.array_equal(got[sample], ref[nin:])
+
+
+@pytest.mark.parametrize("kernel", ["w32", "t16", "lat3", None])
+def test_80bit_direct_decomposition(kernel, keys80, oracle80, monkeypatch):
+    """IYK_HIP_DECOMP=direct (opt-in, include/iyokan_hip.h: iyk_hip_decomposition_levels): the 80-bit set's 10-bit digits
+    as they are, 2 levels instead of 4 virtual ones.  Same ciphertexts as the oracle, word for word, on every rotation
+    kernel — 512 NANDs, the adversarial LWE rows and a TRLWE-mode batch; an integer sum reaching p/2 would show here as a
+    mismatch (probability <= 2e-17 per gate)."""
+    import oracle_lib
+    from iyokan_amd import hip
+
+    if kernel is None:
+        monkeypatch.delenv("IYK_HIP_ROT_KERNEL", raising=False)
+    else:
+        monkeypatch.setenv("IYK_HIP_ROT_KERNEL", kernel)
+    monkeypatch.delenv("IYK_HIP_NTT", raising=False)
+    monkeypatch.setenv("IYK_HIP_DECOMP", "direct")
+    hip.initialize(keys80, device_ids=(0,))
+    try:
+        assert hip.ntt_path() == "fp50" and hip.decomposition_levels() == 2
+        st = hip.Stream(0)
+        p = keys80.params
+        G, nin = 512, 64
+        rng = np.random.default_rng(21)
+        bits = rng.integers(0, 2, size=nin).astype(np.uint8)
+        ia = rng.integers(0, nin, size=G).astype(np.int32)
+        ib = rng.integers(0, nin, size=G).astype(np.int32)
+        rows = oracle_lib.adversarial_rows(p.n)
+        host = np.zeros((nin + len(rows) + G + len(rows), p.n + 1), dtype=np.uint32)
+        host[:nin] = client.encrypt_bits(keys80, bits, seed=9)
+        host[nin:nin + len(rows)] = rows
+        o0 = nin + len(rows)
+        ops = [OPS["NAND"]] * G + [OPS["AND"]] * len(rows)
+        in0 = list(ia) + list(range(nin, nin + len(rows)))
+        in1 = list(ib) + list(range(nin, nin + len(rows)))
+        out = list(range(o0, o0 + G + len(rows)))
+        arena = hip.Arena(host.shape[0])
+        st.upload(arena, 0, host)
+        st.gate_batch(arena, ops, in0, in1, [-1] * len(ops), out)
+        st.sync()
+        got = st.download(arena, 0, host.shape[0])
+        arena.free()
+        st.destroy()
+    finally:
+        hip.cleanup()
+    ref = host.copy()
+    oracle80.gate_batch(ops, in0, in1, [-1] * len(ops), out, ref, nthreads=os.cpu_count() or 1)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(client.decrypt_bits(keys80, got[o0:o0 + G]), 1 - (bits[ia] & bits[ib]))
+
+
+def test_80bit_direct_full_size_and_rejections(keys80, keys128, oracle80, monkeypatch):
+    """65 536 NANDs with the direct decomposition: all decrypt, the noise statistics are the scheme's, a 32-gate sample
+    equals the oracle; the option is refused for the 128-bit set, together with the integer path, and when misspelt."""
+    from iyokan_amd import hip
+
+    monkeypatch.delenv("IYK_HIP_ROT_KERNEL", raising=False)
+    monkeypatch.delenv("IYK_HIP_NTT", raising=False)
+    monkeypatch.setenv("IYK_HIP_DECOMP", "direct")
+    with pytest.raises(hip.IykHipError, match="IYK_HIP_DECOMP=direct applies"):
+        hip.initialize(keys128, device_ids=(0,))
+    monkeypatch.setenv("IYK_HIP_NTT", "goldilocks")
+    with pytest.raises(hip.IykHipError, match="IYK_HIP_DECOMP=direct applies"):
+        hip.initialize(keys80, device_ids=(0,))
+    monkeypatch.delenv("IYK_HIP_NTT", raising=False)
+    monkeypatch.setenv("IYK_HIP_DECOMP", "fast")
+    with pytest.raises(hip.IykHipError, match="must be 'split' or 'direct'"):
+        hip.initialize(keys80, device_ids=(0,))
+    monkeypatch.setenv("IYK_HIP_DECOMP", "direct")
+    hip.initialize(keys80, device_ids=(0,))
+    try:
+        st = hip.Stream(0)
+        p = keys80.params
+        G, nin = 65536, 2048
+        rng = np.random.default_rng(13)
+        bits = rng.integers(0, 2, size=nin).astype(np.uint8)
+        ia = rng.integers(0, nin, size=G).astype(np.int32)
+        ib = rng.integers(0, nin, size=G).astype(np.int32)
+        enc = client.encrypt_bits(keys80, bits, seed=8)
+        arena = hip.Arena(nin + G)
+        st.upload(arena, 0, enc)
+        st.gate_batch(arena, np.full(G, OPS["NAND"], dtype=np.int32), ia, ib, np.full(G, -1, dtype=np.int32),
+                      np.arange(nin, nin + G, dtype=np.int32))
+        st.sync()
+        got = st.download(arena, nin, G)
+        arena.free()
+        st.destroy()
+    finally:
+        hip.cleanup()
+    assert np.array_equal(client.decrypt_bits(keys80, got), 1 - (bits[ia] & bits[ib]))
+    import numpy_tfhe
+
+    numpy_tfhe.check_noise_against_cggi(keys80, got, 1 - (bits[ia] & bits[ib]), rel_tol=0.05)
+    sample = rng.choice(G, size=32, replace=False)
+    ref = np.zeros((nin + 32, p.n + 1), dtype=np.uint32)
+    ref[:nin] = enc
+    oracle80.gate_batch([OPS["NAND"]] * 32, ia[sample], ib[sample], [-1] * 32, list(range(nin, nin + 32)), ref,
+                        nthreads=os.cpu_count() or 1)
+    assert np.array_equal(got[sample], ref[nin:])

@@ -98,3 +98,38 @@ def test_emulated_kernels_on_adversarial_rows(which, request):
             assert fn(ctypes.byref(p), lin.ctypes.data_as(u32p), bk.ctypes.data_as(dp), got.ctypes.data_as(u32p)) == 0
             assert np.array_equal(ref, got), (r, fn)
     assert em.iyk_emul_fp_max_magnitude() < 0.95 * 2.0 ** 53 / 844424931229697
+
+
+def test_emulated_direct_decomposition_80bit(keys80, oracle80):
+    """Decomp<2, 10, 1> (IYK_HIP_DECOMP=direct): the 80-bit set's 10-bit digits as they are — 2 levels, half the key
+    stream.  Exact iff every integer sum stays below p/2, which real key rows give with probability 1 - 2e-17 per gate
+    in the worst case over digits (blind_rotate_fp.hpp): all three kernels' emulations == oracle on encrypted inputs
+    and on the adversarial LWE rows (the rows are adversarial, the key is a real one)."""
+    import oracle_lib
+
+    p = keys80.params
+    em = _emul()
+    em.iyk_emul_fp_max_magnitude.restype = ctypes.c_double
+    dp = ctypes.POINTER(ctypes.c_double)
+    em.iyk_emul_set_direct(1)
+    try:
+        bk = np.zeros(p.bk_words, dtype=np.float64)   # no virtual levels: one double per key word
+        assert em.iyk_emul_bk_ntt_fp(ctypes.byref(p), keys80.bk.ctypes.data_as(u32p), bk.ctypes.data_as(dp)) == 0
+        lins = []
+        for seed, (a, b) in enumerate([(1, 1), (0, 1)]):
+            ca = client.encrypt_bits(keys80, [a], seed=170 + seed)[0]
+            cb = client.encrypt_bits(keys80, [b], seed=180 + seed)[0]
+            lin = (np.uint32(0) - ca - cb).astype(np.uint32)
+            lin[-1] = np.uint32((int(lin[-1]) + p.mu) & 0xFFFFFFFF)
+            lins.append(lin)
+        rows = oracle_lib.adversarial_rows(p.n)
+        lins += [np.ascontiguousarray(rows[r]) for r in (0, 6)]
+        for lin in lins:
+            ref = oracle80.bootstrap_lvl1(lin)
+            for fn in (em.iyk_emul_blind_rotate_fp, em.iyk_emul_blind_rotate_fp_lat3, em.iyk_emul_blind_rotate_fp_t16):
+                got = np.zeros(p.N + 1, dtype=np.uint32)
+                assert fn(ctypes.byref(p), lin.ctypes.data_as(u32p), bk.ctypes.data_as(dp), got.ctypes.data_as(u32p)) == 0
+                assert np.array_equal(ref, got), fn
+        assert em.iyk_emul_fp_max_magnitude() < 0.95 * 2.0 ** 53 / 844424931229697
+    finally:
+        em.iyk_emul_set_direct(0)

@@ -4,14 +4,16 @@
 # writes gpurun_out/<tag>_bench.json, <tag>_kernel_trace.txt, <tag>_pmc.txt, <tag>_counters.json
 # (copy the ones to keep into profiles/; bench.py reads profiles/r03_counters.json and uses it only while its build_id —
 # the hash of the kernel sources, tools/src_hash.py — equals the loaded library's).  Counters are collected in their own
-# --pmc passes, never together with trace domains.  PARAMS=80bit profiles the 80-bit set.
+# --pmc passes, never together with trace domains.  PARAMS=80bit profiles the 80-bit set; DECOMP=direct its opt-in
+# direct decomposition (bench.py --decomp).
 tag=${1:-r03}
 PARAMS=${PARAMS:-128bit}
+DEC=${DECOMP:+--decomp $DECOMP}
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
 mkdir -p gpurun_out
 if [ -z "$PMC_ONLY" ]; then
-timeout 600 python bench.py --params $PARAMS 2>/dev/null | tail -1 > gpurun_out/${tag}_bench.json
-rm -rf /tmp/prof_kt && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python bench.py --params $PARAMS --cpu-sample 0 > /tmp/kt.log 2>&1
+timeout 600 python bench.py --params $PARAMS $DEC 2>/dev/null | tail -1 > gpurun_out/${tag}_bench.json
+rm -rf /tmp/prof_kt && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python bench.py --params $PARAMS $DEC --cpu-sample 0 > /tmp/kt.log 2>&1
 python tools/rocprof_summary.py $(find /tmp/prof_kt -name "*.db" | head -1) > gpurun_out/${tag}_kernel_trace.txt
 fi
 {
@@ -19,18 +21,19 @@ fi
   for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD" \
              "GRBM_GUI_ACTIVE" "SQ_BUSY_CYCLES SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
              "SQ_INSTS SQ_INSTS_SMEM SQ_INSTS_BRANCH" "SQ_WAVE_CYCLES"; do
-    rm -rf /tmp/prof_pmc; timeout 300 rocprofv3 --pmc $grp -d /tmp/prof_pmc -o pmc -- python bench.py --params $PARAMS --steps 1 --warmup 0 --cpu-sample 0 > /tmp/pmc.log 2>&1
+    rm -rf /tmp/prof_pmc; timeout 300 rocprofv3 --pmc $grp -d /tmp/prof_pmc -o pmc -- python bench.py --params $PARAMS $DEC --steps 1 --warmup 0 --cpu-sample 0 > /tmp/pmc.log 2>&1
     db=$(find /tmp/prof_pmc -name "*.db" 2>/dev/null | head -1)
     if [ -n "$db" ]; then
       python tools/rocprof_summary.py $db --pmc | grep -v "^#\|^ calls" | grep "blind_rotate\|keyswitch\|^ *[0-9]" | grep -v "copyBuffer\|at::native"
     else echo "# pass failed: $grp"; tail -5 /tmp/pmc.log | sed 's/^/#   /'; fi
   done
 } > gpurun_out/${tag}_pmc.txt
-python - "$tag" "$PARAMS" <<'PY'
+python - "$tag" "$PARAMS" "${DECOMP:-default}" <<'PY'
 import json, re, sys
 sys.path.insert(0, ".")
 from iyokan_amd import hip
 tag, params_name = sys.argv[1], sys.argv[2]
+levels = {"128bit": 3, "80bit": 2 if sys.argv[3] == "direct" else 4}[params_name]   # iyk_hip_decomposition_levels of the profiled run
 kname = None
 vals, durs = {}, []
 for line in open(f"gpurun_out/{tag}_pmc.txt"):
@@ -52,7 +55,7 @@ if "FETCH_SIZE" in vals:
                 "the kernel sources the profiled library was built from) match the loaded library.",
         "kernel": kname,
         "build_id": hip.build_id(),
-        "workload": {"gates_per_launch": 65536, "params": params_name, "op": "NAND"},
+        "workload": {"gates_per_launch": 65536, "params": params_name, "op": "NAND", "decomposition_levels": levels},
         "FETCH_SIZE_KiB": vals["FETCH_SIZE"], "WRITE_SIZE_KiB": vals.get("WRITE_SIZE", 0.0),
         "traffic_bytes_per_launch": int((2 * vals["FETCH_SIZE"] + vals.get("WRITE_SIZE", 0.0)) * 1024),
     }
