@@ -5,11 +5,12 @@ timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/${T}_gputests.txt 
 tail -3 gpurun_out/${T}_gputests.txt
 bash tools/profile_round.sh ${T} > gpurun_out/${T}_profile_round.log 2>&1
 PARAMS=80bit bash tools/profile_round.sh ${T}_80bit > gpurun_out/${T}_80bit_profile_round.log 2>&1
+PARAMS=80bit DECOMP=direct bash tools/profile_round.sh ${T}_80bit_direct > gpurun_out/${T}_80bit_direct_profile_round.log 2>&1
 for net in cahp-ruby cahp-system mux-ram; do timeout 600 python tools/bench_netlist.py --net $net 2>/dev/null | tail -1; done > gpurun_out/${T}_bench_netlist.txt
 cat gpurun_out/${T}_bench_netlist.txt | cut -c1-200
 python -c "
 import json
-for t in ('${T}','${T}_80bit'):
+for t in ('${T}','${T}_80bit','${T}_80bit_direct'):
     d=json.load(open('gpurun_out/%s_bench.json'%t)); print(t, round(d['value']), d['roofline']['bound'], round(d['roofline']['frac'],3), round(d['roofline']['contract_frac'],3), d['cpu_baseline']['value'] if d.get('cpu_baseline') else None)
 "
 head -8 gpurun_out/${T}_kernel_trace.txt
