@@ -133,3 +133,36 @@ def test_emulated_direct_decomposition_80bit(keys80, oracle80):
         assert em.iyk_emul_fp_max_magnitude() < 0.95 * 2.0 ** 53 / 844424931229697
     finally:
         em.iyk_emul_set_direct(0)
+
+
+def test_direct_decomposition_boundary_is_where_the_bound_says(keys80):
+    """The other side of the direct decomposition's contract: it is exact IFF every integer sum stays below p/2.  A
+    'bootstrapping key' no key generation produces — every word 2^31 - 1, all aligned — drives a sum to 1023 * 256 *
+    2^31 = 2^49 > p/2 = 2^48.58 in the first CMUX step: the direct decomposition then differs from the oracle, the
+    default (split digits, |sum| <= 2^48 whatever the key) still equals it word for word."""
+    import oracle_lib
+
+    p = keys80.params
+    em = _emul()
+    dp = ctypes.POINTER(ctypes.c_double)
+    bad = client.KeySet(p, keys80.s0, keys80.s1, np.full(p.bk_words, 0x7FFFFFFF, dtype=np.uint32), keys80.ksk)
+    orc = oracle_lib.Oracle(bad)
+    lin = np.zeros(p.n + 1, dtype=np.uint32)
+    lin[0] = 0x7FE00000      # abar_0 = 1023: (X^1023 - 1) * testvector = -2 mu on 1023 coefficients, digit -256 at level 1, and
+                             # coefficient 1023 of its product with the all-max row is 1023 * 256 * (2^31 - 1): no wrap-around sign
+    ref = orc.bootstrap_lvl1(lin)
+    got = {}
+    for direct in (0, 1):
+        em.iyk_emul_set_direct(direct)
+        try:
+            bk = np.zeros(p.bk_words * (1 if direct else 2), dtype=np.float64)
+            assert em.iyk_emul_bk_ntt_fp(ctypes.byref(p), bad.bk.ctypes.data_as(u32p), bk.ctypes.data_as(dp)) == 0
+            out = np.zeros(p.N + 1, dtype=np.uint32)
+            assert em.iyk_emul_blind_rotate_fp(ctypes.byref(p), lin.ctypes.data_as(u32p), bk.ctypes.data_as(dp),
+                                               out.ctypes.data_as(u32p)) == 0
+            got[direct] = out
+        finally:
+            em.iyk_emul_set_direct(0)
+    orc.close()
+    assert np.array_equal(got[0], ref)
+    assert not np.array_equal(got[1], ref)
