@@ -58,9 +58,8 @@ struct Decomp {
         const i32 lo = ((d + half) & ((1 << HB) - 1)) - half;
         return (v % SPLIT_ == 0) ? ((d - lo) >> HB) : lo;
     }
-    // largest |digit| and the scale applied to the key row of virtual level v
+    // largest |digit| (the key row of virtual level v = 2 lvl is 2^HB BK_lvl mod 2^32: bk_ntt_fp_kernel)
     static constexpr double max_digit() { return SPLIT_ == 1 ? (double)(1 << (BGBIT_ - 1)) : (double)(1 << (HB - 1)); }
-    IYK_HD static u32 key_scale(int v) { return (SPLIT_ == 2 && (v % SPLIT_ == 0)) ? (1u << HB) : 1u; }
 };
 
 // Twisted-digit table: ztab[j2 * 64 + (d + 32)] = d * zeta^j2 mod p for every digit value d in [-32, 32)

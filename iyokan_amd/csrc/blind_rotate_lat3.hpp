@@ -237,68 +237,13 @@ IYK_HD constexpr int brv3(int x) { return ((x & 1) << 2) | (x & 2) | ((x & 4) >>
 IYK_HD constexpr int freq8(int g, int half, int q) { return 4 * brv3(q) + 2 * half + g; }
 IYK_HD constexpr int inv8(int g, int half, int q) { return (32 - freq8(g, half, q)) & 31; }
 
-// forward pass 1, pre: td[r] = ((X^abar - 1) acc_h)[t + 32 (16 half + r)], digit of virtual level v, times
-// zeta^j2 from the twisted-digit table
-template <class D>
-IYK_HD void fwd1_pre16(int half, int t, int v, u32 abar, const u32* acc_h, double (&x)[16], const double* ztab)
-{
-    u32 td[16];
-#if defined(__HIP_DEVICE_COMPILE__)
-    // PRECONDITION (the kernel's LDS map honours it): acc_h is 4 KB aligned, so the wrapped byte address of the
-    // rotated coefficient is one v_and_or (see fwd1_diff in blind_rotate_fp.hpp)
-    typedef const __attribute__((address_space(3))) u32* lds_u32;
-    const u32 acc_base = (u32)(size_t)(lds_u32)acc_h;
-    const u32 base4 = (((u32)t - abar) << 2) + 2048u * (u32)half;
-    const u32* own = acc_h + t + 512 * half;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const u32 idx4 = base4 + 128u * (u32)r;
-        const u32 neg = (u32)((i32)(idx4 << 19) >> 31);       // bit 12 of 4 idx = bit 10 of idx
-        const u32 a = *(lds_u32)(size_t)((idx4 & 0xFFCu) | acc_base);
-        td[r] = (a ^ neg) + ((0u - own[32 * r]) - neg);
-    }
-#else
-    const u32 base = (u32)t - abar;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int j2 = 16 * half + r;
-        const u32 idx = base + 32u * (u32)j2;  // position of the rotated coefficient, mod 2N
-        const u32 neg = 0u - ((idx >> 10) & 1u);
-        const u32 rot = (acc_h[idx & (NTT_N - 1)] ^ neg) - neg;
-        td[r] = rot - acc_h[t + 32 * j2];
-    }
-#endif
-    const double* zt = ztab + 16 * half * ZTAB_DIGITS + ZTAB_DIGITS / 2;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = zt[r * ZTAB_DIGITS + D::digit(td[r], v)];
-}
-
-// inter-pass twiddles: forward psi^(j1 (2 k2 + 1)) with j1 = t, k2 = freq16; inverse psi^(-j1 (2 k2 + 1)) / N with
-// k2 = t, j1 = inv16.  Tables in the LDS layout of the other workgroup-per-rotation kernels: twf_t[k2 * 32 + j1],
-// twi_t[j1 * 32 + k2].
-IYK_HD void fwd1_twiddle16(int half, int t, double (&x)[16], const double* twf_t)
-{
-#pragma unroll
-    for (int q = 0; q < 16; ++q) x[q] = mulmod(x[q], twf_t[freq16(half, q) * 32 + t]);
-}
-IYK_HD void inv1_twiddle16(int half, int t, double (&x)[16], const double* twi_t)
-{
-#pragma unroll
-    for (int q = 0; q < 16; ++q) x[q] = mulmod(x[q], twi_t[inv16(half, q) * 32 + t]);
-}
-
-// 32 x 32 transpose through a wave-owned f64 [32][33] matrix: value q goes to row freq16 / inv16, column t;
-// the lane then reads elements 16 half + r of row t
+// 32 x 32 transpose through a wave-owned f64 [32][33] matrix: value q goes to row freq16 / inv16, column t; the
+// reader takes row t in the arrangement its first stage wants (kernels.hpp, blind_rotate_t16.hpp)
 template <bool INV>
 IYK_HD void xpose16_write(int half, int t, const double (&x)[16], double* xb)
 {
 #pragma unroll
     for (int q = 0; q < 16; ++q) xb[(INV ? inv16(half, q) : freq16(half, q)) * XB_STRIDE + t] = x[q];
-}
-IYK_HD void xpose16_read(int half, int t, double (&x)[16], const double* xb)
-{
-#pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = xb[t * XB_STRIDE + 16 * half + r];
 }
 
 // key rows of digit polynomial `row` for output polynomial c, the 16 frequencies of this lane: element
