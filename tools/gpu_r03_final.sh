@@ -14,3 +14,13 @@ for t in ('${T}','${T}_80bit','${T}_80bit_direct'):
     d=json.load(open('gpurun_out/%s_bench.json'%t)); print(t, round(d['value']), d['roofline']['bound'], round(d['roofline']['frac'],3), round(d['roofline']['contract_frac'],3), d['cpu_baseline']['value'] if d.get('cpu_baseline') else None)
 "
 head -8 gpurun_out/${T}_kernel_trace.txt
+# bench lines WITH the counters just measured (bench.py reads profiles/: copy first)
+cp gpurun_out/${T}_counters.json profiles/r03_counters.json; cp gpurun_out/${T}_80bit_counters.json profiles/r03_counters_80bit.json; cp gpurun_out/${T}_80bit_direct_counters.json profiles/r03_counters_80bit_direct.json
+python bench.py 2>/dev/null | tail -1 > gpurun_out/${T}_bench_final.json
+python bench.py --params 80bit 2>/dev/null | tail -1 > gpurun_out/${T}_80bit_bench_final.json
+python bench.py --params 80bit --decomp direct 2>/dev/null | tail -1 > gpurun_out/${T}_80bit_direct_bench_final.json
+python -c "
+import json
+for t in ('${T}','${T}_80bit','${T}_80bit_direct'):
+    d=json.load(open('gpurun_out/%s_bench_final.json'%t)); r=d['roofline']; print(t, round(d['value']), r['bound'], round(r['frac'],3), round(r['contract_frac'],3), r.get('valu_dropped'))
+"
