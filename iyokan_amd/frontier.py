@@ -25,12 +25,129 @@ from .netlist import BINARY
 from .params import OPS
 
 
-class FrontierPlan:
-    """Slot assignment + per-level, per-rank gate descriptor arrays."""
+def mi355x_level_cost(rotations):
+    """Milliseconds one rank spends on a level of `rotations` blind rotations, as the dispatch of csrc/iyokan_hip.hip
+    prices it on an MI355X (profiles/r03_sweep_lat3.txt, r03_kernel_trace.txt): full rounds of 2048 on the wave-per-rotation
+    kernel at 19.7 ms; a remainder of up to 1280 on the workgroup-per-rotation kernel, 256 (one per CU) at a time; a larger
+    remainder is one more full round.  Only the SHAPE matters to the planner (where the steps are), not the milliseconds."""
+    if rotations <= 0:
+        return 0.0
+    full, rem = divmod(rotations, 2048)
+    t = 19.7 * full
+    if rem == 0:
+        return t
+    if rem <= 1280:
+        return t + (3.33, 6.96, 10.23, 13.52, 16.79)[-(-rem // 256) - 1]
+    return t + 19.7
 
-    def __init__(self, nl, world=1):
+
+def level_rotations(nl, levels, world=1):
+    """Rotations per rank and level (binary gate 1, MUX 2; dealt round-robin, MUX first: FrontierPlan)."""
+    return [-(-sum(2 if nl.kinds[i] == "MUX" else 1 if nl.kinds[i] in BINARY else 0 for i in lv) // world) for lv in levels]
+
+
+def plan_levels(nl, world=1, cost=mi355x_level_cost):
+    """The cheapest, by `cost`, of levelise() and balanced_levels() at three cut granularities — the greedy is not
+    monotone (a deferral can push a later level over a step), so the plain ASAP levels stay a candidate."""
+    best, best_t = None, None
+    for quanta in (None, (2048, 256), (256,), (2048,)):
+        lv = nl.levelise() if quanta is None else balanced_levels(nl, world, cost, quanta)
+        t = sum(cost(r) for r in level_rotations(nl, lv, world))
+        if best is None or t < best_t - 1e-9:
+            best, best_t = lv, t
+    return best
+
+
+def balanced_levels(nl, world=1, cost=mi355x_level_cost, quanta=(2048, 256)):
+    """The per-clock DAG in as many levels as netlist.levelise() gives (the critical path is not stretched, so the number of
+    level-boundary exchanges is the same), with every gate that has SLACK placed where it costs least.
+
+    levelise() puts a gate at its earliest level.  The kernels price a level in steps — 256 rotations per pass of the
+    narrow-frontier kernel, 2048 per round of the throughput kernel — so a level of 300 rotations costs two passes where
+    256 + 44 deferred would cost one, if 44 of its gates can wait.  A gate can wait until its ALAP level (depth minus its
+    longest path to a sink).  Greedy list scheduling, level by level: ready gates sorted by ALAP level; the gates whose
+    ALAP level is now MUST run; beyond them the level is cut at the multiple of 256 / 2048 rotations (per rank) that gives
+    the lowest time per rotation, and the rest waits.  NOT / CONST cost nothing and run as soon as their input exists.
+    Any cut yields a valid schedule (a deferred gate's successors are deferred with it and all have the slack)."""
+    asap = nl.levelise()
+    depth = len(asap)
+    n = nl.num_nodes
+    level = [0] * n
+    for k, lv in enumerate(asap):
+        for i in lv:
+            level[i] = k + 1
+    order = [i for lv in asap for i in lv]
+    succ = [[] for _ in range(n)]
+    npred = [0] * n
+    root = nl.roots()
+    for i in order:
+        for j in nl.ins[i]:
+            j = root[j] if nl.kinds[j] == "OUTPUT" else j
+            if level[j] > 0:
+                succ[j].append(i)
+                npred[i] += 1
+    alap = [depth] * n
+    for i in reversed(order):
+        for s2 in succ[i]:
+            alap[i] = min(alap[i], alap[s2] - 1)
+    rot = [2 if nl.kinds[i] == "MUX" else 1 if nl.kinds[i] in BINARY else 0 for i in range(n)]
+    ready = [i for i in order if npred[i] == 0]
+    out = []
+    for k in range(1, depth + 1):
+        this = []
+
+        def release(i, into):
+            for s2 in succ[i]:
+                npred[s2] -= 1
+                if npred[s2] == 0:
+                    into.append(s2)
+
+        # free nodes run as soon as they are ready; like levelise(), they count as a level of their own for their
+        # consumers (a batch never reads a slot it writes: two chained NOTs cannot share one elementwise batch)
+        nxt, boots = [], []
+        for i in ready:
+            if rot[i] == 0:
+                this.append(i)
+                release(i, nxt)
+            else:
+                boots.append(i)
+        boots.sort(key=lambda i: (alap[i], i))
+        total = sum(rot[i] for i in boots)
+        must = sum(rot[i] for i in boots if alap[i] <= k)
+        per_rank = lambda r: -(-r // world)
+        cands = {total}
+        for q in (q0 * world for q0 in quanta):
+            c = (total // q) * q
+            if c >= must and c > 0:
+                cands.add(c)
+        if total and k < depth:
+            cut = min(cands, key=lambda c: (cost(per_rank(c)) / c, -c))
+        else:
+            cut = total
+        take, rest, acc = [], [], 0
+        for i in boots:
+            if alap[i] <= k or acc + rot[i] <= cut:
+                take.append(i)
+                acc += rot[i]
+            else:
+                rest.append(i)
+        nxt.extend(rest)
+        for i in take:
+            release(i, nxt)
+        this.extend(take)
+        out.append(this)
+        ready = nxt
+    assert not ready and sum(len(lv) for lv in out) == len(order)
+    return out
+
+
+class FrontierPlan:
+    """Slot assignment + per-level, per-rank gate descriptor arrays.  `balance` (default): gates with slack are placed in
+    the level where the kernels' step-shaped cost is lowest (plan_levels); False: every gate at its earliest level."""
+
+    def __init__(self, nl, world=1, balance=True):
         self.nl, self.world = nl, world
-        levels = nl.levelise()
+        levels = plan_levels(nl, world) if balance else nl.levelise()
         n = nl.num_nodes
         slot = [-1] * n
         nslots = 0
