@@ -29,7 +29,9 @@
 //  * Status codes: every C-ABI failure is mapped to die() = the reference's error::die.
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <string>
 
 #include "../../include/iyokan_hip.h"
 #include "engine.hpp"
@@ -451,9 +453,67 @@ using HIPNetwork = TaskNetwork<HIPWorkerInfo>;
 // The batching worker.  update(): (1) drain the ready frontier, deal it to the GPUs, launch one batch per GPU and
 // enqueue the device-to-device exchange of every GPU's outputs; (2) when all streams are idle, propagate every
 // node of that frontier.
+// Milliseconds one GPU spends on `rot` blind rotations of one batch, as iyk_hip_gate_batch dispatches them on an MI355X:
+// rounds of 2048 on the wave-per-rotation kernel, a remainder of up to 1280 in passes of 256 on the
+// workgroup-per-rotation kernel, a larger one in one more round (profiles/r03_sweep_lat3.txt; only the position of the
+// steps matters).  Same function as iyokan_amd/frontier.py: mi355x_level_cost.
+inline double levelCostMs(long rot)
+{
+    if (rot <= 0) return 0.0;
+    static const double pass[5] = {3.33, 6.96, 10.23, 13.52, 16.79};
+    const long full = rot / 2048, rem = rot % 2048;
+    double t = 19.7 * (double)full;
+    if (rem == 0) return t;
+    if (rem <= 1280) return t + pass[(rem + 255) / 256 - 1];
+    return t + 19.7;
+}
+
 class HIPWorker : public Worker<HIPWorkerInfo> {
     std::vector<HIPWorkerInfo> wi_;  // one per GPU
     std::vector<int> inflight_;
+
+    // A frontier is priced in steps (levelCostMs), so a gate that has SLACK — its longest path to a sink is shorter than
+    // the frontier's longest, the clock's remaining critical path — can wait for a later frontier where it rides for free.
+    // The frontier (popped most urgent first: priority = longest path to a sink) is cut at the multiple of 256 / 2048
+    // rotations per GPU with the lowest time per rotation that still contains every critical gate; the rest goes back to
+    // the queue.  The critical path is never stretched: the number of frontiers per clock stays the DAG's depth.
+    // (The Python executor plans the same statically: iyokan_amd/frontier.py balanced_levels.)
+    void deferSlack(TaskNetwork<HIPWorkerInfo>& net, std::vector<int>& frontier, int G)
+    {
+        static const bool asap = [] { const char* e = std::getenv("IYK_HOST_FRONTIER"); return e && std::string(e) == "asap"; }();
+        if (asap) return;  // A/B knob: every ready gate at once (the reference's behaviour)
+        int crit = 0;
+        for (int id : frontier) crit = std::max(crit, net.node(id).priority);
+        long total = 0, must = 0;
+        for (int id : frontier) {
+            const int r = static_cast<TaskHIPGate&>(net.node(id)).rotations();
+            total += r;
+            if (net.node(id).priority >= crit) must += r;
+        }
+        if (total == 0 || crit == 0) return;
+        long cut = total;
+        double best = levelCostMs((total + G - 1) / G) / (double)total;
+        for (long q : {2048L * G, 256L * G}) {
+            const long c = (total / q) * q;
+            if (c < must || c <= 0 || c == total) continue;
+            const double v = levelCostMs((c + G - 1) / G) / (double)c;
+            if (v < best) best = v, cut = c;
+        }
+        if (cut == total) return;
+        std::vector<int> take;
+        long acc = 0;
+        for (int id : frontier) {   // most urgent first
+            const int r = static_cast<TaskHIPGate&>(net.node(id)).rotations();
+            if (r == 0 || net.node(id).priority >= crit || acc + r <= cut) {
+                take.push_back(id);
+                acc += r;
+            }
+            else {
+                readyQueue_.push(id);
+            }
+        }
+        frontier.swap(take);
+    }
 
 public:
     HIPWorker(ReadyQueue<HIPWorkerInfo>& q, size_t& numFinished, HIPArena* arena) : Worker(q, numFinished)
@@ -472,6 +532,7 @@ public:
         if (inflight_.empty() && !readyQueue_.empty()) {
             std::vector<int> frontier;
             while (!readyQueue_.empty()) frontier.push_back(readyQueue_.pop());
+            deferSlack(net, frontier, G);
             // 2-rotation gates first so that the rotation counts of the GPUs differ by at most one gate
             std::stable_sort(frontier.begin(), frontier.end(), [&](int a, int b) {
                 return static_cast<TaskHIPGate&>(net.node(a)).rotations() > static_cast<TaskHIPGate&>(net.node(b)).rotations();
