@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--net", default="mux-ram", choices=sorted(NETS))
     ap.add_argument("--clocks", type=int, default=2)
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--plan", default="balanced", choices=["balanced", "asap"],
+                    help="level plan: gates with slack placed where a level's step-shaped cost is lowest (frontier.plan_levels, "
+                         "the default) or every gate at its earliest level")
     ap.add_argument("--spawn", action="store_true", help="go through torch.distributed.run even for one GPU (RCCL with one rank)")
     args = ap.parse_args()
     import bench
@@ -40,7 +43,7 @@ def main():
 
     from iyokan_amd import client, hip
     from iyokan_amd import netlist as N
-    from iyokan_amd.frontier import FrontierExecutor, FrontierPlan, HipBackend
+    from iyokan_amd.frontier import FrontierExecutor, FrontierPlan, HipBackend, level_rotations, mi355x_level_cost
     from iyokan_amd.params import params_128bit
     from netlist_util import gold, drive_cycle, input_streams, load_packet
 
@@ -66,7 +69,7 @@ def main():
     if distributed:
         keys = bench.broadcast_keys(keys, dist, dev, rank)   # rank 0's key material, once, over RCCL
     hip.initialize(keys, device_ids=(local,))
-    plan = FrontierPlan(nl, world)
+    plan = FrontierPlan(nl, world, balance=args.plan == "balanced")
     be = HipBackend(plan.num_slots, p, dev)
     ex = FrontierExecutor(plan, be, rank, world, dist if world > 1 else None)
     if distributed and world == 1:
@@ -115,7 +118,8 @@ def main():
         best = min(times[1:])
         print(json.dumps({"net": args.net, "n_gpus": world, "rccl_world_size": dist.get_world_size() if distributed else None, "levels": len(plan.levels), "rotations_per_clock": rot,
                           "s_per_clock": best, "rotations_per_s": rot / best, "collectives_per_clock": len(plan.levels) if world > 1 else 0,
-                          "outputs_match_plaintext": ok, "ntt_path": hip.ntt_path()}))
+                          "outputs_match_plaintext": ok, "ntt_path": hip.ntt_path(), "plan": args.plan,
+                          "model_s_per_clock": sum(mi355x_level_cost(r) for r in level_rotations(nl, [L["boot"] for L in plan.levels], world)) / 1e3}))
     be.close()
     hip.cleanup()
     if distributed:
