@@ -6,7 +6,8 @@ tail -3 gpurun_out/${T}_gputests.txt
 bash tools/profile_round.sh ${T} > gpurun_out/${T}_profile_round.log 2>&1
 PARAMS=80bit bash tools/profile_round.sh ${T}_80bit > gpurun_out/${T}_80bit_profile_round.log 2>&1
 PARAMS=80bit DECOMP=direct bash tools/profile_round.sh ${T}_80bit_direct > gpurun_out/${T}_80bit_direct_profile_round.log 2>&1
-for net in cahp-ruby cahp-system mux-ram; do timeout 600 python tools/bench_netlist.py --net $net 2>/dev/null | tail -1; done > gpurun_out/${T}_bench_netlist.txt
+for net in cahp-ruby cahp-system mux-ram; do timeout 600 python tools/bench_netlist.py --net $net --plan asap 2>/dev/null | tail -1; done > gpurun_out/${T}_bench_netlist.txt
+for net in cahp-ruby cahp-system mux-ram; do timeout 600 python tools/bench_netlist.py --net $net 2>/dev/null | tail -1; done > gpurun_out/${T}_bench_netlist_balanced.txt
 cat gpurun_out/${T}_bench_netlist.txt | cut -c1-200
 python -c "
 import json
