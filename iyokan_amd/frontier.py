@@ -25,20 +25,30 @@ from .netlist import BINARY
 from .params import OPS
 
 
-def mi355x_level_cost(rotations):
-    """Milliseconds one rank spends on a level of `rotations` blind rotations, as the dispatch of csrc/iyokan_hip.hip
-    prices it on an MI355X (profiles/r03_sweep_lat3.txt, r03_kernel_trace.txt): full rounds of 2048 on the wave-per-rotation
-    kernel at 19.7 ms; a remainder of up to 1280 on the workgroup-per-rotation kernel, 256 (one per CU) at a time; a larger
-    remainder is one more full round.  Only the SHAPE matters to the planner (where the steps are), not the milliseconds."""
-    if rotations <= 0:
-        return 0.0
-    full, rem = divmod(rotations, 2048)
-    t = 19.7 * full
-    if rem == 0:
-        return t
-    if rem <= 1280:
-        return t + (3.33, 6.96, 10.23, 13.52, 16.79)[-(-rem // 256) - 1]
-    return t + 19.7
+def make_level_cost(rotation_round=2048):
+    """Milliseconds one rank spends on a level of r blind rotations, as the dispatch of csrc/iyokan_hip.hip prices it
+    (profiles/r03_sweep_lat3.txt, r03_kernel_trace.txt): full rounds of `rotation_round` (iyk_hip_rotation_round: 8 waves on
+    each CU, 2048 on an MI355X) on the wave-per-rotation kernel at 19.7 ms; a remainder of up to five passes of the
+    workgroup-per-rotation kernel, one rotation per CU and pass; a larger remainder is one more full round.  Only the SHAPE
+    matters to the planner (where the steps are), not the milliseconds."""
+    cus = rotation_round // 8
+
+    def cost(rotations):
+        if rotations <= 0:
+            return 0.0
+        full, rem = divmod(rotations, rotation_round)
+        t = 19.7 * full
+        if rem == 0:
+            return t
+        if rem <= 5 * cus:
+            return t + (3.33, 6.96, 10.23, 13.52, 16.79)[-(-rem // cus) - 1]
+        return t + 19.7
+
+    cost.quanta = (rotation_round, cus)
+    return cost
+
+
+mi355x_level_cost = make_level_cost(2048)
 
 
 def level_rotations(nl, levels, world=1):
@@ -50,7 +60,8 @@ def plan_levels(nl, world=1, cost=mi355x_level_cost):
     """The cheapest, by `cost`, of levelise() and balanced_levels() at three cut granularities — the greedy is not
     monotone (a deferral can push a later level over a step), so the plain ASAP levels stay a candidate."""
     best, best_t = None, None
-    for quanta in (None, (2048, 256), (256,), (2048,)):
+    big, small = getattr(cost, "quanta", (2048, 256))
+    for quanta in (None, (big, small), (small,), (big,)):
         lv = nl.levelise() if quanta is None else balanced_levels(nl, world, cost, quanta)
         t = sum(cost(r) for r in level_rotations(nl, lv, world))
         if best is None or t < best_t - 1e-9:
