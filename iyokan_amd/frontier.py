@@ -57,16 +57,98 @@ def level_rotations(nl, levels, world=1):
 
 
 def plan_levels(nl, world=1, cost=mi355x_level_cost):
-    """The cheapest, by `cost`, of levelise() and balanced_levels() at three cut granularities — the greedy is not
-    monotone (a deferral can push a later level over a step), so the plain ASAP levels stay a candidate."""
+    """The cheapest, by `cost`, of levelise(), balanced_levels() at three cut granularities and beam_levels() — the greedy
+    is not monotone (a deferral can push a later level over a step), so the plain ASAP levels stay a candidate."""
     best, best_t = None, None
     big, small = getattr(cost, "quanta", (2048, 256))
-    for quanta in (None, (big, small), (small,), (big,)):
-        lv = nl.levelise() if quanta is None else balanced_levels(nl, world, cost, quanta)
+    for quanta in (None, (big, small), (small,), (big,), "beam"):
+        lv = nl.levelise() if quanta is None else beam_levels(nl, world, cost) if quanta == "beam" else balanced_levels(nl, world, cost, quanta)
         t = sum(cost(r) for r in level_rotations(nl, lv, world))
         if best is None or t < best_t - 1e-9:
             best, best_t = lv, t
     return best
+
+
+def _slack_graph(nl):
+    """(depth, order, succ, npred, alap, rot) of the per-clock DAG: nodes in levelise() order, successor lists and input
+    counts restricted to nodes that have a level (sources are ready from the start; OUTPUT wires stand for their driver),
+    latest level that does not stretch the critical path, rotations per node."""
+    asap = nl.levelise()
+    depth = len(asap)
+    n = nl.num_nodes
+    level = [0] * n
+    for k, lv in enumerate(asap):
+        for i in lv:
+            level[i] = k + 1
+    order = [i for lv in asap for i in lv]
+    succ = [[] for _ in range(n)]
+    npred = [0] * n
+    root = nl.roots()
+    for i in order:
+        for j in nl.ins[i]:
+            j = root[j] if nl.kinds[j] == "OUTPUT" else j
+            if level[j] > 0:
+                succ[j].append(i)
+                npred[i] += 1
+    alap = [depth] * n
+    for i in reversed(order):
+        for s2 in succ[i]:
+            alap[i] = min(alap[i], alap[s2] - 1)
+    rot = [2 if nl.kinds[i] == "MUX" else 1 if nl.kinds[i] in BINARY else 0 for i in range(n)]
+    return depth, order, succ, npred, alap, rot
+
+
+def beam_levels(nl, world=1, cost=mi355x_level_cost, width=6):
+    """balanced_levels with the greedy's one choice per level — where to cut the ready set — searched instead: at every
+    level each kept partial schedule is continued with every cut (all ready gates; the largest multiples of a round / a
+    pass per rank, and one step below each, that still hold the critical gates), and the `width` cheapest by
+    (milliseconds so far + the gates not yet run at the throughput kernel's rate) survive.  Deterministic; the greedy's own
+    schedule is one of the paths, a wider beam only adds others."""
+    depth, order, succ, npred0, alap, rot = _slack_graph(nl)
+    big, small = getattr(cost, "quanta", (2048, 256))
+    rate = cost(big) / big
+    total_rot = sum(rot)
+    # a partial schedule: (ms so far, rotations done, npred, ready, levels so far)
+    beam = [(0.0, 0, list(npred0), [i for i in order if npred0[i] == 0], [])]
+    for k in range(1, depth + 1):
+        grown = []
+        for ms, done, npred, ready, levels in beam:
+            free, boots = [], []
+            for i in ready:
+                (free if rot[i] == 0 else boots).append(i)
+            boots.sort(key=lambda i: (alap[i], i))
+            total = sum(rot[i] for i in boots)
+            must = sum(rot[i] for i in boots if alap[i] <= k)
+            cuts = {total}
+            if total and k < depth:
+                for q in (big * world, small * world):
+                    for c in ((total // q) * q, (total // q) * q - q):
+                        if c >= must and c > 0:
+                            cuts.add(c)
+            for cut in sorted(cuts):
+                np2 = list(npred)
+                nxt, take, acc = [], [], 0
+                for i in free:
+                    for s2 in succ[i]:
+                        np2[s2] -= 1
+                        if np2[s2] == 0:
+                            nxt.append(s2)
+                for i in boots:
+                    if alap[i] <= k or acc + rot[i] <= cut:
+                        take.append(i)
+                        acc += rot[i]
+                        for s2 in succ[i]:
+                            np2[s2] -= 1
+                            if np2[s2] == 0:
+                                nxt.append(s2)
+                    else:
+                        nxt.append(i)
+                grown.append((ms + cost(-(-acc // world)), done + acc, np2, nxt, levels + [free + take]))
+        grown.sort(key=lambda st: (st[0] + (total_rot - st[1]) * rate / world, -st[1]))
+        beam = grown[:width]
+    best = min(beam, key=lambda st: st[0])
+    assert not best[3] and sum(len(lv) for lv in best[4]) == len(order)
+    return best[4]
 
 
 def balanced_levels(nl, world=1, cost=mi355x_level_cost, quanta=(2048, 256)):

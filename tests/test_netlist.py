@@ -147,7 +147,7 @@ def test_balanced_levels_are_a_valid_cheaper_schedule(name, kind, world):
     else:
         nl = (N.load_iyokanl1_json if kind == "l1" else N.load_yosys_json)(gold(name))
     asap = nl.levelise()
-    for levels in (F.balanced_levels(nl, world), F.balanced_levels(nl, world, quanta=(256,)), F.plan_levels(nl, world)):
+    for levels in (F.balanced_levels(nl, world), F.balanced_levels(nl, world, quanta=(256,)), F.beam_levels(nl, world), F.plan_levels(nl, world)):
         assert len(levels) == len(asap)
         where = {}
         for k, lv in enumerate(levels):
@@ -162,16 +162,16 @@ def test_balanced_levels_are_a_valid_cheaper_schedule(name, kind, world):
                 if nl.kinds[j] not in ("INPUT", "DFF"):
                     assert where[j] < k, (i, j)
     cost = lambda lv: sum(F.mi355x_level_cost(r) for r in F.level_rotations(nl, lv, world))
-    assert cost(F.plan_levels(nl, world)) <= cost(asap) + 1e-9
+    assert cost(F.plan_levels(nl, world)) <= min(cost(asap), cost(F.balanced_levels(nl, world))) + 1e-9
 
 
 def test_balanced_plan_gains_on_the_benchmark_netlists():
     """What the planner is for (model milliseconds per clock on one GPU, profiles/r03_bench_netlist*.txt has the measured
-    ones): config #4's system and config #3's RAM lose a tenth of their clock."""
+    ones): config #4's system, config #3's RAM and the CAHP core lose an eighth of their clock."""
     from iyokan_amd import frontier as F
     from iyokan_amd.system import load_blueprint
 
-    for nl, least in ((load_blueprint(gold("cahp-ruby-mux.toml")).nl, 0.08), (N.load_iyokanl1_json(gold("mux-ram-8-16-16.min.json")), 0.08),
-                      (N.load_yosys_json(gold("cahp-ruby-core-yosys.json")), 0.08)):
+    for nl, least in ((load_blueprint(gold("cahp-ruby-mux.toml")).nl, 0.12), (N.load_iyokanl1_json(gold("mux-ram-8-16-16.min.json")), 0.12),
+                      (N.load_yosys_json(gold("cahp-ruby-core-yosys.json")), 0.12)):
         cost = lambda lv: sum(F.mi355x_level_cost(r) for r in F.level_rotations(nl, lv, 1))
         assert cost(F.plan_levels(nl, 1)) <= (1 - least) * cost(nl.levelise())
