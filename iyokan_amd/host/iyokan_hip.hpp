@@ -468,9 +468,19 @@ inline double levelCostMs(long rot)
     return t + 19.7;
 }
 
+// Static plan of a clock: the frontier (0, 1, ...) in which every task starts.  Same search as iyokan_amd/frontier.py
+// beam_levels: frontier by frontier, the ready gates sorted by their latest frontier (depth - 1 - upward rank: later would
+// stretch the critical path); those whose latest frontier is now must run; beyond them the frontier is cut at a multiple
+// of a round / a pass per GPU (or one step below), every such cut is tried, and the `width` cheapest partial schedules by
+// (levelCostMs so far + rotations left at the throughput kernel's rate) survive.  Tasks without rotations (wires, NOT,
+// memories) run as soon as they are ready.  The number of frontiers is the DAG's depth, as without a plan.
+inline std::vector<int> planFrontiers(TaskNetwork<HIPWorkerInfo>& net, int G, int width = 6);
+
 class HIPWorker : public Worker<HIPWorkerInfo> {
     std::vector<HIPWorkerInfo> wi_;  // one per GPU
     std::vector<int> inflight_;
+    const std::vector<int>* plan_ = nullptr;  // planFrontiers of the network this worker runs (the runner owns it)
+    int round_ = 0;
 
     // A frontier is priced in steps (levelCostMs), so a gate that has SLACK — its longest path to a sink is shorter than
     // the frontier's longest, the clock's remaining critical path — can wait for a later frontier where it rides for free.
@@ -525,14 +535,27 @@ public:
             wi_[g].gpu = g;
         }
     }
+    void setPlan(const std::vector<int>* plan) { plan_ = plan; }
     void update() override
     {
         auto& net = readyQueue_.net();
         const int G = (int)wi_.size();
         if (inflight_.empty() && !readyQueue_.empty()) {
+            if (numFinishedTargets_ == 0) round_ = 0;  // first frontier of a clock (spinWorkers resets the counter)
             std::vector<int> frontier;
             while (!readyQueue_.empty()) frontier.push_back(readyQueue_.pop());
-            deferSlack(net, frontier, G);
+            if (plan_ && plan_->size() == net.numNodes()) {  // static plan: a task waits for its frontier
+                std::vector<int> now;
+                for (int id : frontier) ((*plan_)[id] <= round_ ? now : inflight_).push_back(id);
+                if (now.empty()) now.swap(inflight_);       // cannot happen with a valid plan; never stall
+                for (int id : inflight_) readyQueue_.push(id);
+                inflight_.clear();
+                frontier.swap(now);
+            }
+            else {
+                deferSlack(net, frontier, G);
+            }
+            ++round_;
             // 2-rotation gates first so that the rotation counts of the GPUs differ by at most one gate
             std::stable_sort(frontier.begin(), frontier.end(), [&](int a, int b) {
                 return static_cast<TaskHIPGate&>(net.node(a)).rotations() > static_cast<TaskHIPGate&>(net.node(b)).rotations();
@@ -592,6 +615,92 @@ protected:
     HIPWorkerInfo& getWorkerInfo() override { return wi_[0]; }
 };
 
+inline std::vector<int> planFrontiers(TaskNetwork<HIPWorkerInfo>& net, int G, int width)
+{
+    const int n = (int)net.numNodes();
+    std::vector<int> rot(n), alap(n), indeg0(n);
+    int depth = 0;
+    for (int i = 0; i < n; ++i) depth = std::max(depth, net.node(i).priority + 1);
+    long totalRot = 0;
+    for (int i = 0; i < n; ++i) {
+        auto& t = static_cast<TaskHIPGate&>(net.node(i));
+        rot[i] = t.rotations();
+        totalRot += rot[i];
+        alap[i] = depth - 1 - t.priority;
+        indeg0[i] = t.kind == GateKind::DFF ? 0 : (int)t.getInputSize();  // a DFF's input belongs to the next clock
+    }
+    struct Partial {
+        double ms = 0;
+        long done = 0;
+        std::vector<int> indeg, ready, round;
+    };
+    const double rate = levelCostMs(2048) / 2048.0;
+    std::vector<Partial> beam(1);
+    beam[0].indeg = indeg0;
+    beam[0].round.assign(n, -1);
+    for (int i = 0; i < n; ++i)
+        if (indeg0[i] == 0) beam[0].ready.push_back(i);
+    auto release = [&](Partial& p, int id, std::vector<int>& into) {
+        for (int d : net.node(id).dependents)
+            if (net.node(d).kind != GateKind::DFF && --p.indeg[d] == 0) into.push_back(d);
+    };
+    for (int k = 0; k < depth; ++k) {
+        std::vector<Partial> grown;
+        for (Partial& p : beam) {
+            std::vector<int> free_, boots;
+            for (int id : p.ready) (rot[id] == 0 ? free_ : boots).push_back(id);
+            std::sort(boots.begin(), boots.end(), [&](int a, int b) { return alap[a] != alap[b] ? alap[a] < alap[b] : a < b; });
+            long total = 0, must = 0;
+            for (int id : boots) {
+                total += rot[id];
+                if (alap[id] <= k) must += rot[id];
+            }
+            std::vector<long> cuts{total};
+            if (total && k + 1 < depth)
+                for (long q : {2048L * G, 256L * G})
+                    for (long c : {(total / q) * q, (total / q) * q - q})
+                        if (c >= must && c > 0 && std::find(cuts.begin(), cuts.end(), c) == cuts.end()) cuts.push_back(c);
+            for (long cut : cuts) {
+                Partial g;
+                g.ms = p.ms;
+                g.done = p.done;
+                g.indeg = p.indeg;
+                g.round = p.round;
+                long acc = 0;
+                for (int id : free_) {
+                    g.round[id] = k;
+                    release(g, id, g.ready);
+                }
+                for (int id : boots) {
+                    if (alap[id] <= k || acc + rot[id] <= cut) {
+                        acc += rot[id];
+                        g.round[id] = k;
+                        release(g, id, g.ready);
+                    }
+                    else {
+                        g.ready.push_back(id);
+                    }
+                }
+                g.ms += levelCostMs((acc + G - 1) / G);
+                g.done += acc;
+                grown.push_back(std::move(g));
+            }
+        }
+        std::sort(grown.begin(), grown.end(), [&](const Partial& a, const Partial& b) {
+            const double sa = a.ms + (double)(totalRot - a.done) * rate / G, sb = b.ms + (double)(totalRot - b.done) * rate / G;
+            return sa != sb ? sa < sb : a.done > b.done;
+        });
+        if ((int)grown.size() > width) grown.resize(width);
+        beam.swap(grown);
+    }
+    const Partial* best = &beam[0];
+    for (const Partial& p : beam)
+        if (p.ms < best->ms) best = &p;
+    for (int i = 0; i < n; ++i)
+        if (best->round[i] < 0) return {};  // not a complete schedule (a cycle the engine will report): run unplanned
+    return best->round;
+}
+
 // numWorkers is accepted for signature parity with the reference and ignored: ONE batching worker drives every GPU
 inline void processAllGates(HIPNetwork& net, HIPFactory& f, int numWorkers = 1)
 {
@@ -609,6 +718,7 @@ class HIPNetworkRunner {
     ReadyQueue<HIPWorkerInfo> queue_;
     size_t numFinished_ = 0;
     std::vector<std::unique_ptr<HIPWorker>> workers_;
+    std::vector<int> plan_;  // planFrontiers(net_): the frontier every task starts in
 
 public:
     HIPNetworkRunner(HIPNetwork& net, HIPFactory& f) : net_(net), f_(f)
@@ -622,6 +732,11 @@ public:
             latchOut_.push_back(d.slot);
         });
         workers_.emplace_back(new HIPWorker(queue_, numFinished_, &f.arena));
+        const char* e = std::getenv("IYK_HOST_FRONTIER");  // asap / greedy: A/B knobs (default: the static plan)
+        if (!e || (std::string(e) != "asap" && std::string(e) != "greedy")) {
+            plan_ = planFrontiers(net_, f.arena.numGPUs());
+            workers_.back()->setPlan(&plan_);
+        }
     }
     void run(int numWorkers = 1)
     {
