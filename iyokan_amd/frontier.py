@@ -236,11 +236,12 @@ def balanced_levels(nl, world=1, cost=mi355x_level_cost, quanta=(2048, 256)):
 
 class FrontierPlan:
     """Slot assignment + per-level, per-rank gate descriptor arrays.  `balance` (default): gates with slack are placed in
-    the level where the kernels' step-shaped cost is lowest (plan_levels); False: every gate at its earliest level."""
+    the level where the kernels' step-shaped cost is lowest (plan_levels; `cost` = make_level_cost(hip.rotation_round()) on
+    a GPU other than the 256-CU MI355X the default describes); False: every gate at its earliest level."""
 
-    def __init__(self, nl, world=1, balance=True):
+    def __init__(self, nl, world=1, balance=True, cost=mi355x_level_cost):
         self.nl, self.world = nl, world
-        levels = plan_levels(nl, world) if balance else nl.levelise()
+        levels = plan_levels(nl, world, cost) if balance else nl.levelise()
         n = nl.num_nodes
         slot = [-1] * n
         nslots = 0

@@ -43,7 +43,7 @@ def main():
 
     from iyokan_amd import client, hip
     from iyokan_amd import netlist as N
-    from iyokan_amd.frontier import FrontierExecutor, FrontierPlan, HipBackend, level_rotations, mi355x_level_cost
+    from iyokan_amd.frontier import FrontierExecutor, FrontierPlan, HipBackend, level_rotations, make_level_cost
     from iyokan_amd.params import params_128bit
     from netlist_util import gold, drive_cycle, input_streams, load_packet
 
@@ -69,7 +69,8 @@ def main():
     if distributed:
         keys = bench.broadcast_keys(keys, dist, dev, rank)   # rank 0's key material, once, over RCCL
     hip.initialize(keys, device_ids=(local,))
-    plan = FrontierPlan(nl, world, balance=args.plan == "balanced")
+    level_cost = make_level_cost(hip.rotation_round())   # rounds of 8 waves per CU of THIS device
+    plan = FrontierPlan(nl, world, balance=args.plan == "balanced", cost=level_cost)
     be = HipBackend(plan.num_slots, p, dev)
     ex = FrontierExecutor(plan, be, rank, world, dist if world > 1 else None)
     if distributed and world == 1:
@@ -119,7 +120,7 @@ def main():
         print(json.dumps({"net": args.net, "n_gpus": world, "rccl_world_size": dist.get_world_size() if distributed else None, "levels": len(plan.levels), "rotations_per_clock": rot,
                           "s_per_clock": best, "rotations_per_s": rot / best, "collectives_per_clock": len(plan.levels) if world > 1 else 0,
                           "outputs_match_plaintext": ok, "ntt_path": hip.ntt_path(), "plan": args.plan,
-                          "model_s_per_clock": sum(mi355x_level_cost(r) for r in level_rotations(nl, [L["boot"] for L in plan.levels], world)) / 1e3}))
+                          "model_s_per_clock": sum(level_cost(r) for r in level_rotations(nl, [L["boot"] for L in plan.levels], world)) / 1e3}))
     be.close()
     hip.cleanup()
     if distributed:
