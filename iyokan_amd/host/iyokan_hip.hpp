@@ -457,14 +457,20 @@ using HIPNetwork = TaskNetwork<HIPWorkerInfo>;
 // rounds of 2048 on the wave-per-rotation kernel, a remainder of up to 1280 in passes of 256 on the
 // workgroup-per-rotation kernel, a larger one in one more round (profiles/r03_sweep_lat3.txt; only the position of the
 // steps matters).  Same function as iyokan_amd/frontier.py: mi355x_level_cost.
+inline long rotationRound()  // 8 waves on every CU of GPU 0 (2048 on an MI355X); 2048 before the library is initialised
+{
+    static const long r = [] { const int v = iyk_hip_rotation_round(0); return v > 0 ? (long)v : 2048L; }();
+    return r;
+}
 inline double levelCostMs(long rot)
 {
     if (rot <= 0) return 0.0;
     static const double pass[5] = {3.33, 6.96, 10.23, 13.52, 16.79};
-    const long full = rot / 2048, rem = rot % 2048;
+    const long round = rotationRound(), cus = round / 8;
+    const long full = rot / round, rem = rot % round;
     double t = 19.7 * (double)full;
     if (rem == 0) return t;
-    if (rem <= 1280) return t + pass[(rem + 255) / 256 - 1];
+    if (rem <= 5 * cus) return t + pass[(rem + cus - 1) / cus - 1];
     return t + 19.7;
 }
 
@@ -503,7 +509,7 @@ class HIPWorker : public Worker<HIPWorkerInfo> {
         if (total == 0 || crit == 0) return;
         long cut = total;
         double best = levelCostMs((total + G - 1) / G) / (double)total;
-        for (long q : {2048L * G, 256L * G}) {
+        for (long q : {rotationRound() * G, rotationRound() / 8 * G}) {
             const long c = (total / q) * q;
             if (c < must || c <= 0 || c == total) continue;
             const double v = levelCostMs((c + G - 1) / G) / (double)c;
@@ -634,7 +640,7 @@ inline std::vector<int> planFrontiers(TaskNetwork<HIPWorkerInfo>& net, int G, in
         long done = 0;
         std::vector<int> indeg, ready, round;
     };
-    const double rate = levelCostMs(2048) / 2048.0;
+    const double rate = levelCostMs(rotationRound()) / (double)rotationRound();
     std::vector<Partial> beam(1);
     beam[0].indeg = indeg0;
     beam[0].round.assign(n, -1);
@@ -657,7 +663,7 @@ inline std::vector<int> planFrontiers(TaskNetwork<HIPWorkerInfo>& net, int G, in
             }
             std::vector<long> cuts{total};
             if (total && k + 1 < depth)
-                for (long q : {2048L * G, 256L * G})
+                for (long q : {rotationRound() * G, rotationRound() / 8 * G})
                     for (long c : {(total / q) * q, (total / q) * q - q})
                         if (c >= must && c > 0 && std::find(cuts.begin(), cuts.end(), c) == cuts.end()) cuts.push_back(c);
             for (long cut : cuts) {
