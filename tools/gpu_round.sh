@@ -1,4 +1,6 @@
 #!/bin/bash
+# One GPU call at round end (through gpurun): the whole GPU test suite, the three profile rounds (128-bit, 80-bit, 80-bit direct),
+# the netlist benches with both level plans, and the bench lines with the counters just measured.  bash tools/gpu_round.sh <tag>
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
 T=${1:-r03}
 timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/${T}_gputests.txt 2>&1
