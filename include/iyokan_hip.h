@@ -249,6 +249,15 @@ int iyk_hip_timing_log_end(iyk_hip_stream* st, uint64_t* batches, double* blind_
  * wave; the default where instantiated); both subtract the same rows mod 2^32, so they agree word for word. */
 int iyk_hip_ntt_path(void);
 
+/* Round 4: return value 2 = the default since — the wave-per-rotation kernel multiplies through a 512-point COMPLEX FP64
+ * FFT with every key word split into two signed 16-bit halves (csrc/fft512.hpp): every inverse-transform output is
+ * provably within 2^-10 of the exact integer sum, so rint() makes the product the exact schoolbook
+ * one — the same ciphertext words as paths 1 and 0 — at about half the instructions per CMUX step.  The narrow-frontier
+ * kernel stays on path 1's field, so both key forms are resident (iyk_hip_resident_key_bytes).  IYK_HIP_NTT = fft / fp /
+ * goldilocks at iyk_hip_init selects 2 / 1 / 0; IYK_HIP_ROT_KERNEL = fft forces a batch onto the FFT kernel.
+ * With IYK_HIP_DEBUG=1 at init the FFT kernel also records the largest |z - rint(z)| it produced: */
+int iyk_hip_fft_round_error(int gpu_index, double* out);
+
 /* Digit polynomials per accumulator polynomial and CMUX step.  l on the integer path and for the 128-bit set; 2 l = 4 for
  * the 80-bit set on the FP64 path, whose 10-bit digits are split into 5-bit halves so that every integer sum stays below
  * p/2 UNCONDITIONALLY (the default).  IYK_HIP_DECOMP=direct at iyk_hip_init (80-bit set only, opt-in) uses the digits as

@@ -1,0 +1,167 @@
+// blind_rotate_fft.hpp — per-lane phases of one CMUX step on the complex-FFT path (fft512.hpp).
+//
+// One 64-lane wavefront owns one rotation and works on ONE polynomial at a time with 8 complex points per lane.
+// Arrangement A (fft512.hpp): lane L holds the folded coefficients j = L + 64 m, m < 8: real part p[j], imaginary part
+// p[j + 512] — sixteen torus words per lane and accumulator polynomial, indexed q = m (real) and q = 8 + m (imaginary),
+// i.e. coefficient L + 64 q for q < 16.
+//
+// Per step:  for c in {a, b}:  td = (X^abar - 1) acc_c at the lane's 16 coefficients (once per polynomial);
+//                              for each gadget level: digits -> forward transform -> arrangement F ->
+//                              S[c'][half] += D * K[row][c'][half]        (c' in {a, b}, half in {lo, hi}: 4 spectra,
+//                                                                           8 complex each, in registers)
+//            for c' in {a, b}: inverse of S[c'][lo] -> rint -> 16 words; inverse of S[c'][hi] -> rint -> << 16, added;
+//                              acc_c' += (ds_add_u32).
+// Key spectrum: cplx [n][(k+1) l][k+1][2][512], position k2 * 64 + lane'' within a polynomial (fft::freq_pos), scaled by
+// 1/512 — 16 bytes per lane and load, a wave's load is 1 KiB contiguous.
+//
+// Replaces, like blind_rotate_fp.hpp, TFHEpp's CMUXFFTwithPolynomialMulByXaiMinusOne behind
+// /root/reference/src/iyokan_tfhepp.hpp:131-141 (TFHEpp's own product is an FP64 FFT too — an inexact one; this one is
+// exact) and cufhe's NTT-domain external product behind /root/reference/src/iyokan_cufhe.hpp:249-258.
+#pragma once
+#include "blind_rotate_core.hpp"
+#include "fft512.hpp"
+
+namespace iyk {
+namespace fft {
+
+// Gadget decomposition for the FFT path: the L digits of BGBIT bits as they are (no splitting: magnitudes, not a field,
+// bound this path).  u = td + offset + round is formed once per coefficient with the sign bits of all levels flipped, so
+// that a level's signed digit is ONE sign-extending bit-field extract.
+template <int L_, int BGBIT_>
+struct Gadget {
+    static constexpr int L = L_, BGBIT = BGBIT_;
+    static constexpr u32 flip()
+    {
+        u32 f = 0;
+        for (int j = 1; j <= L_; ++j) f |= (1u << (BGBIT_ - 1)) << (32 - j * BGBIT_);
+        return f;
+    }
+    IYK_HD static u32 prepare(u32 td) { return (td + BrConsts<L_, BGBIT_>::offset_plus_round()) ^ flip(); }
+    IYK_HD static i32 digit(u32 u, int lvl)
+    {
+        const u32 sh = 32u - (u32)(lvl + 1) * BGBIT_;
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __builtin_amdgcn_sbfe((i32)u, sh, (u32)BGBIT_);
+#else
+        return (i32)(u << (32u - sh - BGBIT_)) >> (32 - BGBIT_);
+#endif
+    }
+    static constexpr double max_digit() { return (double)(1 << (BGBIT_ - 1)); }
+};
+
+// u[q] = prepare(((X^abar - 1) acc_c)[L + 64 q]), q < 16.  PRECONDITION: acc_c is 4 KB aligned in LDS (device path: the
+// wrapped byte address is one v_and_or, as in fp::fwd1_diff).
+template <class G>
+IYK_HD void diff16(int L, u32 abar, const u32* acc_c, u32 (&u)[16])
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(3))) u32* lds_u32;
+    const u32 acc_base = (u32)(size_t)(lds_u32)acc_c;
+    const u32 base4 = ((u32)L - abar) << 2;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const u32 idx4 = base4 + 256u * (u32)q;
+        const u32 neg = (u32)((i32)(idx4 << 19) >> 31);       // bit 12 of 4 idx = bit 10 of idx
+        const u32 a = *(lds_u32)(size_t)((idx4 & 0xFFCu) | acc_base);
+        u[q] = G::prepare((a ^ neg) + ((0u - acc_c[L + 64 * q]) - neg));
+    }
+#else
+    const u32 base = (u32)L - abar;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const u32 idx = base + 64u * (u32)q;
+        const u32 neg = 0u - ((idx >> 10) & 1u);
+        const u32 a = (acc_c[idx & (NTT_N - 1)] ^ neg) - neg;
+        u[q] = G::prepare(a - acc_c[L + 64 * q]);
+    }
+#endif
+}
+
+template <class G>
+IYK_HD void digits8(int lvl, const u32 (&u)[16], cplx (&a)[8])
+{
+#pragma unroll
+    for (int m = 0; m < 8; ++m) a[m] = {(double)G::digit(u[m], lvl), (double)G::digit(u[8 + m], lvl)};
+}
+
+// S += D * K (FIRST: S = D * K), 4 FMAs
+template <bool FIRST>
+IYK_HD void cmac(cplx& s, cplx d, cplx k)
+{
+    if (FIRST) {
+        s.re = fma_(-d.im, k.im, d.re * k.re);
+        s.im = fma_(d.im, k.re, d.re * k.im);
+    }
+    else {
+        s.re = fma_(-d.im, k.im, fma_(d.re, k.re, s.re));
+        s.im = fma_(d.im, k.re, fma_(d.re, k.im, s.im));
+    }
+}
+
+// Key spectra of one (step, row): four polynomials (c', half) of 512 cplx each, at cplx offset row_off (wave-uniform).
+// Device: buffer loads — one resource descriptor, the row's byte offset in an SGPR, the lane's 16 bytes in one VGPR, the
+// frequency block q * 1024 (+ polynomial * 8192 through the scalar offset) in the instruction: no vector address math.
+struct Keys {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __amdgpu_buffer_rsrc_t rsrc;
+    u32 lane_off;
+    IYK_HD Keys(const cplx* bk_fft, u32 bytes, int lane)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<cplx*>(bk_fft), (short)0, (int)bytes, 0x00020000)),
+          lane_off((u32)lane * 16u)
+    {
+    }
+    // poly in [0, 4) = 2 c' + half, q < 8 compile-time constants; row_off in cplx
+    IYK_HD cplx at(u32 row_off, int poly, int q) const
+    {
+        typedef u32 v4u __attribute__((ext_vector_type(4)));
+        const u32 soff = (row_off + (u32)poly * 512u) * 16u + (q >= 4 ? 4096u : 0u);
+        const v4u w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off + (u32)(q & 3) * 1024u, soff, 0);
+        cplx r;
+        u64 lo = ((u64)w[1] << 32) | w[0], hi = ((u64)w[3] << 32) | w[2];
+        __builtin_memcpy(&r.re, &lo, 8);
+        __builtin_memcpy(&r.im, &hi, 8);
+        return r;
+    }
+#else
+    const cplx* base;
+    u32 lane;
+    IYK_HD Keys(const cplx* bk_fft, u32, int lane_) : base(bk_fft), lane((u32)lane_) {}
+    IYK_HD cplx at(u32 row_off, int poly, int q) const { return base[(size_t)row_off + (size_t)poly * 512 + (size_t)q * 64 + lane]; }
+#endif
+};
+
+// words of the rounded inverse: lo half kept, hi half shifted and added, then acc_c[L + 64 q] += word
+IYK_HD void round16(const cplx (&a)[8], u32 (&w)[16])
+{
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        w[m] = round_u32(a[m].re);
+        w[8 + m] = round_u32(a[m].im);
+    }
+}
+IYK_HD void acc_update16(int L, const cplx (&hi)[8], const u32 (&lo)[16], u32* acc_c)
+{
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const u32 v = lo[q] + (round_u32(q < 8 ? hi[q].re : hi[q - 8].im) << 16);
+#if defined(__HIP_DEVICE_COMPILE__)
+        __hip_atomic_fetch_add(acc_c + L + 64 * q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#else
+        acc_c[L + 64 * q] += v;
+#endif
+    }
+}
+IYK_HD double round_err8(const cplx (&a)[8])
+{
+    double e = 0.0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const double e0 = round_err(a[m].re), e1 = round_err(a[m].im);
+        e = e0 > e ? e0 : e;
+        e = e1 > e ? e1 : e;
+    }
+    return e;
+}
+
+}  // namespace fft
+}  // namespace iyk

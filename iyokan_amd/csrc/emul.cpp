@@ -12,6 +12,7 @@
 #include "blind_rotate_fp.hpp"
 #include "blind_rotate_lat3.hpp"
 #include "blind_rotate_t16.hpp"
+#include "blind_rotate_fft.hpp"
 
 using namespace iyk;
 
@@ -643,6 +644,94 @@ void blind_rotate_fp_t16(const iyk_params* p, const u32* lin, const double* bk_n
     for (u32 j = 1; j < (u32)NTT_N; ++j) tlwe1[j] = 0u - acc[NTT_N - j];
     tlwe1[NTT_N] = acc[NTT_N];
 }
+
+// ---- complex-FFT path (fft512.hpp, blind_rotate_fft.hpp): lane-by-lane run of kernels_fft.hpp -------------------------
+#define ALL_LANES for (int lane = 0; lane < 64; ++lane)
+const fft::Consts& fft_consts()
+{
+    static fft::Consts* C = [] {
+        auto* c = new fft::Consts();
+        fft::make_consts(*c);
+        return c;
+    }();
+    return *C;
+}
+double g_fft_worst = 0.0;
+
+// kernels_fft.hpp::fft_forward / fft_inverse with one loop over the lanes per hand-off
+void fft_forward_wave(fft::cplx (*a)[8], fft::cplx* xb)
+{
+    const fft::Consts& C = fft_consts();
+    ALL_LANES fft::fwd_p1(a[lane], C.u, &C.t1[0][lane]);
+    ALL_LANES fft::x1_put_a(lane, a[lane], xb);
+    ALL_LANES fft::x1_get_b(lane, a[lane], xb);
+    ALL_LANES fft::fwd_p2(a[lane], &C.t2t[0][lane & 7]);
+    ALL_LANES fft::x2_put_b(lane, a[lane], xb);
+    ALL_LANES fft::x2_get_c(lane, a[lane], xb);
+    ALL_LANES fft::fwd_p3(a[lane]);
+}
+void fft_inverse_wave(fft::cplx (*a)[8], fft::cplx* xb)
+{
+    const fft::Consts& C = fft_consts();
+    ALL_LANES fft::inv_p1(a[lane], &C.t2t[0][lane & 7]);
+    ALL_LANES fft::x2_put_c(lane, a[lane], xb);
+    ALL_LANES fft::x2_get_b(lane, a[lane], xb);
+    ALL_LANES fft::inv_p2(a[lane]);
+    ALL_LANES fft::x1_put_b(lane, a[lane], xb);
+    ALL_LANES fft::x1_get_a(lane, a[lane], xb);
+    ALL_LANES fft::inv_p3(a[lane], C.u, &C.t1[0][lane]);
+}
+
+template <class G>
+void blind_rotate_fft(const iyk_params* p, const u32* lin, const fft::cplx* bk_fft, u32* tlwe1)
+{
+    constexpr int L = G::L;
+    std::vector<u32> acc(2 * NTT_N);
+    std::vector<fft::cplx> xbuf(fft::XCHG_BYTES / sizeof(fft::cplx));
+    fft::cplx* xb = xbuf.data();
+    const u32 bbar = br_modswitch_b(lin[p->n]);
+    ALL_LANES br_init_acc(lane >> 5, lane & 31, bbar, p->mu, acc.data() + (lane >> 5) * NTT_N);
+    static thread_local fft::cplx S[2][2][64][8], a[64][8];
+    static thread_local u32 u[64][16], lo[64][16];
+    for (u32 i = 0; i < p->n; ++i) {
+        const u32 ab = br_modswitch_a(lin[i]);
+        for (int r = 0; r < 2 * L; ++r) {
+            const int c = r >= L ? 1 : 0, lvl = r - c * L;
+            if (lvl == 0) ALL_LANES fft::diff16<G>(lane, ab, acc.data() + c * NTT_N, u[lane]);
+            ALL_LANES fft::digits8<G>(lvl, u[lane], a[lane]);
+            fft_forward_wave(a, xb);
+            const u32 row_off = (i * (u32)(2 * L) + (u32)r) * 4u * (u32)fft::M;
+            ALL_LANES
+            {
+                const fft::Keys keys(bk_fft, 0, lane);
+                for (int q = 0; q < 8; ++q)
+                    for (int pc = 0; pc < 4; ++pc) {
+                        if (r == 0) fft::cmac<true>(S[pc >> 1][pc & 1][lane][q], a[lane][q], keys.at(row_off, pc, q));
+                        else fft::cmac<false>(S[pc >> 1][pc & 1][lane][q], a[lane][q], keys.at(row_off, pc, q));
+                    }
+            }
+        }
+        for (int cc = 0; cc < 2; ++cc) {
+            fft_inverse_wave(S[cc][0], xb);
+            ALL_LANES
+            {
+                const double e = fft::round_err8(S[cc][0][lane]);
+                if (e > g_fft_worst) g_fft_worst = e;
+                fft::round16(S[cc][0][lane], lo[lane]);
+            }
+            fft_inverse_wave(S[cc][1], xb);
+            ALL_LANES
+            {
+                const double e = fft::round_err8(S[cc][1][lane]);
+                if (e > g_fft_worst) g_fft_worst = e;
+            }
+            ALL_LANES fft::acc_update16(lane, S[cc][1][lane], lo[lane], acc.data() + cc * NTT_N);
+        }
+    }
+    tlwe1[0] = acc[0];
+    for (u32 j = 1; j < (u32)NTT_N; ++j) tlwe1[j] = 0u - acc[NTT_N - j];
+    tlwe1[NTT_N] = acc[NTT_N];
+}
 }  // namespace
 
 static int g_direct = 0;  // 80-bit set: Decomp<2, 10, 1> (IYK_HIP_DECOMP=direct on the device) instead of the split digits
@@ -701,6 +790,45 @@ int iyk_emul_blind_rotate_fp_t16(const iyk_params* p, const uint32_t* lin, const
 }
 
 double iyk_emul_fp_max_magnitude(void) { return g_fp_maxabs; }
+
+// complex-FFT path: spectra of the signed 16-bit halves of every BK polynomial, cplx [polys][2][512] in arrangement F,
+// scaled by 1/512 (kernels_fft.hpp::bk_fft_kernel).  Output: 2 * bk_words doubles.
+int iyk_emul_bk_fft(const iyk_params* p, const uint32_t* bk, double* bk_fft)
+{
+    const size_t polys = (size_t)iyk_bk_words(p) / p->N;
+    fft::cplx* out = reinterpret_cast<fft::cplx*>(bk_fft);
+    std::vector<fft::cplx> xbuf(fft::XCHG_BYTES / sizeof(fft::cplx));
+    static thread_local fft::cplx a[64][8];
+    for (size_t q = 0; q < 2 * polys; ++q) {
+        const size_t poly = q >> 1;
+        const int half = (int)(q & 1);
+        ALL_LANES for (int m = 0; m < 8; ++m)
+        {
+            const u32 kr = bk[poly * NTT_N + lane + 64 * m], ki = bk[poly * NTT_N + lane + 64 * m + 512];
+            a[lane][m] = {(double)(half ? fft::key_hi(kr) : fft::key_lo(kr)), (double)(half ? fft::key_hi(ki) : fft::key_lo(ki))};
+        }
+        fft_forward_wave(a, xbuf.data());
+        ALL_LANES for (int k2 = 0; k2 < 8; ++k2)
+            out[q * fft::M + (size_t)k2 * 64 + lane] = {a[lane][k2].re * (1.0 / 512.0), a[lane][k2].im * (1.0 / 512.0)};
+    }
+    return 0;
+}
+int iyk_emul_blind_rotate_fft(const iyk_params* p, const uint32_t* lin, const double* bk_fft, uint32_t* tlwe1)
+{
+    if (p->N != 1024 || p->k != 1) return -1;
+    const fft::cplx* k = reinterpret_cast<const fft::cplx*>(bk_fft);
+    if (p->l == 3 && p->Bgbit == 6) blind_rotate_fft<fft::Gadget<3, 6>>(p, lin, k, tlwe1);
+    else if (p->l == 2 && p->Bgbit == 10) blind_rotate_fft<fft::Gadget<2, 10>>(p, lin, k, tlwe1);
+    else return -1;
+    return 0;
+}
+/* largest |z - rint(z)| over every inverse-transform output since the last reset */
+double iyk_emul_fft_round_error(int reset)
+{
+    const double w = g_fft_worst;
+    if (reset) g_fft_worst = 0.0;
+    return w;
+}
 
 
 // NTT of every polynomial q of the torus-domain BK, stored in the device layout (bk_dev_index)

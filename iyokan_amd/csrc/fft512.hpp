@@ -1,0 +1,236 @@
+// fft512.hpp — the negacyclic product mod (X^1024 + 1, 2^32) through a 512-point COMPLEX FP64 FFT, exact by a proven
+// rounding bound, laid out for one 64-lane wavefront per polynomial with 8 complex points per lane.
+//
+// Why: the Z_p transform of fpntt32.hpp spends 8 FP64 instructions per butterfly on 2 REAL points and
+// needs 10 stages; a complex butterfly spends 8 on 2 COMPLEX points, the folded transform has 9 stages, and the radix-8
+// passes below make most twiddles trivial (+-1, +-i, (1 +- i)/sqrt 2): ~290 instead of ~1000 instructions per lane and
+// transform.  Exactness no longer comes from a field but from magnitudes: the key words are split into two SIGNED 16-bit
+// halves k = lo + 2^16 hi, both transformed once at init, and every rounded FFT product sum is within 2^-10 of an integer
+// (proof and margins: DESIGN.md §2b; worst-case test: tests/test_gpu_fft.py), so rint() returns the exact integer sums
+// R_lo, R_hi and R = R_lo + 2^16 R_hi mod 2^32 is the schoolbook result — the same words as the Z_p and Goldilocks paths.
+//
+// Mathematics.  For a real polynomial a of degree < N = 1024 put M = N/2, psi = exp(i pi / N), W = psi^4 = exp(2 pi i / M):
+//     z[j]  = a[j] + i a[j + M]                       (fold)
+//     A[k]  = sum_j z[j] psi^j W^(jk) = a(psi^(4k+1)) (twist + cyclic DFT_M: a at half of the roots of X^N + 1; the other
+//                                                      half are the conjugates and carry nothing new for real a)
+// so (a * b mod X^N + 1) <-> A[k] B[k], and back by z[j] = psi^-j (1/M) sum_k C[k] W^(-jk).
+//
+// Index split (three radix-8 passes): j = 64 j2 + 8 j1 + j0, k = k0 + 8 k1 + 64 k2, all digits in [0, 8):
+//     jk = 64 j2 k0 + (8 j1 + j0) k0 + 64 j1 k1 + 8 j0 k1 + 64 j0 k2   (mod 512)
+//   arrangement A (time):      lane L = 8 j1 + j0, register j2        element j = L + 64 j2
+//   pass 1   DFT8 over j2 -> k0, times T1[L][k0] = psi^(L (4 k0 + 1))  (inter-pass twiddle W^(L k0) and the lane's share
+//            psi^L of the twist in one constant; the other share psi^(64 j2) is wave-uniform and applied before the pass)
+//   exchange 1 (LDS): lane (j1, j0) register k0  ->  lane' = 8 k0 + j0, register j1
+//   pass 2   DFT8 over j1 -> k1, times T2[j0][k1] = exp(2 pi i j0 k1 / 64)
+//   exchange 2 (LDS): lane' (k0, j0) register k1 ->  lane'' = 8 k0 + k1, register j0
+//   pass 3   DFT8 over j0 -> k2
+//   arrangement F (frequency): lane'' = 8 k0 + k1, register k2        frequency k = k0 + 8 k1 + 64 k2
+// The inverse runs the same network backwards with conjugated constants (IDFT8 over k2, conj T2, exchange 2 back, IDFT8
+// over k1, exchange 1 back, conj T1, IDFT8 over k0, conj psi^(64 j2)); the 1/M is folded into the key spectrum.
+// LDS slots (16 bytes each) are chosen so that every ds_write_b128 / ds_read_b128 of both directions is conflict-free
+// under the lane grouping of MI355X_MICROARCH.md §LDS and uses one lane base + immediate offsets:
+//     exchange 1: slot = 72 k0 + 8 j1 + j0        exchange 2: slot = 72 k0 + 9 k1 + j0
+//
+// The same functions run lane by lane on the CPU (csrc/emul.cpp) for the GPU-less tests.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include "goldilocks.hpp"  // IYK_HD, u32 / u64
+
+namespace iyk {
+namespace fft {
+
+struct alignas(16) cplx {
+    double re, im;
+};
+
+static constexpr int M = 512;                 // complex points per polynomial
+static constexpr int XCHG_SLOTS = 7 * 72 + 7 * 9 + 8;   // 575 slots of 16 bytes
+static constexpr size_t XCHG_BYTES = 9216;    // per wave, rounded up to a multiple of 512
+
+IYK_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// a * t and a * conj(t): 4 instructions each (2 mul + 2 fma)
+IYK_HD cplx cmul(cplx a, cplx t) { return {fma_(a.re, t.re, -(a.im * t.im)), fma_(a.re, t.im, a.im * t.re)}; }
+IYK_HD cplx cmulc(cplx a, cplx t) { return {fma_(a.re, t.re, a.im * t.im), fma_(a.im, t.re, -(a.re * t.im))}; }
+IYK_HD cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
+IYK_HD cplx csub(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
+// a + i b, a - i b (no multiplication: i (x + i y) = -y + i x)
+IYK_HD cplx cadd_i(cplx a, cplx b) { return {a.re - b.im, a.im + b.re}; }
+IYK_HD cplx csub_i(cplx a, cplx b) { return {a.re + b.im, a.im - b.re}; }
+
+static constexpr double RSQRT2 = 0.70710678118654752440;
+
+// 8-point DFT, natural order in and out: X[k] = sum_m x[m] e^(+-2 pi i m k / 8) (+: forward, -: INV).  Radix-2 DIF
+// with the bit reversal undone by register naming: 24 complex additions and two rotations by (1 +- i)/sqrt 2 — 56
+// instructions.
+template <bool INV>
+IYK_HD void dft8(cplx (&x)[8])
+{
+    // stage 1: s[m] = x[m] + x[m+4]; d[m] = (x[m] - x[m+4]) w^m, w = e^(+-i pi/4)
+    const cplx s0 = cadd(x[0], x[4]), s1 = cadd(x[1], x[5]), s2 = cadd(x[2], x[6]), s3 = cadd(x[3], x[7]);
+    const cplx u0 = csub(x[0], x[4]), u1 = csub(x[1], x[5]), u2 = csub(x[2], x[6]), u3 = csub(x[3], x[7]);
+    // d0 = u0; d2 = +-i u2 (kept as u2, folded into stage 2); d1 = u1 (1 +- i)/sqrt 2; d3 = u3 (-1 +- i)/sqrt 2
+    cplx d1, d3;
+    if (!INV) {
+        d1 = {(u1.re - u1.im) * RSQRT2, (u1.re + u1.im) * RSQRT2};
+        d3 = {(-u3.re - u3.im) * RSQRT2, (u3.re - u3.im) * RSQRT2};
+    }
+    else {
+        d1 = {(u1.re + u1.im) * RSQRT2, (u1.im - u1.re) * RSQRT2};
+        d3 = {(u3.im - u3.re) * RSQRT2, (-u3.re - u3.im) * RSQRT2};
+    }
+    // stage 2 + 3 on the evens (s) -> X[0], X[4], X[2], X[6]
+    {
+        const cplx a = cadd(s0, s2), b = cadd(s1, s3), c = csub(s0, s2), d = csub(s1, s3);   // d to be rotated by +-i
+        x[0] = cadd(a, b);
+        x[4] = csub(a, b);
+        x[2] = INV ? csub_i(c, d) : cadd_i(c, d);
+        x[6] = INV ? cadd_i(c, d) : csub_i(c, d);
+    }
+    // ... and on the odds (d) -> X[1], X[5], X[3], X[7]; d2 = +-i u2
+    {
+        const cplx a = INV ? csub_i(u0, u2) : cadd_i(u0, u2);   // d0 + d2
+        const cplx c = INV ? cadd_i(u0, u2) : csub_i(u0, u2);   // d0 - d2
+        const cplx b = cadd(d1, d3), d = csub(d1, d3);
+        x[1] = cadd(a, b);
+        x[5] = csub(a, b);
+        x[3] = INV ? csub_i(c, d) : cadd_i(c, d);
+        x[7] = INV ? cadd_i(c, d) : csub_i(c, d);
+    }
+}
+
+// wave-uniform and per-lane constants (host-generated in long double, rounded once: |error| <= 2^-53 per component)
+struct Consts {
+    cplx u[8];         // psi^(64 m) = exp(i pi m / 16)
+    cplx t2t[8][8];    // [b][a]: exp(2 pi i a b / 64) (symmetric in value; the layout says which index a lane owns)
+    cplx t1[8][64];    // [k0][L]: psi^(L (4 k0 + 1))
+};
+
+inline void make_consts(Consts& C)
+{
+    const long double pi = 3.14159265358979323846264338327950288L;
+    auto e = [&](long double num, long double den) {   // exp(i pi num / den)
+        return cplx{(double)cosl(pi * num / den), (double)sinl(pi * num / den)};
+    };
+    for (int m = 0; m < 8; ++m) C.u[m] = e(m, 16);
+    for (int a = 0; a < 8; ++a)
+        for (int b = 0; b < 8; ++b) C.t2t[b][a] = e(2 * ((a * b) % 64), 64);
+    for (int k0 = 0; k0 < 8; ++k0)
+        for (int L = 0; L < 64; ++L) C.t1[k0][L] = e((L * (4 * k0 + 1)) % 2048, 1024);
+}
+
+// ---- LDS exchanges (16-byte slots; the caller fences between a write and the dependent read) -----------------------
+// byte-free slot arithmetic: every access is lane base + compile-time offset
+IYK_HD int x1_wbase(int L) { return L; }                                  // + 72 k0
+IYK_HD int x1_rbase(int L) { return 72 * (L >> 3) + (L & 7); }            // + 8 j1      (L = lane' = 8 k0 + j0)
+IYK_HD int x2_wbase(int L) { return 72 * (L >> 3) + (L & 7); }            // + 9 k1      (lane')
+IYK_HD int x2_rbase(int L) { return 72 * (L >> 3) + 9 * (L & 7); }        // + j0        (L = lane'' = 8 k0 + k1)
+
+// forward: exchange 1 write (lane, register k0), read (lane', register j1); exchange 2 write (lane', register k1), read
+// (lane'', register j0).  The inverse uses the same four with write / read swapped.
+IYK_HD void x1_put_a(int L, const cplx (&a)[8], cplx* xb)
+{
+#pragma unroll
+    for (int r = 0; r < 8; ++r) xb[x1_wbase(L) + 72 * r] = a[r];
+}
+IYK_HD void x1_get_b(int L, cplx (&a)[8], const cplx* xb)
+{
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a[r] = xb[x1_rbase(L) + 8 * r];
+}
+IYK_HD void x1_put_b(int L, const cplx (&a)[8], cplx* xb)
+{
+#pragma unroll
+    for (int r = 0; r < 8; ++r) xb[x1_rbase(L) + 8 * r] = a[r];
+}
+IYK_HD void x1_get_a(int L, cplx (&a)[8], const cplx* xb)
+{
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a[r] = xb[x1_wbase(L) + 72 * r];
+}
+IYK_HD void x2_put_b(int L, const cplx (&a)[8], cplx* xb)
+{
+#pragma unroll
+    for (int r = 0; r < 8; ++r) xb[x2_wbase(L) + 9 * r] = a[r];
+}
+IYK_HD void x2_get_c(int L, cplx (&a)[8], const cplx* xb)
+{
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a[r] = xb[x2_rbase(L) + r];
+}
+IYK_HD void x2_put_c(int L, const cplx (&a)[8], cplx* xb)
+{
+#pragma unroll
+    for (int r = 0; r < 8; ++r) xb[x2_rbase(L) + r] = a[r];
+}
+IYK_HD void x2_get_b(int L, cplx (&a)[8], const cplx* xb)
+{
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a[r] = xb[x2_wbase(L) + 9 * r];
+}
+
+// ---- the pieces of a transform between the exchanges ------------------------------------------------------------------
+// forward, part 1: uniform twist psi^(64 m), DFT8 over j2, T1 (t1 = this lane's column of Consts::t1: t1[64 * k0])
+IYK_HD void fwd_p1(cplx (&a)[8], const cplx* u, const cplx* t1_lane)
+{
+#pragma unroll
+    for (int m = 1; m < 8; ++m) a[m] = cmul(a[m], u[m]);
+    dft8<false>(a);
+#pragma unroll
+    for (int k0 = 0; k0 < 8; ++k0) a[k0] = cmul(a[k0], t1_lane[64 * k0]);
+}
+// forward, part 2: DFT8 over j1, T2.  t2_lane[8 b] = exp(2 pi i a b / 64) for this lane's a = lane' & 7: column a of the
+// transposed table Consts::t2t ([b][a]: the eight lanes of a group read eight consecutive slots — conflict-free)
+IYK_HD void fwd_p2(cplx (&a)[8], const cplx* t2_lane)
+{
+    dft8<false>(a);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; ++k1) a[k1] = cmul(a[k1], t2_lane[8 * k1]);
+}
+IYK_HD void fwd_p3(cplx (&a)[8]) { dft8<false>(a); }
+
+// inverse, part 1 (arrangement F): IDFT8 over k2, conj T2 (row k1 = lane'' & 7)
+IYK_HD void inv_p1(cplx (&a)[8], const cplx* t2_lane)
+{
+    dft8<true>(a);
+#pragma unroll
+    for (int j0 = 1; j0 < 8; ++j0) a[j0] = cmulc(a[j0], t2_lane[8 * j0]);
+}
+IYK_HD void inv_p2(cplx (&a)[8]) { dft8<true>(a); }
+// inverse, part 3 (arrangement A, register k0): conj T1, IDFT8 over k0 -> j2, conj psi^(64 j2)
+IYK_HD void inv_p3(cplx (&a)[8], const cplx* u, const cplx* t1_lane)
+{
+#pragma unroll
+    for (int k0 = 0; k0 < 8; ++k0) a[k0] = cmulc(a[k0], t1_lane[64 * k0]);
+    dft8<true>(a);
+#pragma unroll
+    for (int m = 1; m < 8; ++m) a[m] = cmulc(a[m], u[m]);
+}
+
+// rint(x) mod 2^32 for |x| < 2^51 by the magic-constant addition (one instruction): the low word of x + 1.5 * 2^52
+static constexpr double MAGIC = 6755399441055744.0;
+IYK_HD u32 round_u32(double x)
+{
+    const double t = x + MAGIC;
+    u64 b;
+    __builtin_memcpy(&b, &t, 8);
+    return (u32)b;
+}
+// distance of x from the nearest integer (debug check of the rounding bound)
+IYK_HD double round_err(double x)
+{
+    const double t = (x + MAGIC) - MAGIC;
+    return __builtin_fabs(t - x);
+}
+
+// signed 16-bit halves of a key word: k = lo + 2^16 hi (mod 2^32), both in [-2^15, 2^15)
+IYK_HD int32_t key_lo(u32 k) { return (int32_t)(int16_t)(k & 0xFFFFu); }
+IYK_HD int32_t key_hi(u32 k) { return (int32_t)(int16_t)((k - (u32)key_lo(k)) >> 16); }
+
+// position of frequency k = k0 + 8 k1 + 64 k2 in arrangement F, stored as [k2][lane''] (a wave's loads are contiguous)
+IYK_HD constexpr int freq_pos(int k) { return (k >> 6) * 64 + 8 * (k & 7) + ((k >> 3) & 7); }
+
+}  // namespace fft
+}  // namespace iyk

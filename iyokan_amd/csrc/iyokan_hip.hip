@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -26,6 +27,7 @@
 #include "../../include/iyokan_hip.h"
 #include "kernels.hpp"
 #include "kernels_t16.hpp"
+#include "kernels_fft.hpp"
 
 using namespace iyk;
 
@@ -63,6 +65,9 @@ struct Device {
     u64* tw_fwd = nullptr;   // u64 or double tables, same size
     u64* tw_inv = nullptr;
     fp::NttConsts* fpc = nullptr;  // FP path: 32-point twiddles + twists, read by scalar loads
+    fft::cplx* bk_fft = nullptr;   // FFT path: key spectra of the signed 16-bit halves (kernels_fft.hpp), 16 bytes per point
+    fft::Consts* fftc = nullptr;
+    unsigned long long* fft_err = nullptr;  // IYK_HIP_DEBUG: largest |z - rint(z)| seen by the FFT kernel (bits of a double)
     void release()
     {
         if (ordinal < 0) return;
@@ -72,6 +77,12 @@ struct Device {
         if (tw_fwd) (void)hipFree(tw_fwd);
         if (tw_inv) (void)hipFree(tw_inv);
         if (fpc) (void)hipFree(fpc);
+        if (bk_fft) (void)hipFree(bk_fft);
+        if (fftc) (void)hipFree(fftc);
+        if (fft_err) (void)hipFree(fft_err);
+        bk_fft = nullptr;
+        fftc = nullptr;
+        fft_err = nullptr;
         bk_ntt = nullptr;
         ksk = nullptr;
         tw_fwd = tw_inv = nullptr;
@@ -87,6 +98,8 @@ struct Global {
     u32 ksk_stride = 0;
     int ks_kernel = 1;    // 1: keyswitch_wave_kernel where instantiated, 0: keyswitch_kernel (IYK_HIP_KS_KERNEL)
     bool use_fp = false;          // FP64 path (fp50.hpp) instead of Goldilocks integers
+    bool use_fft = false;         // wave-per-rotation kernel on the complex-FFT path (fft512.hpp); implies use_fp for the narrow-frontier kernel
+    size_t bk_fft_bytes = 0;
     int split = 1;                // FP64 path: digit polynomials per gadget level (blind_rotate_fp.hpp Decomp::SPLIT)
     int lat_threshold = 1280;     // rotations per batch at or below which a workgroup-per-rotation kernel is used
     int tp_kernel = 32;           // wave-per-rotation kernel: 32 = blind_rotate_fp_kernel (2 waves / SIMD), 16 = blind_rotate_fp_t16_kernel (3 waves / SIMD)
@@ -220,6 +233,21 @@ int launch_br_fp(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
     return IYK_OK;
 }
 
+// the complex-FFT wave-per-rotation kernel (kernels_fft.hpp): same geometry as blind_rotate_fp_kernel.  IYK_HIP_DEBUG=1
+// (at init) runs the variant that also records the largest distance of an inverse-transform output from an integer.
+template <class GD>
+int launch_br_fft(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
+{
+    const Device& D = G.devs[st->gpu];
+    dim3 grid((njobs + BR_WAVES - 1) / BR_WAVES), block(64 * BR_WAVES);
+    auto kern = G.debug ? blind_rotate_fft_kernel<GD, true> : blind_rotate_fft_kernel<GD, false>;
+    hipLaunchKernelGGL(kern, grid, block, BR_FFT_LDS_BYTES, st->s, (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE,
+                       njobs, (const fft::cplx*)D.bk_fft, (u32)G.bk_fft_bytes, (const fft::Consts*)D.fftc, o.at(first),
+                       G.p.n, G.p.mu, ABAR_STRIDE, o.trlwe, o.idx(first), D.fft_err);
+    HIP_TRY(hipGetLastError());
+    return IYK_OK;
+}
+
 // the three-waves-per-SIMD wave-per-rotation kernel (kernels_t16.hpp): one workgroup of BR_T16_WAVES waves per CU, jobs
 // dealt round-robin to the resident waves
 template <class DC>
@@ -252,7 +280,7 @@ int launch_br_fp_lat3(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
 
 // which rotation kernel a batch is forced onto: IYK_HIP_ROT_KERNEL = w32 / t16 / lat3 (A/B, tests; read per batch).
 // IYK_HIP_LATENCY_KERNEL = 0 / 3 is the older spelling of w32 / lat3.  0 = no override.
-enum { ROT_AUTO = 0, ROT_W32 = 32, ROT_T16 = 16, ROT_LAT3 = 3 };
+enum { ROT_AUTO = 0, ROT_W32 = 32, ROT_T16 = 16, ROT_LAT3 = 3, ROT_FFT = 8 };
 int forced_rot_kernel()
 {
     if (const char* k = std::getenv("IYK_HIP_ROT_KERNEL")) {
@@ -260,6 +288,7 @@ int forced_rot_kernel()
         if (v == "w32") return ROT_W32;
         if (v == "t16") return ROT_T16;
         if (v == "lat3") return ROT_LAT3;
+        if (v == "fft") return ROT_FFT;
     }
     if (const char* lat = std::getenv("IYK_HIP_LATENCY_KERNEL")) {
         if (lat[0] == '0') return ROT_W32;
@@ -273,18 +302,25 @@ int forced_rot_kernel()
 // workgroup-per-rotation kernel: it takes one CU per rotation, 3.6-4.0 ms per 256 rotations, in sequence (7.5 / 11.1 /
 // 14.6 / 18.5 ms for 512 / 768 / 1024 / 1280); above that one more (partial) round of the wave-per-rotation kernel is
 // faster (profiles/r02_sweep_kernels_v7.txt).
-template <class DC>
+template <class DC, class GD>
 int dispatch_fp(iyk_hip_stream* st, int njobs, const RotOut& o)
 {
     int rc;
     const int forced = forced_rot_kernel();
+    if (forced == ROT_FFT) {
+        if (!G.use_fft) return fail(IYK_ERR_STATE, "IYK_HIP_ROT_KERNEL=fft needs the FFT key spectra (IYK_HIP_NTT=fft at init)");
+        return launch_br_fft<GD>(st, 0, njobs, o);
+    }
     if (forced == ROT_LAT3) return launch_br_fp_lat3<DC>(st, 0, njobs, o);
     if (forced == ROT_W32) return launch_br_fp<DC>(st, 0, njobs, o);
     if (forced == ROT_T16) return launch_br_fp_t16<DC>(st, 0, njobs, o);
-    const bool t16 = G.tp_kernel == 16;
+    const bool t16 = G.tp_kernel == 16 && !G.use_fft;
     const int round = (t16 ? BR_T16_WAVES : BR_WAVES) * G.devs[st->gpu].cus;
     const int rem = njobs % round, full = njobs - rem;
-    auto tp = [&](int first, int count) { return t16 ? launch_br_fp_t16<DC>(st, first, count, o) : launch_br_fp<DC>(st, first, count, o); };
+    auto tp = [&](int first, int count) {
+        if (G.use_fft) return launch_br_fft<GD>(st, first, count, o);
+        return t16 ? launch_br_fp_t16<DC>(st, first, count, o) : launch_br_fp<DC>(st, first, count, o);
+    };
     if (rem > G.lat_threshold) return tp(0, njobs);
     if (full && (rc = tp(0, full))) return rc;
     if (rem) return launch_br_fp_lat3<DC>(st, full, rem, o);
@@ -301,9 +337,9 @@ int launch_blind_rotate(iyk_hip_stream* st, const u32* d_arena, const RotJob* d_
                        ABAR_STRIDE);
     HIP_TRY(hipGetLastError());
     if (G.use_fp) {
-        if (p.l == 3) return dispatch_fp<fp::Decomp<3, 6, 1>>(st, njobs, o);
-        if (G.split == 1) return dispatch_fp<fp::Decomp<2, 10, 1>>(st, njobs, o);
-        return dispatch_fp<fp::Decomp<2, 10, 2>>(st, njobs, o);
+        if (p.l == 3) return dispatch_fp<fp::Decomp<3, 6, 1>, fft::Gadget<3, 6>>(st, njobs, o);
+        if (G.split == 1) return dispatch_fp<fp::Decomp<2, 10, 1>, fft::Gadget<2, 10>>(st, njobs, o);
+        return dispatch_fp<fp::Decomp<2, 10, 2>, fft::Gadget<2, 10>>(st, njobs, o);
     }
     if (p.l == 3 && p.Bgbit == 6) return launch_br<3, 6>(st, njobs, o);
     if (p.l == 2 && p.Bgbit == 10) return launch_br<2, 10>(st, njobs, o);
@@ -380,9 +416,17 @@ int set_fp_attrs()
     if ((rc = set_lds(blind_rotate_fp_t16_kernel<DC, BR_T16_WAVES>, BrT16<BR_T16_WAVES>::LDS_BYTES))) return rc;
     return set_lds(blind_rotate_fp_lat3_kernel<DC>, BrLat3<DC>::LDS_BYTES);
 }
+template <class GD>
+int set_fft_attrs()
+{
+    int rc;
+    if ((rc = set_lds(blind_rotate_fft_kernel<GD, false>, BR_FFT_LDS_BYTES))) return rc;
+    return set_lds(blind_rotate_fft_kernel<GD, true>, BR_FFT_LDS_BYTES);
+}
 int set_kernel_attrs(const iyk_params& p, bool use_fp, int split)
 {
     int rc;
+    if (use_fp && (rc = (p.l == 3) ? set_fft_attrs<fft::Gadget<3, 6>>() : set_fft_attrs<fft::Gadget<2, 10>>())) return rc;
     if (use_fp) rc = (p.l == 3) ? set_fp_attrs<fp::Decomp<3, 6, 1>>() : split == 1 ? set_fp_attrs<fp::Decomp<2, 10, 1>>() : set_fp_attrs<fp::Decomp<2, 10, 2>>();
     else rc = (p.l == 3) ? set_lds(blind_rotate_kernel<3, 6>, BR_LDS_BYTES) : set_lds(blind_rotate_kernel<2, 10>, BR_LDS_BYTES);
     if (rc) return rc;
@@ -454,7 +498,7 @@ void destroy_stream_resources(iyk_hip_stream* st)
 }
 
 int init_devices(std::vector<Device>& devs, const int* device_ids, int avail, const iyk_params& p, bool use_fp,
-                 int split, const uint32_t* bk_torus, const std::vector<u32>& ksk_pad, const std::vector<u64>& twf,
+                 bool use_fft, const fft::Consts& fftc, int split, const uint32_t* bk_torus, const std::vector<u32>& ksk_pad, const std::vector<u64>& twf,
                  const std::vector<u64>& twi, const fp::HostTables& fpt)
 {
     const size_t bk_words = (size_t)iyk_bk_words(&p);
@@ -493,6 +537,16 @@ int init_devices(std::vector<Device>& devs, const int* device_ids, int avail, co
             hipLaunchKernelGGL(bk_ntt_kernel, dim3((unsigned)((polys + 1) / 2)), dim3(64), 0, 0, d_bk, D.bk_ntt,
                                D.tw_fwd, polys);
         HIP_TRY(hipGetLastError());
+        if (use_fft) {  // the wave-per-rotation kernel's key: spectra of the signed 16-bit halves, 2 x 8 KB per polynomial
+            HIP_TRY(hipMalloc((void**)&D.bk_fft, polys * 2 * fft::M * sizeof(fft::cplx)));
+            HIP_TRY(hipMalloc((void**)&D.fftc, sizeof(fft::Consts)));
+            HIP_TRY(hipMalloc((void**)&D.fft_err, sizeof(unsigned long long)));
+            HIP_TRY(hipMemset(D.fft_err, 0, sizeof(unsigned long long)));
+            HIP_TRY(hipMemcpy(D.fftc, &fftc, sizeof(fft::Consts), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(bk_fft_kernel, dim3((unsigned)(polys * 2)), dim3(64), 0, 0, d_bk, D.bk_fft,
+                               (const fft::Consts*)D.fftc, polys);
+            HIP_TRY(hipGetLastError());
+        }
         HIP_TRY(hipDeviceSynchronize());
     }
     return IYK_OK;
@@ -582,10 +636,27 @@ int iyk_hip_get_params(iyk_params* out)
 }
 
 /* 1 = FP64 field path (p = 3 * 2^48 + 1097729), 0 = Goldilocks integer path */
-int iyk_hip_ntt_path(void) { return G.init.load() ? (G.use_fp ? 1 : 0) : IYK_ERR_STATE; }
+int iyk_hip_ntt_path(void) { return G.init.load() ? (G.use_fft ? 2 : G.use_fp ? 1 : 0) : IYK_ERR_STATE; }
+
+/* IYK_HIP_DEBUG=1 at init: the largest |z - rint(z)| any inverse transform of the FFT kernel has produced on this GPU since
+ * init (the quantity DESIGN.md §2b bounds by 2^-10); 0 when nothing was recorded. */
+int iyk_hip_fft_round_error(int gpu_index, double* out)
+{
+    if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
+    if (gpu_index < 0 || gpu_index >= (int)G.devs.size() || !out) return fail(IYK_ERR_INVALID, "gpu_index out of range / null out");
+    *out = 0.0;
+    if (!G.use_fft) return IYK_OK;
+    int rc = set_device(gpu_index);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long bits = 0;
+    HIP_TRY(hipMemcpy(&bits, G.devs[gpu_index].fft_err, sizeof(bits), hipMemcpyDeviceToHost));
+    std::memcpy(out, &bits, sizeof(bits));
+    return IYK_OK;
+}
 
 /* digit polynomials per accumulator polynomial and CMUX step: l, or 2 l where the FP64 path splits every digit */
-int iyk_hip_decomposition_levels(void) { return G.init.load() ? (int)G.p.l * (G.use_fp ? G.split : 1) : IYK_ERR_STATE; }
+int iyk_hip_decomposition_levels(void) { return G.init.load() ? (int)G.p.l * (G.use_fp && !G.use_fft ? G.split : 1) : IYK_ERR_STATE; }
 
 #ifndef IYK_BUILD_ID
 #define IYK_BUILD_ID "unknown"
@@ -597,7 +668,7 @@ int iyk_hip_rotation_round(int gpu_index)
 {
     if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
     if (gpu_index < 0 || gpu_index >= (int)G.devs.size()) return fail(IYK_ERR_INVALID, "gpu_index out of range");
-    return (G.use_fp && G.tp_kernel == 16 ? BR_T16_WAVES : BR_WAVES) * G.devs[gpu_index].cus;
+    return (G.use_fp && !G.use_fft && G.tp_kernel == 16 ? BR_T16_WAVES : BR_WAVES) * G.devs[gpu_index].cus;
 }
 
 int iyk_hip_resident_key_bytes(uint64_t* out)
@@ -638,6 +709,8 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
     const char* dec = std::getenv("IYK_HIP_DECOMP");
     const char* force = std::getenv("IYK_HIP_NTT");
     const bool goldilocks = force && std::string(force) == "goldilocks";
+    if (force && !goldilocks && std::string(force) != "fp" && std::string(force) != "fft")
+        return fail(IYK_ERR_INVALID, "IYK_HIP_NTT must be 'fft' (default), 'fp' or 'goldilocks'");
     const bool direct = dec && std::string(dec) == "direct";
     if (dec && !direct && std::string(dec) != "split") return fail(IYK_ERR_INVALID, "IYK_HIP_DECOMP must be 'split' or 'direct'");
     if (direct && (goldilocks || !(p.l == 2 && p.Bgbit == 10)))
@@ -647,6 +720,16 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
     const double dmax = split == 1 ? (double)(1u << (p.Bgbit - 1)) : (double)(1u << (p.Bgbit / 2 - 1));
     const double worst = 2.0 * (p.k + 1) * LV * p.N * dmax * 2147483648.0;
     const bool use_fp = (worst < fp::P || direct) && !goldilocks;
+    // Default since round 4: the wave-per-rotation kernel multiplies through a complex FP64 FFT with the key split into signed
+    // 16-bit halves — exact by a rounding bound (fft512.hpp), about half the instructions of the field
+    // transform.  The narrow-frontier kernel stays on the field, so both key forms are resident.  IYK_HIP_NTT=fp: field only.
+    // IYK_HIP_DECOMP=direct is an option of the field path (the FFT path uses the 80-bit set's digits as they are anyway,
+    // and exactly): asking for it selects the field path.
+    if (direct && force && std::string(force) == "fft")
+        return fail(IYK_ERR_INVALID, "IYK_HIP_DECOMP=direct applies to the FP64 field path (IYK_HIP_NTT=fp), not to IYK_HIP_NTT=fft");
+    const bool use_fft = use_fp && !direct && !(force && std::string(force) == "fp");
+    auto fftc = std::make_unique<fft::Consts>();
+    if (use_fft) fft::make_consts(*fftc);
     std::vector<u64> twf(NTT_N), twi(2 * NTT_N);  // twi: [k2][j1], then the transposed copy [j1][k2]
     fp::HostTables fpt{};
     if (use_fp) {
@@ -669,7 +752,7 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
         std::memcpy(&ksk_pad[r * stride], ksk + r * (p.n + 1), sizeof(u32) * (p.n + 1));
 
     std::vector<Device> devs(ngpu);
-    int rc = init_devices(devs, device_ids, avail, p, use_fp, split, bk_torus, ksk_pad, twf, twi, fpt);
+    int rc = init_devices(devs, device_ids, avail, p, use_fp, use_fft, *fftc, split, bk_torus, ksk_pad, twf, twi, fpt);
     if (rc) {  // release whatever the loop had allocated before it failed; keep its error text
         const std::string keep = g_last_error;
         for (Device& D : devs) D.release();
@@ -700,12 +783,14 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
     G.tp_kernel = (tk && std::string(tk) == "t16") ? 16 : 32;
     G.p = p;
     G.use_fp = use_fp;
+    G.use_fft = use_fft;
+    G.bk_fft_bytes = use_fft ? (bk_words / NTT_N) * 2 * fft::M * sizeof(fft::cplx) : 0;
     G.split = split;
     G.fpc = fpt.c;
     G.ksk_stride = stride;
     G.devs = devs;
     G.peer = peer;
-    G.key_bytes = bk_words * sizeof(u64) * (use_fp ? split : 1) + ksk_pad.size() * sizeof(u32) + 2 * NTT_N * sizeof(u64);
+    G.key_bytes = bk_words * sizeof(u64) * (use_fp ? split : 1) + ksk_pad.size() * sizeof(u32) + 2 * NTT_N * sizeof(u64) + G.bk_fft_bytes;
     G.init.store(true);
     return IYK_OK;
     IYK_API_END

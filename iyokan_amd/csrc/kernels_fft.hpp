@@ -1,0 +1,204 @@
+// kernels_fft.hpp — the complex-FFT rotation kernels (fft512.hpp, blind_rotate_fft.hpp).
+//
+//   init        bk_fft_kernel                       torus-domain BK rows -> two spectra (signed 16-bit halves) per polynomial
+//   per batch   blind_rotate_fft_kernel<G, CHECK>   one wavefront per rotation, 8 complex points per lane, 2 waves / SIMD
+//
+// LDS map of blind_rotate_fft_kernel (bytes): T1 lane constants cplx [8][64] 8 K | accumulators [wave][2][1024] u32 64 K
+// (every polynomial 4 KB aligned) | exchange buffers [wave] 9 K each = 72 K  -> 144 KiB of the CU's 160, one 8-wave
+// workgroup per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "blind_rotate_fft.hpp"
+#include "kernels.hpp"
+
+namespace iyk {
+
+static constexpr size_t BR_FFT_T1_BYTES = 8 * 64 * sizeof(fft::cplx);
+static constexpr size_t BR_FFT_T2_BYTES = 8 * 8 * sizeof(fft::cplx);
+static constexpr size_t BR_FFT_LDS_BYTES = BR_FFT_T1_BYTES + (size_t)BR_WAVES * 2 * NTT_N * sizeof(u32) + (size_t)BR_WAVES * fft::XCHG_BYTES + BR_FFT_T2_BYTES;
+static_assert(BR_FFT_LDS_BYTES <= 160 * 1024, "FFT rotation kernel does not fit the CU's LDS");
+static_assert(BR_FFT_T1_BYTES % 4096 == 0, "diff16 needs every accumulator polynomial 4 KB aligned");
+
+// forward transform of 8 complex points per lane from arrangement A to arrangement F through the wave's exchange buffer
+__device__ __forceinline__ void fft_forward(int lane, fft::cplx (&a)[8], const fft::cplx* u, const fft::cplx* t1_lane,
+                                            const fft::cplx* t2, fft::cplx* xb)
+{
+    fft::fwd_p1(a, u, t1_lane);
+    fft::x1_put_a(lane, a, xb);
+    lds_sync();
+    fft::x1_get_b(lane, a, xb);
+    lds_sync();
+    fft::fwd_p2(a, t2);
+    fft::x2_put_b(lane, a, xb);
+    lds_sync();
+    fft::x2_get_c(lane, a, xb);
+    lds_sync();
+    fft::fwd_p3(a);
+}
+__device__ __forceinline__ void fft_inverse(int lane, fft::cplx (&a)[8], const fft::cplx* u, const fft::cplx* t1_lane,
+                                            const fft::cplx* t2, fft::cplx* xb)
+{
+    fft::inv_p1(a, t2);
+    fft::x2_put_c(lane, a, xb);
+    lds_sync();
+    fft::x2_get_b(lane, a, xb);
+    lds_sync();
+    fft::inv_p2(a);
+    fft::x1_put_b(lane, a, xb);
+    lds_sync();
+    fft::x1_get_a(lane, a, xb);
+    lds_sync();
+    fft::inv_p3(a, u, t1_lane);
+}
+
+// BK: [polys][1024] u32 torus -> cplx [polys][2][512]: the spectra of the signed 16-bit halves (lo, hi) of every
+// polynomial, arrangement F, scaled by 1/512 (the inverse transform's normalisation).  One wave per (polynomial, half).
+__global__ __launch_bounds__(64) void bk_fft_kernel(const u32* __restrict__ bk, fft::cplx* __restrict__ bk_fft,
+                                                    const fft::Consts* __restrict__ Cp, size_t polys)
+{
+    __shared__ fft::cplx xb[fft::XCHG_BYTES / sizeof(fft::cplx)];
+    const fft::Consts& C = *Cp;
+    const int lane = threadIdx.x;
+    const size_t q = blockIdx.x;            // 2 * poly + half
+    const size_t poly = q >> 1;
+    const int half = (int)(q & 1);
+    if (poly >= polys) return;
+    fft::cplx a[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const u32 kr = bk[poly * NTT_N + lane + 64 * m], ki = bk[poly * NTT_N + lane + 64 * m + 512];
+        a[m] = {(double)(half ? fft::key_hi(kr) : fft::key_lo(kr)), (double)(half ? fft::key_hi(ki) : fft::key_lo(ki))};
+    }
+    fft_forward(lane, a, C.u, &C.t1[0][lane], &C.t2t[0][lane & 7], xb);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) bk_fft[q * fft::M + (size_t)k2 * 64 + lane] = {a[k2].re * (1.0 / 512.0), a[k2].im * (1.0 / 512.0)};
+}
+
+template <class G, bool CHECK>
+__global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
+    const u32* __restrict__ abar_all, int njobs, const fft::cplx* __restrict__ bk_fft, u32 bk_bytes,
+    const fft::Consts* __restrict__ Cp, u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride, int trlwe_mode,
+    const int32_t* __restrict__ out_index, unsigned long long* __restrict__ max_err_bits)
+{
+    const fft::Consts& C = *Cp;
+    constexpr int L = G::L;
+    extern __shared__ __attribute__((aligned(4096))) unsigned char smem[];
+    fft::cplx* s_t1 = reinterpret_cast<fft::cplx*>(smem);                                   // [k0][lane]
+    u32* s_acc = reinterpret_cast<u32*>(smem + BR_FFT_T1_BYTES);                            // [BR_WAVES][2][NTT_N]
+    fft::cplx* s_xb = reinterpret_cast<fft::cplx*>(smem + BR_FFT_T1_BYTES + (size_t)BR_WAVES * 2 * NTT_N * sizeof(u32));
+    fft::cplx* s_t2 = s_xb + (size_t)BR_WAVES * (fft::XCHG_BYTES / sizeof(fft::cplx));             // [b][a]
+
+    for (int e = threadIdx.x; e < 8 * 64; e += 64 * BR_WAVES) s_t1[e] = C.t1[e >> 6][e & 63];
+    if (threadIdx.x < 64) s_t2[threadIdx.x] = C.t2t[threadIdx.x >> 3][threadIdx.x & 7];
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane0 = threadIdx.x & 63;
+    int job = blockIdx.x * BR_WAVES + wave;
+    const bool live = job < njobs;
+    if (!live) job = njobs - 1;   // idle wave of the last workgroup: recompute a real job, discard
+
+    u32* acc_lds = s_acc + wave * 2 * NTT_N;
+    fft::cplx* xb = s_xb + (size_t)wave * (fft::XCHG_BYTES / sizeof(fft::cplx));
+    const u32* abar = abar_all + (size_t)job * abar_stride;
+    br_init_acc(lane0 >> 5, lane0 & 31, abar[n], mu, acc_lds + (lane0 >> 5) * NTT_N);
+    lds_sync();
+
+    const fft::Keys keys(bk_fft, bk_bytes, lane0);
+    double worst = 0.0;
+    constexpr int KB_RING = 4, KB_AHEAD = 2;
+    fft::cplx kb[KB_RING][4];
+    auto load_block = [&](fft::cplx (&dst)[4], u32 row_off, int q) {
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) dst[pc] = keys.at(row_off, pc, q);
+    };
+#pragma unroll
+    for (int q = 0; q < KB_AHEAD; ++q) load_block(kb[q], 0u, q);
+    auto mac_row = [&](auto first, fft::cplx (&S)[2][2][8], const fft::cplx (&a)[8], u32 row_off) {
+        constexpr bool FIRST = decltype(first)::value;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) fft::cmac<FIRST>(S[pc >> 1][pc & 1][q], a[q], kb[q % KB_RING][pc]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + KB_RING < 8) load_block(kb[q % KB_RING], row_off, q + KB_RING);
+            else if (q + KB_RING - 8 < KB_AHEAD) load_block(kb[q % KB_RING], row_off + 4u * (u32)fft::M, q + KB_RING - 8);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    u32 ab_next = abar[0];
+    for (u32 i = 0; i < n; ++i) {
+        const u32 ab = ab_next;
+        ab_next = abar[i + 1 < n ? i + 1 : i];
+        // the eight waves of a CU walk the same key rows: kept in step, the CU's L1 serves seven of eight requests (kernels.hpp)
+        if ((i & 15u) == 0u) asm volatile("s_barrier" ::: "memory");
+
+        fft::cplx S[2][2][8];   // [c'][half][k2]
+#pragma unroll
+        for (int e = 0; e < 32; ++e) S[e >> 4][(e >> 3) & 1][e & 7] = {0.0, 0.0};
+        u32 u[16];
+#pragma unroll 1
+        for (int r = 0; r < 2 * L; ++r) {
+            int lane = lane0;
+            asm volatile("" : "+v"(lane));   // keep lane-dependent address math inside the iteration
+            const int c = r >= L ? 1 : 0, lvl = r - c * L;
+            if (lvl == 0) fft::diff16<G>(lane, ab, acc_lds + c * NTT_N, u);
+            fft::cplx a[8];
+            fft::digits8<G>(lvl, u, a);
+            fft_forward(lane, a, C.u, s_t1 + lane, s_t2 + (lane & 7), xb);
+            // MAC against the row's four key spectra, frequency block q = register q.  The key words come through a ring of
+            // KB_RING blocks (4 loads of 16 bytes per lane each): blocks 0 .. KB_AHEAD-1 of this row were issued during the
+            // previous row's MAC and landed during the transform above; the rest are issued one block ahead of their use as
+            // ring slots free up, and the tail of this MAC issues the first blocks of the NEXT row (the rows of all steps are
+            // contiguous; past the last row the buffer descriptor's bounds check returns zeros that nobody uses).
+            const u32 row_off = (i * (u32)(2 * L) + (u32)r) * 4u * (u32)fft::M;
+#pragma unroll
+            for (int q = KB_AHEAD; q < KB_RING; ++q) load_block(kb[q], row_off, q);
+            __builtin_amdgcn_sched_barrier(0);
+            mac_row(std::false_type{}, S, a, row_off);
+        }
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            int lane = lane0;
+            asm volatile("" : "+v"(lane));
+            u32 lo[16];
+            fft_inverse(lane, S[cc][0], C.u, s_t1 + lane, s_t2 + (lane & 7), xb);
+            if (CHECK) {
+                const double e = fft::round_err8(S[cc][0]);
+                worst = e > worst ? e : worst;
+            }
+            fft::round16(S[cc][0], lo);
+            fft_inverse(lane, S[cc][1], C.u, s_t1 + lane, s_t2 + (lane & 7), xb);
+            if (CHECK) {
+                const double e = fft::round_err8(S[cc][1]);
+                worst = e > worst ? e : worst;
+            }
+            fft::acc_update16(lane, S[cc][1], lo, acc_lds + cc * NTT_N);
+        }
+        lds_sync();
+    }
+
+    if (CHECK && max_err_bits) {   // non-negative doubles order like their bit patterns
+        unsigned long long b;
+        __builtin_memcpy(&b, &worst, 8);
+        atomicMax(max_err_bits, b);
+    }
+    if (live) {
+        const int lane = lane0;
+        if (trlwe_mode) {  // raw accumulator: TRLWE (a(X), b(X)), 2N words per job
+            u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (2 * NTT_N);
+            for (int j = lane; j < 2 * NTT_N; j += 64) out[j] = acc_lds[j];
+        }
+        else {             // sample extract at index 0: a'[0] = a[0], a'[j] = -a[N-j], b' = b[0]
+            u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (NTT_N + 1);
+            for (int j = lane; j < NTT_N; j += 64) out[j] = (j == 0) ? acc_lds[0] : 0u - acc_lds[NTT_N - j];
+            if (lane == 0) out[NTT_N] = acc_lds[NTT_N];
+        }
+    }
+}
+
+}  // namespace iyk

@@ -28,7 +28,7 @@ EXPORTS = [
     "iyk_hip_stream_query", "iyk_hip_stream_sync", "iyk_hip_arena_alloc", "iyk_hip_arena_free",
     "iyk_hip_arena_upload", "iyk_hip_arena_download", "iyk_hip_gate_batch", "iyk_hip_gate_host",
     "iyk_hip_blind_rotate_batch", "iyk_hip_last_batch_timing", "iyk_hip_resident_key_bytes",
-    "iyk_hip_timing_log_begin", "iyk_hip_timing_log_end", "iyk_hip_ntt_path", "iyk_hip_decomposition_levels",
+    "iyk_hip_timing_log_begin", "iyk_hip_timing_log_end", "iyk_hip_ntt_path", "iyk_hip_decomposition_levels", "iyk_hip_fft_round_error",
     "iyk_hip_bootstrap_trlwe_batch", "iyk_hip_sample_extract_keyswitch_batch",
     "iyk_hip_stream_gpu", "iyk_hip_arena_upload_slots", "iyk_hip_arena_download_slots", "iyk_hip_arena_copy",
     "iyk_hip_arena_sync_slots", "iyk_hip_trlwe_alloc", "iyk_hip_trlwe_free", "iyk_hip_trlwe_upload",
@@ -84,6 +84,7 @@ def lib():
         L.iyk_hip_sample_extract_keyswitch_batch.argtypes = [_vp, _vp, u64, u64, _i32p, _i32p, _vp, u64]
         L.iyk_hip_last_batch_timing.argtypes = [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
         L.iyk_hip_resident_key_bytes.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+        L.iyk_hip_fft_round_error.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
         L.iyk_hip_timing_log_begin.argtypes = [_vp]
         L.iyk_hip_timing_log_end.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double),
                                              ctypes.POINTER(ctypes.c_double)]
@@ -125,8 +126,16 @@ def resident_key_bytes():
 
 
 def ntt_path():
-    """'fp50' (FP64 FMA field, default for the 128-bit set) or 'goldilocks' (64-bit integer field)."""
-    return "fp50" if _check(lib().iyk_hip_ntt_path(), "iyk_hip_ntt_path") == 1 else "goldilocks"
+    """'fft' (complex FP64 FFT on 16-bit key halves, exact by a rounding bound: the default), 'fp50' (FP64 FMA field) or
+    'goldilocks' (64-bit integer field)."""
+    return {2: "fft", 1: "fp50", 0: "goldilocks"}[_check(lib().iyk_hip_ntt_path(), "iyk_hip_ntt_path")]
+
+
+def fft_round_error(gpu=0):
+    """IYK_HIP_DEBUG=1 at init: largest distance from an integer of any inverse-transform output of the FFT kernel so far."""
+    v = ctypes.c_double()
+    _check(lib().iyk_hip_fft_round_error(int(gpu), ctypes.byref(v)), "iyk_hip_fft_round_error")
+    return v.value
 
 
 def decomposition_levels():

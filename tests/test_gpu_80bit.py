@@ -10,10 +10,14 @@ from iyokan_amd.params import OPS, PLAIN
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("path,kernel,ks", [("fp50", "t16", None), ("fp50", "w32", None), ("fp50", "lat3", None),
-                                            ("goldilocks", None, None), ("fp50", None, "0")])
+NTT_ENV = {"fft": "fft", "fp50": "fp", "goldilocks": "goldilocks"}
+
+
+@pytest.mark.parametrize("path,kernel,ks", [("fft", "fft", None), ("fft", None, None), ("fp50", "t16", None), ("fp50", "w32", None),
+                                            ("fp50", "lat3", None), ("goldilocks", None, None), ("fp50", None, "0")])
 def test_80bit_gates_bit_exact(path, kernel, ks, keys80, oracle80, monkeypatch):
-    """Both exact-arithmetic paths at the 80-bit set: FP64 field with split digits (default; each of its
+    """All three exact paths at the 80-bit set: complex FFT on 16-bit key halves with the 10-bit digits as they are (the
+    default; the FFT kernel forced, and the size-based dispatch), FP64 field with split digits (IYK_HIP_NTT=fp; each of its
     three rotation kernels forced in turn) and the 64-bit integer field (IYK_HIP_NTT=goldilocks); the last case
     forces the workgroup-per-16-gates key switch (the default is the wave-per-16-gates one, t = 8 / 4 chunks of 128 words)."""
     from iyokan_amd import hip
@@ -27,10 +31,7 @@ def test_80bit_gates_bit_exact(path, kernel, ks, keys80, oracle80, monkeypatch):
     else:
         monkeypatch.setenv("IYK_HIP_ROT_KERNEL", kernel)
     old = os.environ.get("IYK_HIP_NTT")
-    if path == "goldilocks":
-        os.environ["IYK_HIP_NTT"] = "goldilocks"
-    else:
-        os.environ.pop("IYK_HIP_NTT", None)
+    os.environ["IYK_HIP_NTT"] = NTT_ENV[path]
     hip.initialize(keys80, device_ids=(0,))
     if old is None:
         os.environ.pop("IYK_HIP_NTT", None)
@@ -67,7 +68,7 @@ def test_80bit_gates_bit_exact(path, kernel, ks, keys80, oracle80, monkeypatch):
     assert list(client.decrypt_bits(keys80, got[16:])) == want
 
 
-@pytest.mark.parametrize("path", ["fp50", "goldilocks"])
+@pytest.mark.parametrize("path", ["fft", "fp50", "goldilocks"])
 def test_80bit_adversarial_rows(path, keys80, oracle80, monkeypatch):
     """Rows no encryption produces (oracle_lib.adversarial_rows) at the 80-bit set, split-digit FP64 field and
     Goldilocks integers: oracle words (digit extremes of the 10-bit decomposition and of its 5-bit halves)."""
@@ -75,11 +76,10 @@ def test_80bit_adversarial_rows(path, keys80, oracle80, monkeypatch):
     from iyokan_amd import hip
 
     monkeypatch.delenv("IYK_HIP_ROT_KERNEL", raising=False)
+    if path == "fft":
+        monkeypatch.setenv("IYK_HIP_ROT_KERNEL", "fft")   # nine gates would go to the narrow-frontier kernel otherwise
     monkeypatch.delenv("IYK_HIP_KS_KERNEL", raising=False)
-    if path == "goldilocks":
-        monkeypatch.setenv("IYK_HIP_NTT", "goldilocks")
-    else:
-        monkeypatch.delenv("IYK_HIP_NTT", raising=False)
+    monkeypatch.setenv("IYK_HIP_NTT", NTT_ENV[path])
     p = keys80.params
     rows = oracle_lib.adversarial_rows(p.n)
     nin = rows.shape[0]

@@ -11,15 +11,16 @@ from iyokan_amd.params import OPS
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("path", ["goldilocks", "fp50"])
-def test_both_field_paths_bit_exact(path, keys128, oracle128):
+@pytest.mark.parametrize("path", ["goldilocks", "fp50", "fft"])
+def test_both_field_paths_bit_exact(path, keys128, oracle128, monkeypatch):
     from iyokan_amd import hip
 
     old = os.environ.get("IYK_HIP_NTT")
-    if path == "goldilocks":
-        os.environ["IYK_HIP_NTT"] = "goldilocks"
+    os.environ["IYK_HIP_NTT"] = {"fft": "fft", "fp50": "fp", "goldilocks": "goldilocks"}[path]
+    if path == "fft":
+        monkeypatch.setenv("IYK_HIP_ROT_KERNEL", "fft")    # 48 rotations: the size-based dispatch would take the narrow-frontier kernel
     else:
-        os.environ.pop("IYK_HIP_NTT", None)
+        monkeypatch.delenv("IYK_HIP_ROT_KERNEL", raising=False)
     try:
         hip.initialize(keys128, device_ids=(0,))
         assert hip.ntt_path() == path

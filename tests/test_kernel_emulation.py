@@ -166,3 +166,85 @@ def test_direct_decomposition_boundary_is_where_the_bound_says(keys80):
     orc.close()
     assert np.array_equal(got[0], ref)
     assert not np.array_equal(got[1], ref)
+
+
+# ---- complex-FFT path (csrc/fft512.hpp, blind_rotate_fft.hpp, kernels_fft.hpp) ----------------------------------------
+def _fft_keys(em, keys):
+    p = keys.params
+    dp = ctypes.POINTER(ctypes.c_double)
+    bk = np.zeros(p.bk_words * 2, dtype=np.float64)      # cplx [polys][2 halves][512] = 2 doubles per key word
+    assert em.iyk_emul_bk_fft(ctypes.byref(p), keys.bk.ctypes.data_as(u32p), bk.ctypes.data_as(dp)) == 0
+    return bk
+
+
+@pytest.mark.parametrize("which", ["128", "80"])
+def test_emulated_fft_path_bit_exact(which, request):
+    """The complex-FFT kernel (key words split into signed 16-bit halves, 512-point FP64 FFT, rint): lane-by-lane emulation
+    == oracle word for word on fresh encryptions AND on the adversarial rows, both parameter sets (the 80-bit set with its
+    10-bit digits as they are — no digit split), and every inverse-transform output within 2^-10 of an integer (the bound
+    DESIGN.md §2b proves; observed: ~2^-20)."""
+    import oracle_lib
+
+    keys = request.getfixturevalue("keys" + which)
+    orc = request.getfixturevalue("oracle" + which)
+    p = keys.params
+    em = _emul()
+    em.iyk_emul_fft_round_error.restype = ctypes.c_double
+    dp = ctypes.POINTER(ctypes.c_double)
+    bk = _fft_keys(em, keys)
+    em.iyk_emul_fft_round_error(1)
+    lins = []
+    for seed, (a, b) in enumerate([(1, 1), (0, 1)]):
+        ca = client.encrypt_bits(keys, [a], seed=270 + seed)[0]
+        cb = client.encrypt_bits(keys, [b], seed=280 + seed)[0]
+        lin = (np.uint32(0) - ca - cb).astype(np.uint32)
+        lin[-1] = np.uint32((int(lin[-1]) + p.mu) & 0xFFFFFFFF)
+        lins.append(lin)
+    rows = oracle_lib.adversarial_rows(p.n)
+    lins += [np.ascontiguousarray(rows[r]) for r in (0, 3, 6, 7)]
+    for lin in lins:
+        got = np.zeros(p.N + 1, dtype=np.uint32)
+        assert em.iyk_emul_blind_rotate_fft(ctypes.byref(p), lin.ctypes.data_as(u32p), bk.ctypes.data_as(dp),
+                                            got.ctypes.data_as(u32p)) == 0
+        assert np.array_equal(orc.bootstrap_lvl1(lin), got)
+    assert 0.0 < em.iyk_emul_fft_round_error(0) < 2.0 ** -10
+
+
+@pytest.mark.parametrize("which", ["128", "80"])
+def test_emulated_fft_path_worst_case_magnitudes(which, request):
+    """The rounding bound's worst case: a 'bootstrapping key' no key generation produces whose every word has BOTH 16-bit
+    halves at -2^15 (0x80008000), or alternates between that and +(2^15 - 1) in both halves, and an LWE row that drives every
+    digit of the first steps to its extreme — the norms ||d|| ||k|| the bound is stated in are attained.  The FFT path still
+    equals the oracle (exact integer arithmetic) word for word, and the distance from an integer stays below 2^-10."""
+    import oracle_lib
+
+    keys = request.getfixturevalue("keys" + which)
+    p = keys.params
+    em = _emul()
+    em.iyk_emul_fft_round_error.restype = ctypes.c_double
+    dp = ctypes.POINTER(ctypes.c_double)
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    for kind in range(3):
+        if kind == 0:
+            bkw = np.full(p.bk_words, 0x80008000, dtype=np.uint32)
+        elif kind == 1:
+            bkw = np.where(rng.integers(0, 2, p.bk_words) == 1, 0x80008000, 0x7FFF7FFF).astype(np.uint32)
+        else:
+            bkw = np.where(np.arange(p.bk_words) % 2 == 1, 0x80008000, 0x7FFF7FFF).astype(np.uint32)
+        bad = client.KeySet(p, keys.s0, keys.s1, bkw, keys.ksk)
+        orc = oracle_lib.Oracle(bad)
+        bk = _fft_keys(em, bad)
+        em.iyk_emul_fft_round_error(1)
+        rows = oracle_lib.adversarial_rows(p.n)
+        lin0 = np.zeros(p.n + 1, dtype=np.uint32)
+        lin0[0] = 0x7FE00000          # abar_0 = 1023: (X^1023 - 1) tv = -2 mu on 1023 coefficients: extreme digits at once
+        lin0[1:8] = 0x33300000
+        for lin in (lin0, np.ascontiguousarray(rows[6]), np.ascontiguousarray(rows[7])):
+            got = np.zeros(p.N + 1, dtype=np.uint32)
+            assert em.iyk_emul_blind_rotate_fft(ctypes.byref(p), lin.ctypes.data_as(u32p), bk.ctypes.data_as(dp),
+                                                got.ctypes.data_as(u32p)) == 0
+            assert np.array_equal(orc.bootstrap_lvl1(lin), got), kind
+        worst = max(worst, em.iyk_emul_fft_round_error(0))
+        orc.close()
+    assert worst < 2.0 ** -10, worst
