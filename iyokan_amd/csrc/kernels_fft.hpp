@@ -14,6 +14,24 @@
 #include "blind_rotate_fft.hpp"
 #include "kernels.hpp"
 
+// A/B knobs of tools/ab_fft_variants.sh (defaults = the shipped kernel).  IYK_FFT_TIMING_* variants compute WRONG results on
+// purpose (they remove one cost to measure it) and never ship.
+#ifndef IYK_FFT_BARRIER_EVERY
+#define IYK_FFT_BARRIER_EVERY 16
+#endif
+#ifndef IYK_FFT_RING
+#define IYK_FFT_RING 4
+#endif
+#ifndef IYK_FFT_AHEAD
+#define IYK_FFT_AHEAD 3
+#endif
+#ifdef IYK_FFT_NO_SCHED_BARRIER
+#define IYK_FFT_SB
+#else
+#define IYK_FFT_SB __builtin_amdgcn_sched_barrier(0)
+#endif
+static_assert(8 % IYK_FFT_RING == 0 && IYK_FFT_AHEAD < IYK_FFT_RING, "the key ring must divide the 8 frequency blocks");
+
 namespace iyk {
 
 static constexpr size_t BR_FFT_T1_BYTES = 8 * 64 * sizeof(fft::cplx);
@@ -22,17 +40,61 @@ static constexpr size_t BR_FFT_LDS_BYTES = BR_FFT_T1_BYTES + (size_t)BR_WAVES * 
 static_assert(BR_FFT_LDS_BYTES <= 160 * 1024, "FFT rotation kernel does not fit the CU's LDS");
 static_assert(BR_FFT_T1_BYTES % 4096 == 0, "diff16 needs every accumulator polynomial 4 KB aligned");
 
+// Twiddle placement.  IYK_FFT_TPREFETCH: the lane constants of a pass (T1: 8, T2: 7 values of 16 bytes from LDS tables) are
+// fetched BEFORE the DFT8 they follow and pinned there by a scheduling barrier, so that they land under its 56 instructions;
+// otherwise the compiler reads each one right before its product and waits for it (registers: 32 / 28 transient VGPRs).
+#ifdef IYK_FFT_TPREFETCH
+#define IYK_FFT_TW_LOAD(tw, n0, expr)                 \
+    _Pragma("unroll") for (int e_ = n0; e_ < 8; ++e_) tw[e_] = (expr); \
+    __builtin_amdgcn_sched_barrier(0)
+#define IYK_FFT_TW(tw, e_, expr) tw[e_]
+#else
+#define IYK_FFT_TW_LOAD(tw, n0, expr)
+#define IYK_FFT_TW(tw, e_, expr) (expr)
+#endif
+
+// `n` pairs of (4 VALU, 1 LDS store): every value goes to LDS as soon as its twiddle product is done, so that the slow
+// 16-byte stores (13 LDS cycles each, in order) run under the remaining products instead of after them (-3 %,
+// profiles/r04_fft_ab.txt)
+template <int N>
+__device__ __forceinline__ void interleave_products_and_stores()
+{
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
+}
+
 // forward transform of 8 complex points per lane from arrangement A to arrangement F through the wave's exchange buffer
 __device__ __forceinline__ void fft_forward(int lane, fft::cplx (&a)[8], const fft::cplx* u, const fft::cplx* t1_lane,
                                             const fft::cplx* t2, fft::cplx* xb)
 {
-    fft::fwd_p1(a, u, t1_lane);
-    fft::x1_put_a(lane, a, xb);
+    fft::cplx tw[8];
+    (void)tw;
+    IYK_FFT_TW_LOAD(tw, 0, t1_lane[64 * e_]);
+#pragma unroll
+    for (int m = 1; m < 8; ++m) a[m] = fft::cmul(a[m], u[m]);
+    fft::dft8<false>(a);
+#pragma unroll
+    for (int k0 = 0; k0 < 8; ++k0) {
+        a[k0] = fft::cmul(a[k0], IYK_FFT_TW(tw, k0, t1_lane[64 * k0]));
+        xb[fft::x1_wbase(lane) + 72 * k0] = a[k0];
+    }
+    interleave_products_and_stores<8>();
     lds_sync();
     fft::x1_get_b(lane, a, xb);
+    IYK_FFT_TW_LOAD(tw, 1, t2[8 * e_]);
     lds_sync();
-    fft::fwd_p2(a, t2);
-    fft::x2_put_b(lane, a, xb);
+    fft::dft8<false>(a);
+    xb[fft::x2_wbase(lane)] = a[0];
+#pragma unroll
+    for (int k1 = 1; k1 < 8; ++k1) {
+        a[k1] = fft::cmul(a[k1], IYK_FFT_TW(tw, k1, t2[8 * k1]));
+        xb[fft::x2_wbase(lane) + 9 * k1] = a[k1];
+    }
+    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    interleave_products_and_stores<7>();
     lds_sync();
     fft::x2_get_c(lane, a, xb);
     lds_sync();
@@ -41,8 +103,18 @@ __device__ __forceinline__ void fft_forward(int lane, fft::cplx (&a)[8], const f
 __device__ __forceinline__ void fft_inverse(int lane, fft::cplx (&a)[8], const fft::cplx* u, const fft::cplx* t1_lane,
                                             const fft::cplx* t2, fft::cplx* xb)
 {
-    fft::inv_p1(a, t2);
-    fft::x2_put_c(lane, a, xb);
+    fft::cplx tw[8];
+    (void)tw;
+    IYK_FFT_TW_LOAD(tw, 1, t2[8 * e_]);
+    fft::dft8<true>(a);
+    xb[fft::x2_rbase(lane)] = a[0];
+#pragma unroll
+    for (int j0 = 1; j0 < 8; ++j0) {
+        a[j0] = fft::cmulc(a[j0], IYK_FFT_TW(tw, j0, t2[8 * j0]));
+        xb[fft::x2_rbase(lane) + j0] = a[j0];
+    }
+    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    interleave_products_and_stores<7>();
     lds_sync();
     fft::x2_get_b(lane, a, xb);
     lds_sync();
@@ -50,8 +122,13 @@ __device__ __forceinline__ void fft_inverse(int lane, fft::cplx (&a)[8], const f
     fft::x1_put_b(lane, a, xb);
     lds_sync();
     fft::x1_get_a(lane, a, xb);
+    IYK_FFT_TW_LOAD(tw, 0, t1_lane[64 * e_]);
     lds_sync();
-    fft::inv_p3(a, u, t1_lane);
+#pragma unroll
+    for (int k0 = 0; k0 < 8; ++k0) a[k0] = fft::cmulc(a[k0], IYK_FFT_TW(tw, k0, t1_lane[64 * k0]));
+    fft::dft8<true>(a);
+#pragma unroll
+    for (int m = 1; m < 8; ++m) a[m] = fft::cmulc(a[m], u[m]);
 }
 
 // BK: [polys][1024] u32 torus -> cplx [polys][2][512]: the spectra of the signed 16-bit halves (lo, hi) of every
@@ -109,7 +186,7 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
 
     const fft::Keys keys(bk_fft, bk_bytes, lane0);
     double worst = 0.0;
-    constexpr int KB_RING = 4, KB_AHEAD = 2;
+    constexpr int KB_RING = IYK_FFT_RING, KB_AHEAD = IYK_FFT_AHEAD;
     fft::cplx kb[KB_RING][4];
     auto load_block = [&](fft::cplx (&dst)[4], u32 row_off, int q) {
 #pragma unroll
@@ -123,10 +200,10 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
         for (int q = 0; q < 8; ++q) {
 #pragma unroll
             for (int pc = 0; pc < 4; ++pc) fft::cmac<FIRST>(S[pc >> 1][pc & 1][q], a[q], kb[q % KB_RING][pc]);
-            __builtin_amdgcn_sched_barrier(0);
+            IYK_FFT_SB;
             if (q + KB_RING < 8) load_block(kb[q % KB_RING], row_off, q + KB_RING);
             else if (q + KB_RING - 8 < KB_AHEAD) load_block(kb[q % KB_RING], row_off + 4u * (u32)fft::M, q + KB_RING - 8);
-            __builtin_amdgcn_sched_barrier(0);
+            IYK_FFT_SB;
         }
     };
 
@@ -135,7 +212,7 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
         const u32 ab = ab_next;
         ab_next = abar[i + 1 < n ? i + 1 : i];
         // the eight waves of a CU walk the same key rows: kept in step, the CU's L1 serves seven of eight requests (kernels.hpp)
-        if ((i & 15u) == 0u) asm volatile("s_barrier" ::: "memory");
+        if (i % (u32)(IYK_FFT_BARRIER_EVERY) == 0u) asm volatile("s_barrier" ::: "memory");
 
         fft::cplx S[2][2][8];   // [c'][half][k2]
 #pragma unroll
@@ -155,7 +232,11 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
             // previous row's MAC and landed during the transform above; the rest are issued one block ahead of their use as
             // ring slots free up, and the tail of this MAC issues the first blocks of the NEXT row (the rows of all steps are
             // contiguous; past the last row the buffer descriptor's bounds check returns zeros that nobody uses).
+#ifdef IYK_FFT_TIMING_L1KEYS
+            const u32 row_off = 0u;
+#else
             const u32 row_off = (i * (u32)(2 * L) + (u32)r) * 4u * (u32)fft::M;
+#endif
 #pragma unroll
             for (int q = KB_AHEAD; q < KB_RING; ++q) load_block(kb[q], row_off, q);
             __builtin_amdgcn_sched_barrier(0);

@@ -12,7 +12,12 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" \
            "SQ_INST_CYCLES_VMEM_RD SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_SMEM" \
            "SQ_WAIT_INST_VMEM SQ_WAIT_INST_SCA SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU" \
-           "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_WAVE32 SQ_WAVES"; do
+           "SQ_INSTS SQ_INSTS_BRANCH SQ_INSTS_WAVE32 SQ_WAVES" \
+           "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TA_TCP_STATE_READ_sum" \
+           "TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum" \
+           "TA_BUSY_avr TA_TA_BUSY_sum TD_TD_BUSY_sum" \
+           "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
+           "GRBM_GUI_ACTIVE"; do
     i=$((i+1))
     d=/tmp/pmc_$tag_$i
     rm -rf $d
