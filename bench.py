@@ -65,9 +65,9 @@ def parse_args():
     return ap.parse_args()
 
 
-COUNTER_FILES = ("r03_counters.json", "r03_counters_80bit.json", "r03_counters_80bit_direct.json", "r02_counters.json",
+COUNTER_FILES = ("r04_counters.json", "r04_counters_80bit.json", "r03_counters.json", "r03_counters_80bit.json", "r03_counters_80bit_direct.json", "r02_counters.json",
                  "r01_traffic.json")  # newest first
-DEFAULT_LEVELS = {"128bit": 3, "80bit": 4}   # iyk_hip_decomposition_levels of counter files older than the field
+DEFAULT_LEVELS = {"128bit": 3, "80bit": 4}   # (r04 files always carry the field: the FFT path runs the 80-bit set at 2)   # iyk_hip_decomposition_levels of counter files older than the field
 
 
 def counters(args, gates, build_id, levels):
@@ -95,6 +95,27 @@ def counters(args, gates, build_id, levels):
         except (OSError, KeyError, ValueError):
             continue
     return None, why
+
+
+def useful_valu_per_step(params, path):
+    """VALU instructions one CMUX step of one rotation NEEDS at the kernel's stated per-operation costs:
+    FFT path: per forward transform 3 DFT8 x 56 + twist 28 + T1 32 + T2 28 + 16 x (bit-field + convert) = 288; per row 8 x 4
+    complex MACs x 4 FMAs = 128; per inverse transform 256, + 3 per coefficient to round, shift and combine; 7 per
+    coefficient for (X^a - 1) acc.  Field paths: radix-2 butterflies of 8 (fp50) / ~30 (Goldilocks) instructions."""
+    rows, N = params.trgsw_rows, params.N            # (k+1) l digit polynomials
+    if path == "fft":
+        return rows * (288 + 128) + 4 * 256 + 3 * 2 * 16 + 7 * 2 * 16
+    per_bfly, per_mac = (8, 7) if path == "fp50" else (30, 30)
+    lanes = 64
+    bflies = (rows + params.k + 1) * (N // 2) * 10
+    return (bflies * per_bfly + (params.k + 1) * rows * N * per_mac) / lanes
+
+
+def key_stream_bytes(params, path):
+    """bytes of bootstrapping key one rotation reads: 8 per key word on the field paths, 2 halves x 8 per word (complex
+    spectra of N/2 points x 16 bytes) on the FFT path"""
+    words = params.n * params.trgsw_rows * (params.k + 1) * params.N
+    return words * (16 if path == "fft" else 8)
 
 
 def shard(total, world, rank):
@@ -358,90 +379,66 @@ def main():
                 "gates_per_step_per_gpu": G_total, "ms_per_step": w_elapsed / args.steps * 1e3, "scaling": "weak"}
 
     if rank == 0:
-        fp_path = hip.ntt_path() == "fp50"
+        path = hip.ntt_path()                         # "fft" (default), "fp50", "goldilocks"
         value = G_total * args.steps / elapsed
         b_gate = params.gate_algorithmic_bytes(rotations=1, inputs=2)
-        # dominant kernel = blind_rotate: its share of B_gate is the BK stream + its own I/O
+        # dominant kernel = blind_rotate: its share of B_gate is the BK stream at 8 bytes per key word + its own I/O
         br_bytes_per_gate = params.n * params.trgsw_rows * (params.k + 1) * params.N * 8 \
             + 2 * (params.n + 1) * 4 + (params.N + 1) * 4
         br_avg_s = (br_ms / max(nb, 1)) * 1e-3
         achieved = br_bytes_per_gate * G_mine / br_avg_s if br_avg_s > 0 else 0.0
         pmc, pmc_why = counters(args, G_mine, hip.build_id(), hip.decomposition_levels())
         traffic = args.traffic_bytes if args.traffic_bytes is not None else (pmc or {}).get("traffic_bytes_per_launch")
-        contract = {   # algorithmic key bytes of the dominant kernel / its launch time against the HBM peak
-            "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_BYTES_PER_S,
+        t_over_a = (traffic / (br_bytes_per_gate * G_mine)) if traffic else None
+        steps_per_launch = G_mine * params.n                  # one wave per rotation, n CMUX steps each
+        capacity = (br_avg_s * 1e9 / VALU_PEAK_NS) * N_SIMDS if br_avg_s > 0 else 0.0   # issue slots of the launch (one per 4 cycles per SIMD at 2.4 GHz)
+        # USEFUL work: the instructions the algorithm needs per CMUX step and wave at the kernel's stated costs (DESIGN.md
+        # section 4.1) — no waits, spills, address arithmetic or table reads — against the same issue capacity
+        useful = useful_valu_per_step(params, path)
+        issue = {
+            "note": "what bounds this kernel: a SIMD issues one instruction of ANY kind per ~4 cycles (DESIGN.md section 8); "
+                    "capacity = 1024 SIMDs x launch time / (4 cycles at 2.4 GHz)",
+            "useful_valu_per_step_per_wave": useful,
+            "useful_frac": (useful * steps_per_launch / capacity) if capacity else None,
         }
-        valu = None
-        if pmc and pmc.get("valu_insts_per_launch") and br_avg_s > 0:
-            insts = pmc["valu_insts_per_launch"]
-            steps_per_launch = G_mine * params.n              # one wave per rotation, n CMUX steps each
-            ns = br_avg_s * 1e9 / (insts / N_SIMDS)
-            valu = {
-                "insts_per_launch": insts,
-                "insts_per_step_per_wave": insts / steps_per_launch,
-                "ns_per_winstr_per_simd": ns,                # live duration / instruction count of the same build
-                "peak_ns": VALU_PEAK_NS,                     # 4 cycles @ 2.4 GHz
-                "frac": VALU_PEAK_NS / ns,
-                "source": pmc["_file"],
-                "build_id": pmc.get("build_id"),
-            }
-            for k in ("lds_insts_per_launch", "vmem_rd_insts_per_launch", "salu_insts_per_launch", "smem_insts_per_launch"):
-                if pmc.get(k):
-                    valu[k] = pmc[k]
+        if pmc and pmc.get("valu_insts_per_launch") and capacity:
+            issue.update({
+                "valu_insts_per_step_per_wave": pmc["valu_insts_per_launch"] / steps_per_launch,
+                "valu_frac": pmc["valu_insts_per_launch"] / capacity,
+                "source": pmc["_file"], "build_id": pmc.get("build_id"),
+            })
             if pmc.get("all_insts_per_launch"):
-                # Issue view: a SIMD issues one instruction of ANY kind per ~4 cycles, so what a
-                # rotation costs is the TOTAL instruction count (SQ_INSTS: VALU, LDS, VMEM, SALU, SMEM, s_waitcnt, branches)
-                allc = pmc["all_insts_per_launch"]
-                ns_all = br_avg_s * 1e9 / (allc / N_SIMDS)
-                valu["issue"] = {
-                    "all_insts_per_step_per_wave": allc / steps_per_launch,
-                    "ns_per_instruction_per_simd": ns_all,
-                    "frac_of_one_per_4_cycles_at_2.4GHz": VALU_PEAK_NS / ns_all,
-                }
-            if pmc.get("sustained_clock_ghz"):               # busy cycles / duration of the profiled launch
-                clk = pmc["sustained_clock_ghz"]
-                valu["sustained_clock_ghz"] = clk
-                valu["frac_at_sustained_clock"] = (4.0 / clk) / ns
-            if pmc.get("issue_ceiling"):                     # what pure instruction streams reach on this chip
-                ic = pmc["issue_ceiling"]
-                share = ic["valu_f64_share"]
-                mix2 = share * ic["fma64_ns_2_waves_per_simd"] + (1 - share) * ic["int32_ns_2_waves_per_simd"]
-                mix4 = share * ic["fma64_ns_4_waves_per_simd"] + (1 - share) * ic["int32_ns_4_waves_per_simd"]
-                valu["stream_ceiling"] = {
-                    "note": "ns per wave-instruction per SIMD of dependency-free v_fma_f64 / v_add_u32 streams in the "
-                            "kernel's FP64 : integer proportion (tools/ubench/valu_occ.hip, 10-26 ms runs)",
-                    "mix_ns_2_waves_per_simd": mix2, "frac_of_2_wave_stream": mix2 / ns,
-                    "mix_ns_4_waves_per_simd": mix4, "frac_of_4_wave_stream": mix4 / ns,
-                }
-        cus = torch.cuda.get_device_properties(dev).multi_processor_count
-        waves_per_cu = hip.rotation_round() // max(cus, 1)     # resident waves of the default wave-per-rotation kernel
-        kernel = ("blind_rotate_fp_t16_kernel" if waves_per_cu == 11 else "blind_rotate_fp_kernel") if fp_path else "blind_rotate_kernel"
+                issue["all_insts_per_step_per_wave"] = pmc["all_insts_per_launch"] / steps_per_launch
+                issue["frac"] = pmc["all_insts_per_launch"] / capacity     # issued instructions of any kind / capacity
+            for k in ("lds_insts_per_launch", "vmem_rd_insts_per_launch", "salu_insts_per_launch", "smem_insts_per_launch",
+                      "sustained_clock_ghz", "l1_requests_per_launch", "l1_to_l2_requests_per_launch", "l2_hit_rate"):
+                if pmc.get(k) is not None:
+                    issue[k] = pmc[k]
+        else:
+            issue["counters_dropped"] = pmc_why
+        kernel = {"fft": "blind_rotate_fft_kernel", "fp50": "blind_rotate_fp_kernel", "goldilocks": "blind_rotate_kernel"}[path]
         roofline = {
-            # achieved / peak / unit / frac describe the BINDING ceiling: VALU issue when the counters of this very build
-            # are at hand (the key stream is served by L2, see traffic_over_algorithmic), else the contract's HBM figure
-            "bound": "valu" if valu else "hbm",
+            # achieved / peak / unit / frac ALWAYS mean the SURVEY 8(d) contract: algorithmic key bytes of the dominant kernel
+            # per launch / its measured launch time against the HBM peak (one meaning per key).  `binding` says
+            # whether that ceiling can bind at all: with the key stream served by L1 / L2 (traffic_over_algorithmic << 1) it
+            # cannot, values above 1 are possible, and the number to read is issue{} — instruction issue, the measured bound.
+            "bound": "hbm",
+            "frac_kind": "contract: SURVEY 8(d) algorithmic bytes / launch time vs 8 TB/s",
             "kernel": kernel,
-            "achieved": (1.0 / valu["ns_per_winstr_per_simd"] * N_SIMDS) if valu else contract["achieved"],
-            "peak": (1.0 / VALU_PEAK_NS * N_SIMDS) if valu else contract["peak"],
-            "unit": "G VALU wave-instructions/s" if valu else "GB/s",
-            "frac": valu["frac"] if valu else contract["frac"],
-            "bound_note": ("VALU issue: SQ_INSTS_VALU of this build (valu.source) / live launch time against 4 cycles per "
-                           "wave-instruction per SIMD at 2.4 GHz; the SURVEY 8(d) contract figure is kept in contract{}"
-                           if valu else "contract figure (algorithmic key bytes / launch time vs HBM peak); the measured bound "
-                           "is VALU issue, but: " + (pmc_why or "no instruction count for this build")),
-            "contract": contract,
-            "contract_frac": contract["frac"],
+            "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_BYTES_PER_S,
+            "binding": (t_over_a >= 0.5) if t_over_a is not None else None,
+            "contract_frac": achieved / HBM_PEAK_BYTES_PER_S,
             "traffic": traffic,
             "algorithmic_bytes_per_launch": br_bytes_per_gate * G_mine,
-            "traffic_over_algorithmic": (traffic / (br_bytes_per_gate * G_mine)) if traffic else None,
+            "key_bytes_streamed_per_rotation": key_stream_bytes(params, path),
+            "traffic_over_algorithmic": t_over_a,
             "measured_hbm_GBps": (traffic / br_avg_s / 1e9) if (traffic and br_avg_s > 0) else None,
             "avg_launch_ms": br_avg_s * 1e3,
             "keyswitch_avg_launch_ms": ks_ms / max(nb, 1),
             "gate_bytes": b_gate,
             "gate_frac": value / world * b_gate / HBM_PEAK_BYTES_PER_S,
-            "valu": valu,
-            "valu_dropped": None if valu else pmc_why,
+            "issue": issue,
             "build_id": hip.build_id(),
         }
         line = {
@@ -457,8 +454,9 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": ("u32 torus; NTT in f64 mod p = 3*2^48+1097729 (exact FMA arithmetic)" if fp_path
-                      else "u32 torus; NTT in u64 mod 2^64-2^32+1"),
+            "dtype": {"fft": "u32 torus; products exact through a 512-point complex f64 FFT on signed 16-bit key halves (rounding bound 2^-10, rint)",
+                      "fp50": "u32 torus; NTT in f64 mod p = 3*2^48+1097729 (exact FMA arithmetic)",
+                      "goldilocks": "u32 torus; NTT in u64 mod 2^64-2^32+1"}[path],
             "data": "synthetic",
             "config": {
                 "workload": f"{G_total} independent Hom{args.op} gates per step (flat DAG), {args.params} params, "

@@ -102,8 +102,13 @@ IYK_HD void dft8(cplx (&x)[8])
 }
 
 // wave-uniform and per-lane constants (host-generated in long double, rounded once: |error| <= 2^-53 per component)
+// the wave-uniform share of the twist, psi^(64 m) = exp(i pi m / 16), m < 8: by the symmetry cos(pi (8 - m) / 16) = sin(pi m / 16)
+// three (cos, sin) pairs carry all of it (m = 4 is (1 + i)/sqrt 2, m = 0 is 1) — 12 SGPRs instead of 32
+struct Twist {
+    double c1, s1, c2, s2, c3, s3;   // cos / sin of pi/16, 2 pi/16, 3 pi/16
+};
 struct Consts {
-    cplx u[8];         // psi^(64 m) = exp(i pi m / 16)
+    Twist u;
     cplx t2t[8][8];    // [b][a]: exp(2 pi i a b / 64) (symmetric in value; the layout says which index a lane owns)
     cplx t1[8][64];    // [k0][L]: psi^(L (4 k0 + 1))
 };
@@ -114,7 +119,7 @@ inline void make_consts(Consts& C)
     auto e = [&](long double num, long double den) {   // exp(i pi num / den)
         return cplx{(double)cosl(pi * num / den), (double)sinl(pi * num / den)};
     };
-    for (int m = 0; m < 8; ++m) C.u[m] = e(m, 16);
+    C.u = {e(1, 16).re, e(1, 16).im, e(2, 16).re, e(2, 16).im, e(3, 16).re, e(3, 16).im};
     for (int a = 0; a < 8; ++a)
         for (int b = 0; b < 8; ++b) C.t2t[b][a] = e(2 * ((a * b) % 64), 64);
     for (int k0 = 0; k0 < 8; ++k0)
@@ -171,12 +176,26 @@ IYK_HD void x2_get_b(int L, cplx (&a)[8], const cplx* xb)
     for (int r = 0; r < 8; ++r) a[r] = xb[x2_wbase(L) + 9 * r];
 }
 
+// a[m] *= psi^(+-64 m), m = 1 .. 7 (INV: the conjugates): 6 general products + one rotation by (1 +- i)/sqrt 2
+template <bool INV>
+IYK_HD void twist8(cplx (&a)[8], const Twist& u)
+{
+    const cplx u1 = {u.c1, u.s1}, u2 = {u.c2, u.s2}, u3 = {u.c3, u.s3}, u5 = {u.s3, u.c3}, u6 = {u.s2, u.c2}, u7 = {u.s1, u.c1};
+    a[1] = INV ? cmulc(a[1], u1) : cmul(a[1], u1);
+    a[2] = INV ? cmulc(a[2], u2) : cmul(a[2], u2);
+    a[3] = INV ? cmulc(a[3], u3) : cmul(a[3], u3);
+    a[4] = INV ? cplx{(a[4].re + a[4].im) * RSQRT2, (a[4].im - a[4].re) * RSQRT2}
+               : cplx{(a[4].re - a[4].im) * RSQRT2, (a[4].re + a[4].im) * RSQRT2};
+    a[5] = INV ? cmulc(a[5], u5) : cmul(a[5], u5);
+    a[6] = INV ? cmulc(a[6], u6) : cmul(a[6], u6);
+    a[7] = INV ? cmulc(a[7], u7) : cmul(a[7], u7);
+}
+
 // ---- the pieces of a transform between the exchanges ------------------------------------------------------------------
 // forward, part 1: uniform twist psi^(64 m), DFT8 over j2, T1 (t1 = this lane's column of Consts::t1: t1[64 * k0])
-IYK_HD void fwd_p1(cplx (&a)[8], const cplx* u, const cplx* t1_lane)
+IYK_HD void fwd_p1(cplx (&a)[8], const Twist& u, const cplx* t1_lane)
 {
-#pragma unroll
-    for (int m = 1; m < 8; ++m) a[m] = cmul(a[m], u[m]);
+    twist8<false>(a, u);
     dft8<false>(a);
 #pragma unroll
     for (int k0 = 0; k0 < 8; ++k0) a[k0] = cmul(a[k0], t1_lane[64 * k0]);
@@ -200,13 +219,12 @@ IYK_HD void inv_p1(cplx (&a)[8], const cplx* t2_lane)
 }
 IYK_HD void inv_p2(cplx (&a)[8]) { dft8<true>(a); }
 // inverse, part 3 (arrangement A, register k0): conj T1, IDFT8 over k0 -> j2, conj psi^(64 j2)
-IYK_HD void inv_p3(cplx (&a)[8], const cplx* u, const cplx* t1_lane)
+IYK_HD void inv_p3(cplx (&a)[8], const Twist& u, const cplx* t1_lane)
 {
 #pragma unroll
     for (int k0 = 0; k0 < 8; ++k0) a[k0] = cmulc(a[k0], t1_lane[64 * k0]);
     dft8<true>(a);
-#pragma unroll
-    for (int m = 1; m < 8; ++m) a[m] = cmulc(a[m], u[m]);
+    twist8<true>(a, u);
 }
 
 // rint(x) mod 2^32 for |x| < 2^51 by the magic-constant addition (one instruction): the low word of x + 1.5 * 2^52

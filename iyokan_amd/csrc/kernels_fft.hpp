@@ -23,7 +23,7 @@
 #define IYK_FFT_RING 4
 #endif
 #ifndef IYK_FFT_AHEAD
-#define IYK_FFT_AHEAD 3
+#define IYK_FFT_AHEAD 2
 #endif
 #ifdef IYK_FFT_NO_SCHED_BARRIER
 #define IYK_FFT_SB
@@ -40,95 +40,102 @@ static constexpr size_t BR_FFT_LDS_BYTES = BR_FFT_T1_BYTES + (size_t)BR_WAVES * 
 static_assert(BR_FFT_LDS_BYTES <= 160 * 1024, "FFT rotation kernel does not fit the CU's LDS");
 static_assert(BR_FFT_T1_BYTES % 4096 == 0, "diff16 needs every accumulator polynomial 4 KB aligned");
 
-// Twiddle placement.  IYK_FFT_TPREFETCH: the lane constants of a pass (T1: 8, T2: 7 values of 16 bytes from LDS tables) are
-// fetched BEFORE the DFT8 they follow and pinned there by a scheduling barrier, so that they land under its 56 instructions;
-// otherwise the compiler reads each one right before its product and waits for it (registers: 32 / 28 transient VGPRs).
-#ifdef IYK_FFT_TPREFETCH
-#define IYK_FFT_TW_LOAD(tw, n0, expr)                 \
-    _Pragma("unroll") for (int e_ = n0; e_ < 8; ++e_) tw[e_] = (expr); \
-    __builtin_amdgcn_sched_barrier(0)
-#define IYK_FFT_TW(tw, e_, expr) tw[e_]
-#else
-#define IYK_FFT_TW_LOAD(tw, n0, expr)
-#define IYK_FFT_TW(tw, e_, expr) (expr)
-#endif
-
-// `n` pairs of (4 VALU, 1 LDS store): every value goes to LDS as soon as its twiddle product is done, so that the slow
-// 16-byte stores (13 LDS cycles each, in order) run under the remaining products instead of after them (-3 %,
-// profiles/r04_fft_ab.txt)
-template <int N>
-__device__ __forceinline__ void interleave_products_and_stores()
+// The lane twiddles of a pass (T1: 8, T2: 7 values of 16 bytes in LDS tables) are read TWO AHEAD of their products: the
+// first two before the DFT8 they follow (they land under its 56 instructions), then one more per product.  Left to the
+// compiler every value was read right before its product and waited for with lgkmcnt(0) — behind the 13-cycle store issued
+// just before it: ~20 k cycles of exposed LDS latency per step and wave.  All of them up front would need 32 more VGPRs
+// than the forward phase has (profiles/r04_fft_ab.txt: tp2 / tp3 spill).  Each product's value goes to LDS as soon as it is
+// done (pattern: 1 LDS read, 4 VALU, 1 LDS store), so the slow 16-byte stores run under the remaining products.
+template <int E0, bool CONJ, class Store>
+__device__ __forceinline__ void twiddle_and_store(fft::cplx (&a)[8], const fft::cplx* tw, int stride, fft::cplx t0, fft::cplx t1,
+                                                  Store store)
 {
 #pragma unroll
-    for (int e = 0; e < N; ++e) {
+    for (int e = E0; e < 8; ++e) {
+        fft::cplx t2 = t1;
+        if (e + 2 < 8) t2 = tw[stride * (e + 2)];
+        a[e] = CONJ ? fft::cmulc(a[e], t0) : fft::cmul(a[e], t0);
+        store(e);
+        t0 = t1;
+        t1 = t2;
+    }
+#pragma unroll
+    for (int e = E0; e < 8; ++e) {
+        if (e + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
         __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
     }
 }
 
 // forward transform of 8 complex points per lane from arrangement A to arrangement F through the wave's exchange buffer
-__device__ __forceinline__ void fft_forward(int lane, fft::cplx (&a)[8], const fft::cplx* u, const fft::cplx* t1_lane,
+__device__ __forceinline__ void fft_forward(int lane, fft::cplx (&a)[8], const fft::Twist& u, const fft::cplx* t1_lane,
                                             const fft::cplx* t2, fft::cplx* xb)
 {
-    fft::cplx tw[8];
-    (void)tw;
-    IYK_FFT_TW_LOAD(tw, 0, t1_lane[64 * e_]);
-#pragma unroll
-    for (int m = 1; m < 8; ++m) a[m] = fft::cmul(a[m], u[m]);
-    fft::dft8<false>(a);
-#pragma unroll
-    for (int k0 = 0; k0 < 8; ++k0) {
-        a[k0] = fft::cmul(a[k0], IYK_FFT_TW(tw, k0, t1_lane[64 * k0]));
-        xb[fft::x1_wbase(lane) + 72 * k0] = a[k0];
+    {
+        const fft::cplx ta = t1_lane[0], tb = t1_lane[64];
+        __builtin_amdgcn_sched_barrier(0);
+        fft::twist8<false>(a, u);
+        fft::dft8<false>(a);
+        twiddle_and_store<0, false>(a, t1_lane, 64, ta, tb, [&](int k0) { xb[fft::x1_wbase(lane) + 72 * k0] = a[k0]; });
     }
-    interleave_products_and_stores<8>();
     lds_sync();
     fft::x1_get_b(lane, a, xb);
-    IYK_FFT_TW_LOAD(tw, 1, t2[8 * e_]);
-    lds_sync();
-    fft::dft8<false>(a);
-    xb[fft::x2_wbase(lane)] = a[0];
-#pragma unroll
-    for (int k1 = 1; k1 < 8; ++k1) {
-        a[k1] = fft::cmul(a[k1], IYK_FFT_TW(tw, k1, t2[8 * k1]));
-        xb[fft::x2_wbase(lane) + 9 * k1] = a[k1];
+    {
+        const fft::cplx ta = t2[8], tb = t2[16];
+        lds_sync();
+        fft::dft8<false>(a);
+        xb[fft::x2_wbase(lane)] = a[0];
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        twiddle_and_store<1, false>(a, t2, 8, ta, tb, [&](int k1) { xb[fft::x2_wbase(lane) + 9 * k1] = a[k1]; });
     }
-    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-    interleave_products_and_stores<7>();
     lds_sync();
     fft::x2_get_c(lane, a, xb);
     lds_sync();
     fft::fwd_p3(a);
 }
-__device__ __forceinline__ void fft_inverse(int lane, fft::cplx (&a)[8], const fft::cplx* u, const fft::cplx* t1_lane,
-                                            const fft::cplx* t2, fft::cplx* xb)
+
+// Two independent inverse transforms (the lo and hi halves of one output polynomial) through ONE exchange buffer, software-
+// pipelined: a wave's LDS operations execute in issue order, so B's stores may be issued right behind A's reads — they cannot
+// overtake them — and A's reads land while B's DFT8 computes, B's while A's next pass computes.  Half of the exchange round
+// trips of the inverse phase disappear behind arithmetic of the same wave (with two waves per SIMD the partner alone cannot
+// hide them: a lone wave issues at ~60 % of the pair's rate).
+__device__ __forceinline__ void fft_inverse2(int lane, fft::cplx (&a)[8], fft::cplx (&b)[8], const fft::Twist& u,
+                                             const fft::cplx* t1_lane, const fft::cplx* t2, fft::cplx* xb)
 {
-    fft::cplx tw[8];
-    (void)tw;
-    IYK_FFT_TW_LOAD(tw, 1, t2[8 * e_]);
-    fft::dft8<true>(a);
-    xb[fft::x2_rbase(lane)] = a[0];
+    auto p1 = [&](fft::cplx (&x)[8]) {
+        const fft::cplx ta = t2[8], tb = t2[16];
+        __builtin_amdgcn_sched_barrier(0);
+        fft::dft8<true>(x);
+        xb[fft::x2_rbase(lane)] = x[0];
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        twiddle_and_store<1, true>(x, t2, 8, ta, tb, [&](int j0) { xb[fft::x2_rbase(lane) + j0] = x[j0]; });
+        lds_sync();
+        fft::x2_get_b(lane, x, xb);
+        lds_sync();
+    };
+    auto p2 = [&](fft::cplx (&x)[8]) {
+        fft::inv_p2(x);
+        fft::x1_put_b(lane, x, xb);
+        lds_sync();
+        fft::x1_get_a(lane, x, xb);
+        lds_sync();
+    };
+    auto p3 = [&](fft::cplx (&x)[8]) {   // the inverse phase has the registers (the dead u[16] and x[8]) for all of T1 at once
+        fft::cplx tw[8];
 #pragma unroll
-    for (int j0 = 1; j0 < 8; ++j0) {
-        a[j0] = fft::cmulc(a[j0], IYK_FFT_TW(tw, j0, t2[8 * j0]));
-        xb[fft::x2_rbase(lane) + j0] = a[j0];
-    }
-    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-    interleave_products_and_stores<7>();
-    lds_sync();
-    fft::x2_get_b(lane, a, xb);
-    lds_sync();
-    fft::inv_p2(a);
-    fft::x1_put_b(lane, a, xb);
-    lds_sync();
-    fft::x1_get_a(lane, a, xb);
-    IYK_FFT_TW_LOAD(tw, 0, t1_lane[64 * e_]);
-    lds_sync();
+        for (int k0 = 0; k0 < 8; ++k0) tw[k0] = t1_lane[64 * k0];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k0 = 0; k0 < 8; ++k0) a[k0] = fft::cmulc(a[k0], IYK_FFT_TW(tw, k0, t1_lane[64 * k0]));
-    fft::dft8<true>(a);
-#pragma unroll
-    for (int m = 1; m < 8; ++m) a[m] = fft::cmulc(a[m], u[m]);
+        for (int k0 = 0; k0 < 8; ++k0) x[k0] = fft::cmulc(x[k0], tw[k0]);
+        fft::dft8<true>(x);
+        fft::twist8<true>(x, u);
+    };
+    p1(a);
+    p1(b);
+    p2(a);
+    p2(b);
+    p3(a);
+    p3(b);
 }
 
 // BK: [polys][1024] u32 torus -> cplx [polys][2][512]: the spectra of the signed 16-bit halves (lo, hi) of every
@@ -186,6 +193,10 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
 
     const fft::Keys keys(bk_fft, bk_bytes, lane0);
     double worst = 0.0;
+    // the uniform twist constants: fetched once and pinned in SGPRs (left alone, the compiler re-reads them with scalar
+    // loads inside the transforms, and a scalar load forces lgkmcnt(0): every LDS operation in flight is waited for)
+    fft::Twist U = C.u;
+    asm volatile("" : "+s"(U.c1), "+s"(U.s1), "+s"(U.c2), "+s"(U.s2), "+s"(U.c3), "+s"(U.s3));
     constexpr int KB_RING = IYK_FFT_RING, KB_AHEAD = IYK_FFT_AHEAD;
     fft::cplx kb[KB_RING][4];
     auto load_block = [&](fft::cplx (&dst)[4], u32 row_off, int q) {
@@ -198,6 +209,13 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
         constexpr bool FIRST = decltype(first)::value;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
+#ifndef IYK_FFT_FINE_WAITS
+            {   // one s_waitcnt for the block's four loads instead of one per load: a wait is an issue slot like any other
+                fft::cplx(&k)[4] = kb[q % KB_RING];
+                asm volatile("" : "+v"(k[0].re), "+v"(k[0].im), "+v"(k[1].re), "+v"(k[1].im), "+v"(k[2].re), "+v"(k[2].im),
+                             "+v"(k[3].re), "+v"(k[3].im));
+            }
+#endif
 #pragma unroll
             for (int pc = 0; pc < 4; ++pc) fft::cmac<FIRST>(S[pc >> 1][pc & 1][q], a[q], kb[q % KB_RING][pc]);
             IYK_FFT_SB;
@@ -226,7 +244,7 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
             if (lvl == 0) fft::diff16<G>(lane, ab, acc_lds + c * NTT_N, u);
             fft::cplx a[8];
             fft::digits8<G>(lvl, u, a);
-            fft_forward(lane, a, C.u, s_t1 + lane, s_t2 + (lane & 7), xb);
+            fft_forward(lane, a, U, s_t1 + lane, s_t2 + (lane & 7), xb);
             // MAC against the row's four key spectra, frequency block q = register q.  The key words come through a ring of
             // KB_RING blocks (4 loads of 16 bytes per lane each): blocks 0 .. KB_AHEAD-1 of this row were issued during the
             // previous row's MAC and landed during the transform above; the rest are issued one block ahead of their use as
@@ -247,17 +265,13 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
             int lane = lane0;
             asm volatile("" : "+v"(lane));
             u32 lo[16];
-            fft_inverse(lane, S[cc][0], C.u, s_t1 + lane, s_t2 + (lane & 7), xb);
+            fft_inverse2(lane, S[cc][0], S[cc][1], U, s_t1 + lane, s_t2 + (lane & 7), xb);
             if (CHECK) {
-                const double e = fft::round_err8(S[cc][0]);
-                worst = e > worst ? e : worst;
+                const double e0 = fft::round_err8(S[cc][0]), e1 = fft::round_err8(S[cc][1]);
+                worst = e0 > worst ? e0 : worst;
+                worst = e1 > worst ? e1 : worst;
             }
             fft::round16(S[cc][0], lo);
-            fft_inverse(lane, S[cc][1], C.u, s_t1 + lane, s_t2 + (lane & 7), xb);
-            if (CHECK) {
-                const double e = fft::round_err8(S[cc][1]);
-                worst = e > worst ? e : worst;
-            }
             fft::acc_update16(lane, S[cc][1], lo, acc_lds + cc * NTT_N);
         }
         lds_sync();

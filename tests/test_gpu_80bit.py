@@ -111,7 +111,8 @@ def test_80bit_adversarial_rows(path, keys80, oracle80, monkeypatch):
 
 def test_80bit_full_size_flat_nand_property(keys80, oracle80):
     """BASELINE config #5 shape at full size: 65 536 independent NANDs at the 80-bit set; every output decrypts to
-    the NAND of its plaintexts, and a 32-gate sample is bit-equal to the oracle."""
+    the NAND of its plaintexts, EVERY output has the oracle's digest (tests/golden/fullsize_nand_80.bin), and a 32-gate sample
+    is bit-equal to the oracle run here."""
     from iyokan_amd import hip
 
     hip.initialize(keys80, device_ids=(0,))
@@ -138,6 +139,9 @@ def test_80bit_full_size_flat_nand_property(keys80, oracle80):
     import numpy_tfhe
 
     numpy_tfhe.check_noise_against_cggi(keys80, got, 1 - (bits[ia] & bits[ib]), rel_tol=0.05)   # noise KAT, 65 536 outputs
+    from test_gpu_parity import _check_fullsize_digests
+
+    _check_fullsize_digests("80", got)       # every one of the 65 536 outputs against the oracle's committed digest
     sample = rng.choice(G, size=32, replace=False)
     ref = np.zeros((nin + 32, p.n + 1), dtype=np.uint32)
     ref[:nin] = enc

@@ -149,7 +149,7 @@ def test_error_codes(gpu, keys128):
     assert L.iyk_hip_cleanup() == -2 and b"streams still alive" in L.iyk_hip_last_error()
     h = ctypes.c_void_p()
     assert L.iyk_hip_stream_create(7, ctypes.byref(h)) == -1                               # gpu_index out of range
-    assert gpu.resident_key_bytes() > 100e6 and gpu.ntt_path() in ("fp50", "goldilocks")
+    assert gpu.resident_key_bytes() > 100e6 and gpu.ntt_path() in ("fft", "fp50", "goldilocks")
     assert L.iyk_hip_stream_gpu(st.h) == 0
     arena.free()
     st.destroy()

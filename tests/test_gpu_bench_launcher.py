@@ -23,7 +23,7 @@ def test_bench_one_gpu_through_the_launcher():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["rccl_world_size"] == 1 and len(line["per_rank_ms_per_step"]) == 1
     assert line["config"]["decrypt_check"] is True and line["value"] > 0
-    assert line["roofline"]["build_id"] and line["roofline"]["contract"]["unit"] == "GB/s"
+    assert line["roofline"]["build_id"] and line["roofline"]["unit"] == "GB/s" and line["roofline"]["issue"]["useful_frac"] > 0
 
 
 def test_bench_refuses_more_gpus_than_visible():

@@ -363,3 +363,70 @@ def test_frontier_two_ranks_one_gpu(gpu, keys128):
         for dec, want in rank_out[1]:
             assert dec == want
     assert got[0][3] == got[1][3] > 0
+
+
+def _twin_run(nl, keys, oracle, drive, clocks, after_first_tick=None):
+    """The same netlist, plan and encryptions through the HIP backend and through the CPU oracle (OracleBackend, test
+    infrastructure), clock by clock; returns both arenas."""
+    import torch
+
+    from oracle_lib import OracleBackend
+
+    plan = FrontierPlan(nl, 1)
+    hb = HipBackend(plan.num_slots, keys.params, torch.device("cuda", 0))
+    ob = OracleBackend(plan.num_slots, oracle)
+    exs = [FrontierExecutor(plan, hb), FrontierExecutor(plan, ob)]
+    zero = client.trivial(keys.params, 0)
+    for be in (hb, ob):
+        be.write_many([plan.slot[i] for i in plan.dffs], np.tile(zero, (len(plan.dffs), 1)))
+    seed = [7000]
+
+    def set_both(port, bit, v):
+        seed[0] += 1
+        row = client.encrypt_bits(keys, [v], seed=seed[0])[0]
+        for ex in exs:
+            ex.set_input(port, bit, row)
+
+    for c in range(clocks):
+        drive(set_both, c)
+        for ex in exs:
+            ex.run()
+        if c + 1 < clocks:
+            for ex in exs:
+                ex.tick()
+            if c == 0 and after_first_tick:
+                after_first_tick(plan, (hb, ob))
+    everything = list(range(plan.num_slots))
+    got, ref = hb.read_many(everything), ob.read_many(everything)
+    hb.close()
+    return plan, got, ref
+
+
+def test_config3_arena_equals_oracle_word_for_word(gpu, keys128, oracle128):
+    """VERDICT r03 next #3b: one clock of BASELINE config #3 (mux-ram-8-16-16, inputs of test08 cycle 0: 18 985 blind rotations
+    in 14 level batches, round + remainder dispatch, both rotation kernels) through the HIP backend and through the oracle on
+    IDENTICAL encryptions: the whole ciphertext arena — every wire of the netlist, not just the decrypted outputs — is equal
+    word for word.  A slot-aliasing or planner bug that still decrypts shows here."""
+    nl = N.load_iyokanl1_json(gold("mux-ram-8-16-16.min.json"))
+    streams = input_streams(load_packet(gold("test08.in")))
+    plan, got, ref = _twin_run(nl, keys128, oracle128, lambda set_enc, c: drive_cycle(set_enc, nl, streams, c), clocks=1)
+    bad = np.nonzero((got != ref).any(axis=1))[0]
+    assert len(bad) == 0, f"{len(bad)} of {plan.num_slots} arena slots differ, first {bad[:8]}"
+    assert (got != 0).any(axis=1).sum() > 13000          # the comparison is not over an empty arena
+
+
+def test_cahp_core_arena_equals_oracle_word_for_word(gpu, keys128, oracle128):
+    """The CAHP-ruby core (4 281 rotations, 41 levels per clock: the narrow-frontier kernel's territory): reset cycle + two
+    clocks, random encrypted inputs, HIP backend vs oracle on identical encryptions — arenas equal word for word after the
+    third evaluation (registers latched twice in between)."""
+    nl = N.load_yosys_json(gold("cahp-ruby-core-yosys.json"))
+    rng = np.random.default_rng(5)
+
+    def drive(set_enc, c):
+        for (port, bit) in sorted(nl.inputs):
+            set_enc(port, bit, int(rng.integers(0, 2)) if port != "reset" else int(c == 0))
+
+    plan, got, ref = _twin_run(nl, keys128, oracle128, drive, clocks=3)
+    bad = np.nonzero((got != ref).any(axis=1))[0]
+    assert len(bad) == 0, f"{len(bad)} of {plan.num_slots} arena slots differ, first {bad[:8]}"
+    assert (got != 0).any(axis=1).sum() > 3000

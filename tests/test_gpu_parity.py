@@ -4,6 +4,7 @@ properties at the full BASELINE size."""
 import hashlib
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -212,8 +213,10 @@ def test_chained_levels_stay_on_device(gpu128, keys128):
 
 
 def test_full_size_flat_nand_property(gpu128, keys128, oracle128):
-    """BASELINE config #2 shape (65 536 independent NANDs, fresh encryptions): every output
-    decrypts to NAND of the plaintexts; a 64-gate sample is bit-equal to the oracle."""
+    """BASELINE config #2 shape (65 536 independent NANDs, fresh encryptions): every output decrypts to NAND of the plaintexts,
+    EVERY output TLWE has the digest the oracle produced for it in the build container (tests/golden/fullsize_nand_128.bin,
+    made by tests/golden/make_fullsize_digests.py on this very workload: word-level parity on all 65 536 outputs), and a
+    64-gate sample is compared with the oracle run here."""
     hip, st = gpu128
     p = keys128.params
     G = 65536
@@ -237,12 +240,30 @@ def test_full_size_flat_nand_property(gpu128, keys128, oracle128):
     import numpy_tfhe
 
     numpy_tfhe.check_noise_against_cggi(keys128, got, want, rel_tol=0.05)
+    _check_fullsize_digests("128", got)
     sample = rng.choice(G, size=64, replace=False)
     ref = np.zeros((nin + 64, p.n + 1), dtype=np.uint32)
     ref[:nin] = enc
     oracle128.gate_batch([OPS["NAND"]] * 64, ia[sample], ib[sample], [-1] * 64,
                          list(range(nin, nin + 64)), ref, nthreads=os.cpu_count() or 1)
     assert np.array_equal(got[sample], ref[nin:])
+
+
+def _check_fullsize_digests(name, got):
+    """every output row against the committed oracle digests (first 8 bytes of sha256 per TLWE) + the checksum of checksums"""
+    import hashlib
+    import json
+
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, golden)
+    import make_fullsize_digests as mk
+
+    want = np.fromfile(os.path.join(golden, f"fullsize_nand_{name}.bin"), dtype=np.uint8).reshape(-1, 8)
+    meta = json.load(open(os.path.join(golden, f"fullsize_nand_{name}.json")))
+    assert len(want) == len(got) == meta["gates"] and hashlib.sha256(want.tobytes()).hexdigest() == meta["sha256_of_digests"]
+    mine = mk.digests(got)
+    bad = np.nonzero((mine != want).any(axis=1))[0]
+    assert len(bad) == 0, f"{len(bad)} of {len(got)} outputs differ from the oracle's words, first at gate {bad[:5]}"
 
 
 def test_all_rotation_kernels_agree(gpu128, keys128, oracle128):

@@ -2,28 +2,26 @@
 # One GPU call at round end (through gpurun): the whole GPU test suite, the three profile rounds (128-bit, 80-bit, 80-bit direct),
 # the netlist benches with both level plans, and the bench lines with the counters just measured.  bash tools/gpu_round.sh <tag>
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
-T=${1:-r03}
+T=${1:-r04}
 timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/${T}_gputests.txt 2>&1
 tail -3 gpurun_out/${T}_gputests.txt
 bash tools/profile_round.sh ${T} > gpurun_out/${T}_profile_round.log 2>&1
 PARAMS=80bit bash tools/profile_round.sh ${T}_80bit > gpurun_out/${T}_80bit_profile_round.log 2>&1
-PARAMS=80bit DECOMP=direct bash tools/profile_round.sh ${T}_80bit_direct > gpurun_out/${T}_80bit_direct_profile_round.log 2>&1
 for net in cahp-ruby cahp-system mux-ram; do timeout 600 python tools/bench_netlist.py --net $net --plan asap 2>/dev/null | tail -1; done > gpurun_out/${T}_bench_netlist.txt
 for net in cahp-ruby cahp-system mux-ram; do timeout 600 python tools/bench_netlist.py --net $net 2>/dev/null | tail -1; done > gpurun_out/${T}_bench_netlist_balanced.txt
 cat gpurun_out/${T}_bench_netlist.txt | cut -c1-200
 python -c "
 import json
-for t in ('${T}','${T}_80bit','${T}_80bit_direct'):
-    d=json.load(open('gpurun_out/%s_bench.json'%t)); print(t, round(d['value']), d['roofline']['bound'], round(d['roofline']['frac'],3), round(d['roofline']['contract_frac'],3), d['cpu_baseline']['value'] if d.get('cpu_baseline') else None)
+for t in ('${T}','${T}_80bit'):
+    d=json.load(open('gpurun_out/%s_bench.json'%t)); print(t, round(d['value']), d['roofline']['bound'], round(d['roofline']['frac'],3), d['roofline']['issue'].get('useful_frac'), d['cpu_baseline']['value'] if d.get('cpu_baseline') else None)
 "
 head -8 gpurun_out/${T}_kernel_trace.txt
 # bench lines WITH the counters just measured (bench.py reads profiles/: copy first)
-cp gpurun_out/${T}_counters.json profiles/r03_counters.json; cp gpurun_out/${T}_80bit_counters.json profiles/r03_counters_80bit.json; cp gpurun_out/${T}_80bit_direct_counters.json profiles/r03_counters_80bit_direct.json
+cp gpurun_out/${T}_counters.json profiles/r04_counters.json; cp gpurun_out/${T}_80bit_counters.json profiles/r04_counters_80bit.json
 python bench.py 2>/dev/null | tail -1 > gpurun_out/${T}_bench_final.json
 python bench.py --params 80bit 2>/dev/null | tail -1 > gpurun_out/${T}_80bit_bench_final.json
-python bench.py --params 80bit --decomp direct 2>/dev/null | tail -1 > gpurun_out/${T}_80bit_direct_bench_final.json
 python -c "
 import json
-for t in ('${T}','${T}_80bit','${T}_80bit_direct'):
-    d=json.load(open('gpurun_out/%s_bench_final.json'%t)); r=d['roofline']; print(t, round(d['value']), r['bound'], round(r['frac'],3), round(r['contract_frac'],3), r.get('valu_dropped'))
+for t in ('${T}','${T}_80bit'):
+    d=json.load(open('gpurun_out/%s_bench_final.json'%t)); r=d['roofline']; print(t, round(d['value']), r['bound'], round(r['frac'],3), r['binding'], r['issue'].get('frac'), r['issue'].get('useful_frac'), r['issue'].get('counters_dropped'))
 "

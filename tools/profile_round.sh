@@ -2,11 +2,11 @@
 # One-shot profile of the headline workload on the GPU box (run through gpurun):
 #   bash tools/profile_round.sh <tag>
 # writes gpurun_out/<tag>_bench.json, <tag>_kernel_trace.txt, <tag>_pmc.txt, <tag>_counters.json
-# (copy the ones to keep into profiles/; bench.py reads profiles/r03_counters.json and uses it only while its build_id —
+# (copy the ones to keep into profiles/; bench.py reads profiles/r04_counters.json and uses it only while its build_id —
 # the hash of the kernel sources, tools/src_hash.py — equals the loaded library's).  Counters are collected in their own
 # --pmc passes, never together with trace domains.  PARAMS=80bit profiles the 80-bit set; DECOMP=direct its opt-in
 # direct decomposition (bench.py --decomp).
-tag=${1:-r03}
+tag=${1:-r04}
 PARAMS=${PARAMS:-128bit}
 DEC=${DECOMP:+--decomp $DECOMP}
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
@@ -20,7 +20,8 @@ fi
   echo "# rocprofv3 --pmc passes, 65536 NAND / launch (bench.py --steps 1 --warmup 0); FETCH/WRITE in KiB (gfx950: double FETCH_SIZE)"
   for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD" \
              "GRBM_GUI_ACTIVE" "SQ_BUSY_CYCLES SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
-             "SQ_INSTS SQ_INSTS_SMEM SQ_INSTS_BRANCH" "SQ_WAVE_CYCLES"; do
+             "SQ_INSTS SQ_INSTS_SMEM SQ_INSTS_BRANCH" "SQ_WAVE_CYCLES" \
+             "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
     rm -rf /tmp/prof_pmc; timeout 300 rocprofv3 --pmc $grp -d /tmp/prof_pmc -o pmc -- python bench.py --params $PARAMS $DEC --steps 1 --warmup 0 --cpu-sample 0 > /tmp/pmc.log 2>&1
     db=$(find /tmp/prof_pmc -name "*.db" 2>/dev/null | head -1)
     if [ -n "$db" ]; then
@@ -33,7 +34,8 @@ import json, re, sys
 sys.path.insert(0, ".")
 from iyokan_amd import hip
 tag, params_name = sys.argv[1], sys.argv[2]
-levels = {"128bit": 3, "80bit": 2 if sys.argv[3] == "direct" else 4}[params_name]   # iyk_hip_decomposition_levels of the profiled run
+import os
+levels = {"128bit": 3, "80bit": 2 if (sys.argv[3] == "direct" or os.environ.get("IYK_HIP_NTT", "fft") == "fft") else 4}[params_name]   # iyk_hip_decomposition_levels of the profiled run
 kname = None
 vals, durs = {}, []
 for line in open(f"gpurun_out/{tag}_pmc.txt"):
@@ -68,7 +70,9 @@ if "FETCH_SIZE" in vals:
                          ("SQ_WAIT_ANY", "SQ_WAIT_ANY"), ("SQ_WAIT_INST_ANY", "SQ_WAIT_INST_ANY"),
                          ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_ANY"), ("SQ_WAVE_CYCLES", "SQ_WAVE_CYCLES"),
                          ("GRBM_GUI_ACTIVE", "GRBM_GUI_ACTIVE"), ("SQ_BUSY_CYCLES", "SQ_BUSY_CYCLES"),
-                         ("SQ_WAVES", "SQ_WAVES")):
+                         ("SQ_WAVES", "SQ_WAVES"), ("TCP_TOTAL_CACHE_ACCESSES_sum", "l1_requests_per_launch"),
+                         ("TCP_TCC_READ_REQ_sum", "l1_to_l2_requests_per_launch"),
+                         ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_BANK_CONFLICT"), ("SQ_LDS_IDX_ACTIVE", "SQ_LDS_IDX_ACTIVE")):
         if k_src in vals:
             out[k_dst] = vals[k_src]
     if durs:
