@@ -239,12 +239,11 @@ int iyk_hip_timing_log_end(iyk_hip_stream* st, uint64_t* batches, double* blind_
  * integers (forced with the environment variable IYK_HIP_NTT=goldilocks at init, or chosen when a
  * parameter set does not meet the FP64 field's exactness bound).  Both give identical ciphertexts.
  *
- * A/B knobs for tests and measurements.  Read at every batch: IYK_HIP_ROT_KERNEL = w32 / t16 / lat3 forces one
- * rotation kernel — w32: a wave per rotation, 32 points per lane, 2 waves per SIMD (the default for full rounds);
- * t16: a wave per rotation, 16 points per lane, 3 waves per SIMD (measured slower, kept selectable); lat3: a workgroup
+ * A/B knobs for tests and measurements.  Read at every batch: IYK_HIP_ROT_KERNEL = fft / w32 / lat3 forces one
+ * rotation kernel — fft: a wave per rotation, complex FFT, 8 points per lane (the default for full rounds); w32: a wave
+ * per rotation on the FP64 field, 32 points per lane (the default for full rounds with IYK_HIP_NTT=fp); lat3: a workgroup
  * of 8 waves per rotation (the default for narrow frontiers).  Unset = chosen by batch size.
- * IYK_HIP_LATENCY_KERNEL = 0 / 3 is the older spelling of w32 / lat3.  Read at init: IYK_HIP_TP_KERNEL = t16 / w32,
- * the wave-per-rotation kernel the size-based dispatch uses.  IYK_HIP_KS_KERNEL = 0 / 1, read at every batch, forces
+ * IYK_HIP_LATENCY_KERNEL = 0 / 3 is the older spelling of w32 / lat3.  IYK_HIP_KS_KERNEL = 0 / 1, read at every batch, forces
  * the key switch with 16 gates per workgroup (3 words per thread) or the one with 16 gates per wave (whole rows per
  * wave; the default where instantiated); both subtract the same rows mod 2^32, so they agree word for word. */
 int iyk_hip_ntt_path(void);
@@ -272,11 +271,33 @@ int iyk_hip_decomposition_levels(void);
  * instruction count is never paired with a duration of a different kernel build. */
 const char* iyk_hip_build_id(void);
 
-/* Rotations one full round of the default wave-per-rotation kernel holds on GPU `gpu_index` (resident waves: 11 per
- * CU for t16, 8 per CU for w32).  A scheduler that can choose its batch sizes does best with multiples of it; the
- * remainder of a batch goes to the workgroup-per-rotation kernel (<= 1280 rotations) or one more partial round.
+/* Rotations one full round of the wave-per-rotation kernel holds on GPU `gpu_index` (8 resident waves per CU).  A scheduler
+ * that can choose its batch sizes does best with multiples of it; the remainder of a batch goes to the workgroup-per-rotation
+ * kernel (up to iyk_level_cost.max_passes passes) or one more partial round.
  * < 0 on error.  (cuFHE has no counterpart: it launches one gate per stream, /root/reference/src/iyokan_cufhe.hpp:249-258.) */
 int iyk_hip_rotation_round(int gpu_index);
+
+/* What a level of `rotations` blind rotations costs one GPU, as iyk_hip_gate_batch dispatches it: full rounds on the
+ * wave-per-rotation kernel, a remainder of up to max_passes * pass rotations in passes of the narrow-frontier kernel (one
+ * rotation per CU and pass), a larger remainder as one more round.  A scheduler that may choose which gates go into which
+ * batch (iyokan_amd/frontier.py: plan_levels; host/iyokan_hip.hpp: planFrontiers) prices its choices with THIS table — the
+ * library owns the only copy of the figures (round 3 had three).  _defaults: compiled-in MI355X figures of this build, no GPU
+ * or initialisation needed; _table / _ms: GPU `gpu_index` of the initialised library (its CU count; measured values once
+ * iyk_hip_calibrate(gpu_index) has run — ~0.15 s, also moves the dispatch's narrow-frontier threshold to the measured
+ * cross-over).  build_id ties a table to the kernels it describes.  No upstream counterpart (cuFHE launches gate by gate). */
+typedef struct iyk_level_cost {
+    int32_t round;        /* rotations per full round of the wave-per-rotation kernel: 8 waves x CUs */
+    int32_t pass;         /* rotations per pass of the narrow-frontier kernel: one per CU */
+    int32_t max_passes;   /* remainders of up to max_passes * pass rotations go to the narrow-frontier kernel */
+    int32_t calibrated;   /* 0: compiled-in figures, 1: measured on this GPU by iyk_hip_calibrate */
+    float round_ms;       /* one round */
+    float pass_ms[8];     /* pass_ms[j]: (j + 1) passes */
+    char build_id[20];
+} iyk_level_cost;
+int iyk_hip_level_cost_defaults(iyk_level_cost* out);
+int iyk_hip_level_cost_table(int gpu_index, iyk_level_cost* out);
+double iyk_hip_level_cost_ms(int gpu_index, int rotations);
+int iyk_hip_calibrate(int gpu_index);
 
 /* Bytes of device memory holding keys on one GPU (NTT-domain BK + padded KSK + tables). */
 int iyk_hip_resident_key_bytes(uint64_t* out);

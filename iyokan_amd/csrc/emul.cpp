@@ -511,140 +511,6 @@ void blind_rotate_fp_lat3(const iyk_params* p, const u32* lin, const double* bk_
     tlwe1[NTT_N] = acc[2 * NTT_N];
 }
 // ---------------------------------------------------------------------------------------------
-// Lane-by-lane emulation of kernels_t16.hpp::blind_rotate_fp_t16_kernel (blind_rotate_t16.hpp): one wave per rotation,
-// one polynomial at a time, 16 points per lane; stage 0 on arrangement P, ONE v_permlane32_swap round, stages 1..4 on
-// arrangement B; in-place u32 transposes (modelled on whole doubles: the two 32-bit rounds move the same words);
-// every lane multiplies its 16 frequencies with the key rows of both output polynomials.
-template <class D>
-void blind_rotate_fp_t16(const iyk_params* p, const u32* lin, const double* bk_ntt, u32* tlwe1)
-{
-    constexpr int L = D::LV;
-    const FpTables& T = fptables();
-    const fp::NttConsts& C = T.t.c;
-    std::vector<double> ztab(fp::ZTAB_ENTRIES);
-    for (int e = 0; e < fp::ZTAB_ENTRIES; ++e) ztab[e] = fp::ztab_entry(e, C.zf);
-    std::vector<u32> acc(2 * NTT_N), xlo(XB_WORDS32), xhi(XB_WORDS32);
-    struct Lane {
-        double x[16], sum[2][16], tw0[8];
-        u32 tb[16];
-    };
-    std::vector<Lane> R(64);
-    auto track1 = [&](double v) {
-        const double a = (v < 0 ? -v : v) / fp::P;
-        if (a > g_fp_maxabs) g_fp_maxabs = a;
-    };
-    auto trackw = [&]() {
-        for (Lane& r : R)
-            for (double v : r.x) track1(v);
-    };
-    // v_permlane32_swap on registers (a[2m], a[2m+1]): upper half of the first <-> lower half of the second
-    auto swap16 = [&]() {
-        for (int m = 0; m < 8; ++m)
-            for (int l = 0; l < 32; ++l) std::swap(R[32 + l].x[2 * m], R[l].x[2 * m + 1]);
-    };
-    auto pass = [&](int which) {
-        for (int lane = 0; lane < 64; ++lane) {
-            if (which == 1) fp::dif16_stage0<fp::PASS1>(R[lane].x, lane >> 5, R[lane].tw0);
-            else fp::dif16_stage0<fp::PASS2>(R[lane].x, lane >> 5, R[lane].tw0);
-        }
-        trackw();
-        swap16();
-        for (int lane = 0; lane < 64; ++lane) {
-            if (which == 1) fp::dif16_stages14<fp::PASS1>(R[lane].x, C.w);
-            else fp::dif16_stages14<fp::PASS2>(R[lane].x, C.w);
-        }
-        trackw();
-    };
-    auto xpose = [&](bool inv) {
-        u32 w[16];
-        for (int round = 0; round < 2; ++round) {
-            std::vector<u32>& xb = round ? xhi : xlo;
-            for (int lane = 0; lane < 64; ++lane) {
-                for (int q = 0; q < 16; ++q) {
-                    const u64 b = fp::d2u(R[lane].x[q]);
-                    w[q] = round ? (u32)(b >> 32) : (u32)b;
-                }
-                if (inv) fp::t16_xpose_write<true>(lane >> 5, lane & 31, w, xb.data());
-                else fp::t16_xpose_write<false>(lane >> 5, lane & 31, w, xb.data());
-            }
-        }
-        for (int lane = 0; lane < 64; ++lane) {
-            u32 lo[16], hi[16];
-            fp::t16_xpose_read(lane >> 5, lane & 31, lo, xlo.data());
-            fp::t16_xpose_read(lane >> 5, lane & 31, hi, xhi.data());
-            for (int e = 0; e < 16; ++e) R[lane].x[e] = fp::u2d(((u64)hi[e] << 32) | lo[e]);
-        }
-    };
-    const u32 bbar = br_modswitch_b(lin[p->n]);
-    for (int lane = 0; lane < 64; ++lane) {
-        const int half = lane >> 5, t = lane & 31;
-        for (int m = 0; m < 8; ++m) R[lane].tw0[m] = C.w[2 * m + half];
-        for (int r = 0; r < 16; ++r) {
-            const int j = t + 32 * (16 * half + r);
-            const u32 idx = ((u32)j - bbar) & (2 * NTT_N - 1);
-            acc[j] = 0u;
-            acc[NTT_N + j] = (idx & NTT_N) ? 0u - p->mu : p->mu;
-        }
-    }
-    for (u32 i = 0; i < p->n; ++i) {
-        const u32 ab = br_modswitch_a(lin[i]);
-        for (int h = 0; h < 2; ++h) {
-            for (int lane = 0; lane < 64; ++lane) fp::t16_diff<D>(lane >> 5, lane & 31, ab, acc.data() + h * NTT_N, R[lane].tb);
-            for (int lvl = 0; lvl < L; ++lvl) {
-                const int row = h * L + lvl;
-                for (int lane = 0; lane < 64; ++lane) fp::t16_digits<D>(lane >> 5, lvl, R[lane].tb, R[lane].x, ztab.data(), C.zf);
-                pass(1);
-                for (int lane = 0; lane < 64; ++lane) fp::t16_fwd_twiddle(lane >> 5, lane & 31, R[lane].x, T.twf_t.data());
-                trackw();
-                xpose(false);
-                pass(2);
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int half = lane >> 5, t = lane & 31;
-                    const fp::T16Keys keys(bk_ntt, 0, half, t);
-                    const u32 poly0 = (i * (u32)(2 * L) + (u32)row) * (u32)(2 * NTT_N);
-                    Lane& r = R[lane];
-                    double kb[fp::T16_KCH][2];
-                    for (int ch = 0; ch < 16 / fp::T16_KCH; ++ch) {
-                        fp::t16_key_load(ch, keys, poly0, kb);
-                        if (row) fp::t16_mac_chunk<false>(ch, r.x, kb, r.sum[0], r.sum[1]);
-                        else fp::t16_mac_chunk<true>(ch, r.x, kb, r.sum[0], r.sum[1]);
-                    }
-                    for (int q = 0; q < 16; ++q) {
-                        track1(r.sum[0][q]);
-                        track1(r.sum[1][q]);
-                    }
-                    if (L > 3 && row == L - 1)
-                        for (int q = 0; q < 16; ++q) {
-                            r.sum[0][q] = fp::norm(r.sum[0][q]);
-                            r.sum[1][q] = fp::norm(r.sum[1][q]);
-                        }
-                }
-            }
-        }
-        for (int c = 0; c < 2; ++c) {
-            for (int lane = 0; lane < 64; ++lane)
-                for (int e = 0; e < 16; ++e) R[lane].x[e] = fp::norm(R[lane].sum[c][fp::t16_sum_pos(e)]);
-            pass(1);
-            for (int lane = 0; lane < 64; ++lane) {
-                double lc[16];
-                fp::t16_inv_twiddle_load(lane >> 5, lane & 31, lc, T.twi_t.data());
-                fp::t16_mul16(R[lane].x, lc);
-            }
-            trackw();
-            xpose(true);
-            pass(2);
-            for (int lane = 0; lane < 64; ++lane) {
-                double lc[16];
-                fp::t16_inv_zeta_load(lane >> 5, lc, C.zi);
-                fp::t16_inv_post(lane >> 5, lane & 31, R[lane].x, lc, acc.data() + c * NTT_N);
-            }
-        }
-    }
-    tlwe1[0] = acc[0];
-    for (u32 j = 1; j < (u32)NTT_N; ++j) tlwe1[j] = 0u - acc[NTT_N - j];
-    tlwe1[NTT_N] = acc[NTT_N];
-}
-
 // ---- complex-FFT path (fft512.hpp, blind_rotate_fft.hpp): lane-by-lane run of kernels_fft.hpp -------------------------
 #define ALL_LANES for (int lane = 0; lane < 64; ++lane)
 const fft::Consts& fft_consts()
@@ -775,16 +641,6 @@ int iyk_emul_blind_rotate_fp_lat3(const iyk_params* p, const uint32_t* lin, cons
     if (p->l == 3 && p->Bgbit == 6) blind_rotate_fp_lat3<fp::Decomp<3, 6, 1>>(p, lin, bk_ntt, tlwe1);
     else if (p->l == 2 && p->Bgbit == 10 && g_direct) blind_rotate_fp_lat3<fp::Decomp<2, 10, 1>>(p, lin, bk_ntt, tlwe1);
     else if (p->l == 2 && p->Bgbit == 10) blind_rotate_fp_lat3<fp::Decomp<2, 10, 2>>(p, lin, bk_ntt, tlwe1);
-    else return -1;
-    return 0;
-}
-
-int iyk_emul_blind_rotate_fp_t16(const iyk_params* p, const uint32_t* lin, const double* bk_ntt, uint32_t* tlwe1)
-{
-    if (p->N != 1024 || p->k != 1) return -1;
-    if (p->l == 3 && p->Bgbit == 6) blind_rotate_fp_t16<fp::Decomp<3, 6, 1>>(p, lin, bk_ntt, tlwe1);
-    else if (p->l == 2 && p->Bgbit == 10 && g_direct) blind_rotate_fp_t16<fp::Decomp<2, 10, 1>>(p, lin, bk_ntt, tlwe1);
-    else if (p->l == 2 && p->Bgbit == 10) blind_rotate_fp_t16<fp::Decomp<2, 10, 2>>(p, lin, bk_ntt, tlwe1);
     else return -1;
     return 0;
 }

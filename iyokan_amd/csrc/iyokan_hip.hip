@@ -26,7 +26,6 @@
 
 #include "../../include/iyokan_hip.h"
 #include "kernels.hpp"
-#include "kernels_t16.hpp"
 #include "kernels_fft.hpp"
 
 using namespace iyk;
@@ -68,6 +67,7 @@ struct Device {
     fft::cplx* bk_fft = nullptr;   // FFT path: key spectra of the signed 16-bit halves (kernels_fft.hpp), 16 bytes per point
     fft::Consts* fftc = nullptr;
     unsigned long long* fft_err = nullptr;  // IYK_HIP_DEBUG: largest |z - rint(z)| seen by the FFT kernel (bits of a double)
+    iyk_level_cost cost{};         // what a level of r rotations costs on this GPU (iyk_hip_level_cost_table)
     void release()
     {
         if (ordinal < 0) return;
@@ -90,6 +90,38 @@ struct Device {
     }
 };
 
+#ifndef IYK_BUILD_ID
+#define IYK_BUILD_ID "unknown"
+#endif
+
+// THE cost table (the only copy of these figures: iyokan_amd/frontier.py and host/iyokan_hip.hpp ask for it through
+// iyk_hip_level_cost_*).  Compiled-in milliseconds: MI355X, 128-bit set, this source revision (profiles/r04_sweep_*.txt);
+// iyk_hip_calibrate() overwrites them with what the GPU at hand measures.  `fft`: the wave-per-rotation kernel of the
+// default path; the field path's round is longer.
+iyk_level_cost default_level_cost(int cus, bool fft)
+{
+    iyk_level_cost c{};
+    c.round = BR_WAVES * cus;
+    c.pass = cus;
+    c.calibrated = 0;
+    c.round_ms = fft ? 15.0f : 19.7f;
+    const float pass_ms[8] = {3.33f, 6.96f, 10.23f, 13.52f, 16.79f, 20.1f, 23.4f, 26.7f};
+    for (int j = 0; j < 8; ++j) c.pass_ms[j] = pass_ms[j];
+    c.max_passes = 0;
+    while (c.max_passes < 8 && c.pass_ms[c.max_passes] < c.round_ms) ++c.max_passes;
+    std::snprintf(c.build_id, sizeof c.build_id, "%s", IYK_BUILD_ID);
+    return c;
+}
+double level_cost_ms(const iyk_level_cost& c, long rot)
+{
+    if (rot <= 0) return 0.0;
+    const long full = rot / c.round, rem = rot % c.round;
+    const double t = (double)c.round_ms * (double)full;
+    if (rem == 0) return t;
+    if (rem <= (long)c.max_passes * c.pass) return t + c.pass_ms[(rem + c.pass - 1) / c.pass - 1];
+    return t + c.round_ms;
+}
+
 struct Global {
     std::mutex mu;
     std::atomic<bool> init{false};
@@ -101,8 +133,6 @@ struct Global {
     bool use_fft = false;         // wave-per-rotation kernel on the complex-FFT path (fft512.hpp); implies use_fp for the narrow-frontier kernel
     size_t bk_fft_bytes = 0;
     int split = 1;                // FP64 path: digit polynomials per gadget level (blind_rotate_fp.hpp Decomp::SPLIT)
-    int lat_threshold = 1280;     // rotations per batch at or below which a workgroup-per-rotation kernel is used
-    int tp_kernel = 32;           // wave-per-rotation kernel: 32 = blind_rotate_fp_kernel (2 waves / SIMD), 16 = blind_rotate_fp_t16_kernel (3 waves / SIMD)
     fp::NttConsts fpc{};
     std::vector<Device> devs;
     std::vector<char> peer;       // [a * ngpu + b]: device a reads device b's memory directly (peer access enabled)
@@ -248,23 +278,6 @@ int launch_br_fft(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
     return IYK_OK;
 }
 
-// the three-waves-per-SIMD wave-per-rotation kernel (kernels_t16.hpp): one workgroup of BR_T16_WAVES waves per CU, jobs
-// dealt round-robin to the resident waves
-template <class DC>
-int launch_br_fp_t16(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
-{
-    const Device& D = G.devs[st->gpu];
-    typedef BrT16<BR_T16_WAVES> M;
-    const int groups = (njobs + M::WAVES - 1) / M::WAVES;
-    dim3 grid((unsigned)(groups < D.cus ? groups : D.cus)), block(M::THREADS);
-    hipLaunchKernelGGL((blind_rotate_fp_t16_kernel<DC, BR_T16_WAVES>), grid, block, M::LDS_BYTES, st->s,
-                       (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE, njobs, (const double*)D.bk_ntt,
-                       (const double*)D.tw_fwd, (const double*)D.tw_inv + NTT_N, D.fpc, o.at(first), G.p.n, G.p.mu,
-                       ABAR_STRIDE, o.trlwe, o.idx(first));
-    HIP_TRY(hipGetLastError());
-    return IYK_OK;
-}
-
 // narrow frontiers: one rotation per workgroup of 8 waves (kernels.hpp, blind_rotate_fp_lat3_kernel)
 template <class DC>
 int launch_br_fp_lat3(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
@@ -278,15 +291,14 @@ int launch_br_fp_lat3(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
     return IYK_OK;
 }
 
-// which rotation kernel a batch is forced onto: IYK_HIP_ROT_KERNEL = w32 / t16 / lat3 (A/B, tests; read per batch).
+// which rotation kernel a batch is forced onto: IYK_HIP_ROT_KERNEL = fft / w32 / lat3 (A/B, tests; read per batch).
 // IYK_HIP_LATENCY_KERNEL = 0 / 3 is the older spelling of w32 / lat3.  0 = no override.
-enum { ROT_AUTO = 0, ROT_W32 = 32, ROT_T16 = 16, ROT_LAT3 = 3, ROT_FFT = 8 };
+enum { ROT_AUTO = 0, ROT_W32 = 32, ROT_LAT3 = 3, ROT_FFT = 8 };
 int forced_rot_kernel()
 {
     if (const char* k = std::getenv("IYK_HIP_ROT_KERNEL")) {
         const std::string v(k);
         if (v == "w32") return ROT_W32;
-        if (v == "t16") return ROT_T16;
         if (v == "lat3") return ROT_LAT3;
         if (v == "fft") return ROT_FFT;
     }
@@ -297,11 +309,11 @@ int forced_rot_kernel()
     return ROT_AUTO;
 }
 
-// Dispatch (profiles/*sweep*): full rounds (one job per resident wave: 8 x CUs on blind_rotate_fp_kernel, 11 x CUs on
-// blind_rotate_fp_t16_kernel) on the wave-per-rotation kernel, a remainder of up to lat_threshold rotations on the
-// workgroup-per-rotation kernel: it takes one CU per rotation, 3.6-4.0 ms per 256 rotations, in sequence (7.5 / 11.1 /
-// 14.6 / 18.5 ms for 512 / 768 / 1024 / 1280); above that one more (partial) round of the wave-per-rotation kernel is
-// faster (profiles/r02_sweep_kernels_v7.txt).
+// Dispatch: full rounds (one job per resident wave: 8 x CUs) on the wave-per-rotation kernel; a remainder of up to
+// max_passes x CUs rotations on the workgroup-per-rotation kernel (one CU per rotation, pass after pass); above that one more
+// (partial) round of the wave-per-rotation kernel is faster.  max_passes and every millisecond a scheduler may want to know
+// come from ONE table, level_cost_of(gpu) below — compiled-in figures of this source revision until iyk_hip_calibrate()
+// replaces them by what this GPU measures.
 template <class DC, class GD>
 int dispatch_fp(iyk_hip_stream* st, int njobs, const RotOut& o)
 {
@@ -313,15 +325,12 @@ int dispatch_fp(iyk_hip_stream* st, int njobs, const RotOut& o)
     }
     if (forced == ROT_LAT3) return launch_br_fp_lat3<DC>(st, 0, njobs, o);
     if (forced == ROT_W32) return launch_br_fp<DC>(st, 0, njobs, o);
-    if (forced == ROT_T16) return launch_br_fp_t16<DC>(st, 0, njobs, o);
-    const bool t16 = G.tp_kernel == 16 && !G.use_fft;
-    const int round = (t16 ? BR_T16_WAVES : BR_WAVES) * G.devs[st->gpu].cus;
+    const int round = BR_WAVES * G.devs[st->gpu].cus;
     const int rem = njobs % round, full = njobs - rem;
     auto tp = [&](int first, int count) {
-        if (G.use_fft) return launch_br_fft<GD>(st, first, count, o);
-        return t16 ? launch_br_fp_t16<DC>(st, first, count, o) : launch_br_fp<DC>(st, first, count, o);
+        return G.use_fft ? launch_br_fft<GD>(st, first, count, o) : launch_br_fp<DC>(st, first, count, o);
     };
-    if (rem > G.lat_threshold) return tp(0, njobs);
+    if (rem > G.devs[st->gpu].cost.max_passes * G.devs[st->gpu].cus) return tp(0, njobs);
     if (full && (rc = tp(0, full))) return rc;
     if (rem) return launch_br_fp_lat3<DC>(st, full, rem, o);
     return IYK_OK;
@@ -413,7 +422,6 @@ int set_fp_attrs()
 {
     int rc;
     if ((rc = set_lds(blind_rotate_fp_kernel<DC>, BR_FP_LDS_BYTES))) return rc;
-    if ((rc = set_lds(blind_rotate_fp_t16_kernel<DC, BR_T16_WAVES>, BrT16<BR_T16_WAVES>::LDS_BYTES))) return rc;
     return set_lds(blind_rotate_fp_lat3_kernel<DC>, BrLat3<DC>::LDS_BYTES);
 }
 template <class GD>
@@ -548,6 +556,7 @@ int init_devices(std::vector<Device>& devs, const int* device_ids, int avail, co
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipDeviceSynchronize());
+        D.cost = default_level_cost(D.cus, use_fft);
     }
     return IYK_OK;
 }
@@ -658,9 +667,6 @@ int iyk_hip_fft_round_error(int gpu_index, double* out)
 /* digit polynomials per accumulator polynomial and CMUX step: l, or 2 l where the FP64 path splits every digit */
 int iyk_hip_decomposition_levels(void) { return G.init.load() ? (int)G.p.l * (G.use_fp && !G.use_fft ? G.split : 1) : IYK_ERR_STATE; }
 
-#ifndef IYK_BUILD_ID
-#define IYK_BUILD_ID "unknown"
-#endif
 /* first 16 hex digits of the SHA-256 over the sources this library was built from (tools/src_hash.py) */
 const char* iyk_hip_build_id(void) { return IYK_BUILD_ID; }
 
@@ -668,7 +674,98 @@ int iyk_hip_rotation_round(int gpu_index)
 {
     if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
     if (gpu_index < 0 || gpu_index >= (int)G.devs.size()) return fail(IYK_ERR_INVALID, "gpu_index out of range");
-    return (G.use_fp && !G.use_fft && G.tp_kernel == 16 ? BR_T16_WAVES : BR_WAVES) * G.devs[gpu_index].cus;
+    return BR_WAVES * G.devs[gpu_index].cus;
+}
+
+int iyk_hip_level_cost_defaults(iyk_level_cost* out)
+{
+    if (!out) return fail(IYK_ERR_INVALID, "null out");
+    *out = default_level_cost(256, true);
+    return IYK_OK;
+}
+
+int iyk_hip_level_cost_table(int gpu_index, iyk_level_cost* out)
+{
+    if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
+    if (gpu_index < 0 || gpu_index >= (int)G.devs.size() || !out) return fail(IYK_ERR_INVALID, "gpu_index out of range / null out");
+    *out = G.devs[gpu_index].cost;
+    return IYK_OK;
+}
+
+double iyk_hip_level_cost_ms(int gpu_index, int rotations)
+{
+    if (!G.init.load() || gpu_index < 0 || gpu_index >= (int)G.devs.size()) return level_cost_ms(default_level_cost(256, true), rotations);
+    return level_cost_ms(G.devs[gpu_index].cost, rotations);
+}
+
+/* ~0.15 s: one warm-up + one timed full round of the wave-per-rotation kernel and 1 .. 8 passes of the narrow-frontier kernel
+ * on all-zero rows (every kernel runs all n CMUX steps whatever the row holds), HIP events on a private stream.  The table of
+ * GPU `gpu_index` then holds measured milliseconds, and the dispatch's narrow-frontier threshold follows it (the largest
+ * number of passes still cheaper than one more round). */
+int iyk_hip_calibrate(int gpu_index)
+{
+    IYK_API_BEGIN
+    if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
+    if (gpu_index < 0 || gpu_index >= (int)G.devs.size()) return fail(IYK_ERR_INVALID, "gpu_index out of range");
+    if (!G.use_fp) return IYK_OK;   // integer path: one kernel, no dispatch choice; the defaults stay
+    iyk_hip_stream* st = nullptr;
+    int rc = stream_new(gpu_index, nullptr, false, &st);
+    if (rc) return rc;
+    Device& D = G.devs[gpu_index];
+    iyk_level_cost c = D.cost;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto done = [&](int code) {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        (void)hipStreamSynchronize(st->s);
+        destroy_stream_resources(st);
+        delete st;
+        G.nstreams.fetch_sub(1);
+        return code;
+    };
+    if ((rc = ensure_rot(st, (size_t)c.round))) return done(rc);
+    if (hipMemsetAsync(st->d_abar, 0, (size_t)c.round * ABAR_STRIDE * sizeof(u32), st->s) != hipSuccess ||
+        hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+        return done(fail(IYK_ERR_HIP, "calibration set-up failed"));
+    const RotOut o{st->d_rot, nullptr, 0};
+    auto timed = [&](auto launch, float* ms) -> int {
+        if (hipEventRecord(e0, st->s) != hipSuccess) return fail(IYK_ERR_HIP, "hipEventRecord");
+        int r = launch();
+        if (r) return r;
+        if (hipEventRecord(e1, st->s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+            hipEventElapsedTime(ms, e0, e1) != hipSuccess)
+            return fail(IYK_ERR_HIP, "calibration timing failed");
+        return IYK_OK;
+    };
+    auto tp = [&](int count) {
+        if (G.p.l == 3) return G.use_fft ? launch_br_fft<fft::Gadget<3, 6>>(st, 0, count, o) : launch_br_fp<fp::Decomp<3, 6, 1>>(st, 0, count, o);
+        if (G.use_fft) return launch_br_fft<fft::Gadget<2, 10>>(st, 0, count, o);
+        return G.split == 1 ? launch_br_fp<fp::Decomp<2, 10, 1>>(st, 0, count, o) : launch_br_fp<fp::Decomp<2, 10, 2>>(st, 0, count, o);
+    };
+    auto lat = [&](int count) {
+        if (G.p.l == 3) return launch_br_fp_lat3<fp::Decomp<3, 6, 1>>(st, 0, count, o);
+        return G.split == 1 ? launch_br_fp_lat3<fp::Decomp<2, 10, 1>>(st, 0, count, o) : launch_br_fp_lat3<fp::Decomp<2, 10, 2>>(st, 0, count, o);
+    };
+    float ms = 0.f;
+    if ((rc = timed([&] { return tp(c.round); }, &ms))) return done(rc);   // warm-up (clocks, caches, code upload)
+    if ((rc = timed([&] { return tp(c.round); }, &c.round_ms))) return done(rc);
+    if ((rc = timed([&] { return lat(c.pass); }, &ms))) return done(rc);
+    for (int j = 0; j < 8; ++j) {
+        if ((rc = timed([&] { return lat((j + 1) * c.pass); }, &c.pass_ms[j]))) return done(rc);
+        if (c.pass_ms[j] > 1.25f * c.round_ms) {   // far beyond the cross-over: extrapolate the rest, do not spend the time
+            for (int k = j + 1; k < 8; ++k) c.pass_ms[k] = c.pass_ms[j] * (float)(k + 1) / (float)(j + 1);
+            break;
+        }
+    }
+    c.max_passes = 0;
+    while (c.max_passes < 8 && c.pass_ms[c.max_passes] < c.round_ms) ++c.max_passes;
+    c.calibrated = 1;
+    {
+        std::lock_guard<std::mutex> lock(G.mu);
+        D.cost = c;
+    }
+    return done(IYK_OK);
+    IYK_API_END
 }
 
 int iyk_hip_resident_key_bytes(uint64_t* out)
@@ -777,10 +874,8 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
             (void)hipGetLastError();
         }
     const char* dbg = std::getenv("IYK_HIP_DEBUG");
-    const char* tk = std::getenv("IYK_HIP_TP_KERNEL");  // w32 / t16: the wave-per-rotation kernel of the size-based dispatch
     G.ks_kernel = 1;
     G.debug = dbg && dbg[0] == '1';
-    G.tp_kernel = (tk && std::string(tk) == "t16") ? 16 : 32;
     G.p = p;
     G.use_fp = use_fp;
     G.use_fft = use_fft;

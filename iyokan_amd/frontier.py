@@ -25,30 +25,61 @@ from .netlist import BINARY
 from .params import OPS
 
 
-def make_level_cost(rotation_round=2048):
-    """Milliseconds one rank spends on a level of r blind rotations, as the dispatch of csrc/iyokan_hip.hip prices it
-    (profiles/r03_sweep_lat3.txt, r03_kernel_trace.txt): full rounds of `rotation_round` (iyk_hip_rotation_round: 8 waves on
-    each CU, 2048 on an MI355X) on the wave-per-rotation kernel at 19.7 ms; a remainder of up to five passes of the
-    workgroup-per-rotation kernel, one rotation per CU and pass; a larger remainder is one more full round.  Only the SHAPE
-    matters to the planner (where the steps are), not the milliseconds."""
-    cus = rotation_round // 8
+def make_level_cost(table=None):
+    """Milliseconds one rank spends on a level of r blind rotations, as the dispatch of csrc/iyokan_hip.hip prices it: full
+    rounds on the wave-per-rotation kernel, a remainder of up to max_passes passes of the workgroup-per-rotation kernel (one
+    rotation per CU and pass), a larger remainder as one more full round.  The FIGURES are the library's (include/
+    iyokan_hip.h: iyk_level_cost; this module holds none): `table` = hip.level_cost_table(gpu) / hip.calibrate(gpu) on a
+    GPU, default hip.level_cost_defaults() — the compiled-in MI355X table of the loaded build, readable without a GPU.
+    Only the SHAPE matters to the planner (where the steps are), not the milliseconds."""
+    if table is None:
+        from . import hip
+
+        table = hip.level_cost_defaults()
+    rnd, pas, maxp = int(table["round"]), int(table["pass"]), int(table["max_passes"])
+    round_ms, pass_ms = float(table["round_ms"]), [float(v) for v in table["pass_ms"]]
 
     def cost(rotations):
         if rotations <= 0:
             return 0.0
-        full, rem = divmod(rotations, rotation_round)
-        t = 19.7 * full
+        full, rem = divmod(rotations, rnd)
+        t = round_ms * full
         if rem == 0:
             return t
-        if rem <= 5 * cus:
-            return t + (3.33, 6.96, 10.23, 13.52, 16.79)[-(-rem // cus) - 1]
-        return t + 19.7
+        if rem <= maxp * pas:
+            return t + pass_ms[-(-rem // pas) - 1]
+        return t + round_ms
 
-    cost.quanta = (rotation_round, cus)
+    cost.quanta = (rnd, pas)
+    cost.table = table
     return cost
 
 
-mi355x_level_cost = make_level_cost(2048)
+class _DefaultCost:
+    """make_level_cost() of the library's compiled-in table, resolved at first use (importing this module must not need
+    the shared library)."""
+
+    def __init__(self):
+        self._f = None
+
+    def _get(self):
+        if self._f is None:
+            self._f = make_level_cost()
+        return self._f
+
+    def __call__(self, rotations):
+        return self._get()(rotations)
+
+    @property
+    def quanta(self):
+        return self._get().quanta
+
+    @property
+    def table(self):
+        return self._get().table
+
+
+mi355x_level_cost = _DefaultCost()
 
 
 def level_rotations(nl, levels, world=1):
@@ -151,7 +182,7 @@ def beam_levels(nl, world=1, cost=mi355x_level_cost, width=6):
     return best[4]
 
 
-def balanced_levels(nl, world=1, cost=mi355x_level_cost, quanta=(2048, 256)):
+def balanced_levels(nl, world=1, cost=mi355x_level_cost, quanta=None):
     """The per-clock DAG in as many levels as netlist.levelise() gives (the critical path is not stretched, so the number of
     level-boundary exchanges is the same), with every gate that has SLACK placed where it costs least.
 
@@ -162,6 +193,8 @@ def balanced_levels(nl, world=1, cost=mi355x_level_cost, quanta=(2048, 256)):
     ALAP level is now MUST run; beyond them the level is cut at the multiple of 256 / 2048 rotations (per rank) that gives
     the lowest time per rotation, and the rest waits.  NOT / CONST cost nothing and run as soon as their input exists.
     Any cut yields a valid schedule (a deferred gate's successors are deferred with it and all have the slack)."""
+    if quanta is None:
+        quanta = getattr(cost, "quanta", (2048, 256))
     asap = nl.levelise()
     depth = len(asap)
     n = nl.num_nodes
@@ -417,10 +450,15 @@ class FrontierExecutor:
                 if L["B"] == 0:
                     continue
                 be.gate_batch(*L["rank_desc"][self.rank])
-                if w > 1:
+                if self.dist is not None:
+                    # The level's one exchange, IN PLACE on the arena: the slot layout puts rank r's outputs of this level at
+                    # [base + r B, base + (r + 1) B), so the rank's block is already where the gathered tensor wants it (RCCL's
+                    # in-place all-gather: send buffer = receive buffer + rank * count; no staging copy).  Issued whenever a
+                    # process group exists — with ONE rank too, so that the 1-GPU boxes this is developed on execute the very
+                    # collective the 8-GPU run depends on (tests/test_gpu_bench_launcher.py asserts it ran).
                     lo, B = L["base"], L["B"]
                     whole = be.arena[lo: lo + w * B]
-                    mine = be.arena[lo + self.rank * B: lo + (self.rank + 1) * B].clone()
+                    mine = be.arena[lo + self.rank * B: lo + (self.rank + 1) * B]
                     self._all_gather(whole, mine)
                     self.collectives += 1
 
@@ -428,9 +466,9 @@ class FrontierExecutor:
         """RCCL all_gather_into_tensor on the device arena.  Test rigs with ONE GPU run the ranks as processes sharing that
         GPU over gloo (RCCL refuses two ranks on one device; gloo has no device all-gather): the same per-level exchange,
         staged through the host — every other line of the sharded path (plans, per-rank batches, slot layout) is the product's."""
-        if whole.is_cuda and self.dist.get_backend() == "gloo":
+        if self.dist.get_backend() == "gloo":
             host = whole.new_empty(whole.shape, device="cpu")
-            self.dist.all_gather_into_tensor(host, mine.cpu())
+            self.dist.all_gather_into_tensor(host, mine.cpu().clone())
             whole.copy_(host)
         else:
             self.dist.all_gather_into_tensor(whole, mine)

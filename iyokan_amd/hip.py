@@ -28,7 +28,8 @@ EXPORTS = [
     "iyk_hip_stream_query", "iyk_hip_stream_sync", "iyk_hip_arena_alloc", "iyk_hip_arena_free",
     "iyk_hip_arena_upload", "iyk_hip_arena_download", "iyk_hip_gate_batch", "iyk_hip_gate_host",
     "iyk_hip_blind_rotate_batch", "iyk_hip_last_batch_timing", "iyk_hip_resident_key_bytes",
-    "iyk_hip_timing_log_begin", "iyk_hip_timing_log_end", "iyk_hip_ntt_path", "iyk_hip_decomposition_levels", "iyk_hip_fft_round_error",
+    "iyk_hip_timing_log_begin", "iyk_hip_timing_log_end", "iyk_hip_ntt_path", "iyk_hip_decomposition_levels", "iyk_hip_fft_round_error", "iyk_hip_level_cost_defaults", "iyk_hip_level_cost_table",
+    "iyk_hip_level_cost_ms", "iyk_hip_calibrate",
     "iyk_hip_bootstrap_trlwe_batch", "iyk_hip_sample_extract_keyswitch_batch",
     "iyk_hip_stream_gpu", "iyk_hip_arena_upload_slots", "iyk_hip_arena_download_slots", "iyk_hip_arena_copy",
     "iyk_hip_arena_sync_slots", "iyk_hip_trlwe_alloc", "iyk_hip_trlwe_free", "iyk_hip_trlwe_upload",
@@ -84,6 +85,8 @@ def lib():
         L.iyk_hip_sample_extract_keyswitch_batch.argtypes = [_vp, _vp, u64, u64, _i32p, _i32p, _vp, u64]
         L.iyk_hip_last_batch_timing.argtypes = [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
         L.iyk_hip_resident_key_bytes.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+        L.iyk_hip_level_cost_ms.restype = ctypes.c_double
+        L.iyk_hip_level_cost_ms.argtypes = [ctypes.c_int, ctypes.c_int]
         L.iyk_hip_fft_round_error.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
         L.iyk_hip_timing_log_begin.argtypes = [_vp]
         L.iyk_hip_timing_log_end.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double),
@@ -154,6 +157,37 @@ def build_id():
 def peer_access(gpu_a, gpu_b):
     """True when GPU a reads GPU b's memory directly (peer access enabled at init), False when copies are host-staged."""
     return _check(lib().iyk_hip_peer_access(int(gpu_a), int(gpu_b)), "iyk_hip_peer_access") == 1
+
+
+class IykLevelCost(ctypes.Structure):
+    """include/iyokan_hip.h: iyk_level_cost — what a level of r rotations costs one GPU (the library's only copy)."""
+    _fields_ = [("round", ctypes.c_int32), ("pass_", ctypes.c_int32), ("max_passes", ctypes.c_int32),
+                ("calibrated", ctypes.c_int32), ("round_ms", ctypes.c_float), ("pass_ms", ctypes.c_float * 8),
+                ("build_id", ctypes.c_char * 20)]
+
+    def as_dict(self):
+        return {"round": self.round, "pass": self.pass_, "max_passes": self.max_passes, "calibrated": bool(self.calibrated),
+                "round_ms": float(self.round_ms), "pass_ms": [float(v) for v in self.pass_ms], "build_id": self.build_id.decode()}
+
+
+def level_cost_defaults():
+    """The compiled-in MI355X cost table of the loaded library (no GPU, no initialisation needed)."""
+    c = IykLevelCost()
+    _check(lib().iyk_hip_level_cost_defaults(ctypes.byref(c)), "iyk_hip_level_cost_defaults")
+    return c.as_dict()
+
+
+def level_cost_table(gpu=0):
+    """GPU `gpu`'s cost table: its CU count, measured milliseconds once calibrate(gpu) has run."""
+    c = IykLevelCost()
+    _check(lib().iyk_hip_level_cost_table(int(gpu), ctypes.byref(c)), "iyk_hip_level_cost_table")
+    return c.as_dict()
+
+
+def calibrate(gpu=0):
+    """~0.15 s self-calibration of the cost table (and of the dispatch's narrow-frontier threshold) on GPU `gpu`."""
+    _check(lib().iyk_hip_calibrate(int(gpu)), "iyk_hip_calibrate")
+    return level_cost_table(gpu)
 
 
 def rotation_round(gpu=0):

@@ -453,26 +453,20 @@ using HIPNetwork = TaskNetwork<HIPWorkerInfo>;
 // The batching worker.  update(): (1) drain the ready frontier, deal it to the GPUs, launch one batch per GPU and
 // enqueue the device-to-device exchange of every GPU's outputs; (2) when all streams are idle, propagate every
 // node of that frontier.
-// Milliseconds one GPU spends on `rot` blind rotations of one batch, as iyk_hip_gate_batch dispatches them on an MI355X:
-// rounds of 2048 on the wave-per-rotation kernel, a remainder of up to 1280 in passes of 256 on the
-// workgroup-per-rotation kernel, a larger one in one more round (profiles/r03_sweep_lat3.txt; only the position of the
-// steps matters).  Same function as iyokan_amd/frontier.py: mi355x_level_cost.
-inline long rotationRound()  // 8 waves on every CU of GPU 0 (2048 on an MI355X); 2048 before the library is initialised
+// Milliseconds one GPU spends on `rot` blind rotations of one batch, as iyk_hip_gate_batch dispatches them: asked of the
+// LIBRARY (iyk_hip_level_cost_*: rounds on the wave-per-rotation kernel, a remainder in passes of the workgroup-per-rotation
+// kernel, a larger one in one more round) — the figures live in csrc/iyokan_hip.hip only, measured ones once
+// iyk_hip_calibrate() has run.  Never cached here: before iyk_hip_init the library answers with its compiled-in MI355X table,
+// afterwards with GPU 0's (round 3 cached the first answer for the whole process).
+inline iyk_level_cost levelCostTable()
 {
-    static const long r = [] { const int v = iyk_hip_rotation_round(0); return v > 0 ? (long)v : 2048L; }();
-    return r;
+    iyk_level_cost c{};
+    if (iyk_hip_level_cost_table(0, &c) != IYK_OK) (void)iyk_hip_level_cost_defaults(&c);
+    return c;
 }
-inline double levelCostMs(long rot)
-{
-    if (rot <= 0) return 0.0;
-    static const double pass[5] = {3.33, 6.96, 10.23, 13.52, 16.79};
-    const long round = rotationRound(), cus = round / 8;
-    const long full = rot / round, rem = rot % round;
-    double t = 19.7 * (double)full;
-    if (rem == 0) return t;
-    if (rem <= 5 * cus) return t + pass[(rem + cus - 1) / cus - 1];
-    return t + 19.7;
-}
+inline long rotationRound() { return (long)levelCostTable().round; }
+inline long rotationPass() { return (long)levelCostTable().pass; }
+inline double levelCostMs(long rot) { return iyk_hip_level_cost_ms(0, (int)rot); }
 
 // Static plan of a clock: the frontier (0, 1, ...) in which every task starts.  Same search as iyokan_amd/frontier.py
 // beam_levels: frontier by frontier, the ready gates sorted by their latest frontier (depth - 1 - upward rank: later would
@@ -509,7 +503,7 @@ class HIPWorker : public Worker<HIPWorkerInfo> {
         if (total == 0 || crit == 0) return;
         long cut = total;
         double best = levelCostMs((total + G - 1) / G) / (double)total;
-        for (long q : {rotationRound() * G, rotationRound() / 8 * G}) {
+        for (long q : {rotationRound() * G, rotationPass() * G}) {
             const long c = (total / q) * q;
             if (c < must || c <= 0 || c == total) continue;
             const double v = levelCostMs((c + G - 1) / G) / (double)c;
@@ -663,7 +657,7 @@ inline std::vector<int> planFrontiers(TaskNetwork<HIPWorkerInfo>& net, int G, in
             }
             std::vector<long> cuts{total};
             if (total && k + 1 < depth)
-                for (long q : {rotationRound() * G, rotationRound() / 8 * G})
+                for (long q : {rotationRound() * G, rotationPass() * G})
                     for (long c : {(total / q) * q, (total / q) * q - q})
                         if (c >= must && c > 0 && std::find(cuts.begin(), cuts.end(), c) == cuts.end()) cuts.push_back(c);
             for (long cut : cuts) {

@@ -13,12 +13,12 @@ pytestmark = pytest.mark.gpu
 NTT_ENV = {"fft": "fft", "fp50": "fp", "goldilocks": "goldilocks"}
 
 
-@pytest.mark.parametrize("path,kernel,ks", [("fft", "fft", None), ("fft", None, None), ("fp50", "t16", None), ("fp50", "w32", None),
+@pytest.mark.parametrize("path,kernel,ks", [("fft", "fft", None), ("fft", None, None), ("fp50", "w32", None),
                                             ("fp50", "lat3", None), ("goldilocks", None, None), ("fp50", None, "0")])
 def test_80bit_gates_bit_exact(path, kernel, ks, keys80, oracle80, monkeypatch):
     """All three exact paths at the 80-bit set: complex FFT on 16-bit key halves with the 10-bit digits as they are (the
     default; the FFT kernel forced, and the size-based dispatch), FP64 field with split digits (IYK_HIP_NTT=fp; each of its
-    three rotation kernels forced in turn) and the 64-bit integer field (IYK_HIP_NTT=goldilocks); the last case
+    two rotation kernels forced in turn) and the 64-bit integer field (IYK_HIP_NTT=goldilocks); the last case
     forces the workgroup-per-16-gates key switch (the default is the wave-per-16-gates one, t = 8 / 4 chunks of 128 words)."""
     from iyokan_amd import hip
 
@@ -150,7 +150,7 @@ def test_80bit_full_size_flat_nand_property(keys80, oracle80):
     assert np.array_equal(got[sample], ref[nin:])
 
 
-@pytest.mark.parametrize("kernel", ["w32", "t16", "lat3", None])
+@pytest.mark.parametrize("kernel", ["w32", "lat3", None])
 def test_80bit_direct_decomposition(kernel, keys80, oracle80, monkeypatch):
     """IYK_HIP_DECOMP=direct (opt-in, include/iyokan_hip.h: iyk_hip_decomposition_levels): the 80-bit set's 10-bit digits
     as they are, 2 levels instead of 4 virtual ones.  Same ciphertexts as the oracle, word for word, on every rotation

@@ -199,7 +199,7 @@ def test_timing_log_covers_rotation_only_calls(gpu, keys128):
     st.destroy()
 
 
-@pytest.mark.parametrize("kernel", [None, "t16", "w32", "lat3"])
+@pytest.mark.parametrize("kernel", [None, "fft", "w32", "lat3"])
 def test_cmux_memory_entry_points_256_jobs(gpu, keys128, oracle128, kernel, monkeypatch):
     """Every rotation kernel (default dispatch, then each one forced) through the TRLWE output mode and the output
     indirection.  VERDICT r01 item 6: the two GPU pieces of the CMUX memories composed on 300 jobs —
@@ -301,4 +301,48 @@ def test_extract_keyswitch_on_arbitrary_trlwe_words(gpu, keys128, oracle128, ks,
         assert np.array_equal(got[j], oracle128.keyswitch(t1)), j
     assert L.iyk_hip_trlwe_free(0, d_trlwe) == 0
     arena.free()
+    st.destroy()
+
+
+def test_zz_calibrated_cost_table_and_dispatch_threshold(gpu, keys128, oracle128):
+    """iyk_hip_calibrate: the level-cost table of include/iyokan_hip.h measured on THIS GPU (one full round of the
+    wave-per-rotation kernel, 1 .. 8 passes of the narrow-frontier kernel), stamped with the build; the dispatch's
+    narrow-frontier threshold follows the measured cross-over, and a batch either side of it still equals the oracle.
+    (Runs last in this module: it changes the dispatch threshold of the shared library instance.)"""
+    import os
+
+    before = gpu.level_cost_table(0)
+    assert not before["calibrated"] and before["round"] == gpu.rotation_round() == 8 * before["pass"]
+    t = gpu.calibrate(0)
+    assert t["calibrated"] and t["build_id"] == gpu.build_id() and t["round"] == before["round"]
+    assert 5.0 < t["round_ms"] < 60.0 and 1.0 < t["pass_ms"][0] < 10.0
+    assert all(b > a for a, b in zip(t["pass_ms"], t["pass_ms"][1:]))
+    mp = t["max_passes"]
+    assert 1 <= mp <= 8 and t["pass_ms"][mp - 1] < t["round_ms"] and (mp == 8 or t["pass_ms"][mp] >= t["round_ms"])
+    L = gpu.lib()
+    assert abs(L.iyk_hip_level_cost_ms(0, t["round"] + 1) - (t["round_ms"] + t["pass_ms"][0])) < 1e-3
+    assert abs(L.iyk_hip_level_cost_ms(0, mp * t["pass"] + 1) - t["round_ms"]) < 1e-3
+    st = gpu.Stream(0)
+    p = keys128.params
+    rng = np.random.default_rng(314)
+    nin = 128
+    bits = rng.integers(0, 2, size=nin).astype(np.uint8)
+    for ng in (mp * t["pass"], mp * t["pass"] + 1):       # last size of the narrow-frontier kernel, first of the partial round
+        ia, ib = (rng.integers(0, nin, size=ng).astype(np.int32) for _ in range(2))
+        host = np.zeros((nin + ng, p.n + 1), dtype=np.uint32)
+        host[:nin] = client.encrypt_bits(keys128, bits, seed=315)
+        arena = gpu.Arena(host.shape[0])
+        st.upload(arena, 0, host)
+        st.gate_batch(arena, np.full(ng, OPS["NAND"], dtype=np.int32), ia, ib, np.full(ng, -1, dtype=np.int32),
+                      np.arange(nin, nin + ng, dtype=np.int32))
+        st.sync()
+        got = st.download(arena, nin, ng)
+        arena.free()
+        assert np.array_equal(client.decrypt_bits(keys128, got), 1 - (bits[ia] & bits[ib]))
+        sample = rng.choice(ng, size=16, replace=False)
+        ref = np.zeros((nin + 16, p.n + 1), dtype=np.uint32)
+        ref[:nin] = host[:nin]
+        oracle128.gate_batch([OPS["NAND"]] * 16, ia[sample], ib[sample], [-1] * 16, list(range(nin, nin + 16)), ref,
+                             nthreads=os.cpu_count() or 1)
+        assert np.array_equal(got[sample], ref[nin:])
     st.destroy()

@@ -38,3 +38,21 @@ def test_netlist_bench_one_gpu_through_the_launcher():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["rccl_world_size"] == 1 and line["outputs_match_plaintext"] is True
+    # the per-level all_gather_into_tensor ran on RCCL, in place on the device arena, once per bootstrapped level
+    assert line["collectives_per_clock"] > 0
+
+
+def test_scale_all_writes_lines_and_stops_at_the_first_refusal(tmp_path):
+    """tools/scale_all.sh (the one command for the 1/2/4/8 table): on this box it measures every GPU count that exists and
+    exits with status 3 at the first count that does not, leaving the measured lines + a {"refused": ...} marker."""
+    import torch
+
+    n = torch.cuda.device_count()
+    out = tmp_path / "scale.jsonl"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"GPUS": f"{n} {n + 1}", "STEPS": "1"})
+    r = subprocess.run(["bash", "tools/scale_all.sh", str(out)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    lines = [json.loads(x) for x in out.read_text().splitlines()]
+    assert r.returncode == 3, (r.returncode, r.stderr[-1000:])
+    assert len(lines) == 2 and lines[0]["n_gpus"] == n and lines[0]["config"]["decrypt_check"] is True
+    assert lines[1]["refused"] == f"bench 128bit x{n + 1}" and lines[1]["status"] == 3

@@ -66,11 +66,6 @@ def test_emulated_fp64_path_bit_exact(which, request):
         assert em.iyk_emul_blind_rotate_fp_lat3(ctypes.byref(p), lin.ctypes.data_as(u32p), bk.ctypes.data_as(dp),
                                                 got3.ctypes.data_as(u32p)) == 0
         assert np.array_equal(ref, got3)
-        # wave-per-rotation kernel at three waves per SIMD: polynomial-sequential, 16 points per lane, one swap round per pass
-        got16 = np.zeros(p.N + 1, dtype=np.uint32)
-        assert em.iyk_emul_blind_rotate_fp_t16(ctypes.byref(p), lin.ctypes.data_as(u32p), bk.ctypes.data_as(dp),
-                                               got16.ctypes.data_as(u32p)) == 0
-        assert np.array_equal(ref, got16)
     assert em.iyk_emul_fp_max_magnitude() < 0.95 * 2.0 ** 53 / 844424931229697
 
 
@@ -93,7 +88,7 @@ def test_emulated_kernels_on_adversarial_rows(which, request):
     for r in (0, 3, 6, 7):
         lin = np.ascontiguousarray(rows[r])
         ref = orc.bootstrap_lvl1(lin)
-        for fn in (em.iyk_emul_blind_rotate_fp, em.iyk_emul_blind_rotate_fp_lat3, em.iyk_emul_blind_rotate_fp_t16):
+        for fn in (em.iyk_emul_blind_rotate_fp, em.iyk_emul_blind_rotate_fp_lat3):
             got = np.zeros(p.N + 1, dtype=np.uint32)
             assert fn(ctypes.byref(p), lin.ctypes.data_as(u32p), bk.ctypes.data_as(dp), got.ctypes.data_as(u32p)) == 0
             assert np.array_equal(ref, got), (r, fn)
@@ -103,7 +98,7 @@ def test_emulated_kernels_on_adversarial_rows(which, request):
 def test_emulated_direct_decomposition_80bit(keys80, oracle80):
     """Decomp<2, 10, 1> (IYK_HIP_DECOMP=direct): the 80-bit set's 10-bit digits as they are — 2 levels, half the key
     stream.  Exact iff every integer sum stays below p/2, which real key rows give with probability 1 - 2e-17 per gate
-    in the worst case over digits (blind_rotate_fp.hpp): all three kernels' emulations == oracle on encrypted inputs
+    in the worst case over digits (blind_rotate_fp.hpp): both kernels' emulations == oracle on encrypted inputs
     and on the adversarial LWE rows (the rows are adversarial, the key is a real one)."""
     import oracle_lib
 
@@ -126,7 +121,7 @@ def test_emulated_direct_decomposition_80bit(keys80, oracle80):
         lins += [np.ascontiguousarray(rows[r]) for r in (0, 6)]
         for lin in lins:
             ref = oracle80.bootstrap_lvl1(lin)
-            for fn in (em.iyk_emul_blind_rotate_fp, em.iyk_emul_blind_rotate_fp_lat3, em.iyk_emul_blind_rotate_fp_t16):
+            for fn in (em.iyk_emul_blind_rotate_fp, em.iyk_emul_blind_rotate_fp_lat3):
                 got = np.zeros(p.N + 1, dtype=np.uint32)
                 assert fn(ctypes.byref(p), lin.ctypes.data_as(u32p), bk.ctypes.data_as(dp), got.ctypes.data_as(u32p)) == 0
                 assert np.array_equal(ref, got), fn

@@ -175,3 +175,39 @@ def test_balanced_plan_gains_on_the_benchmark_netlists():
                       (N.load_yosys_json(gold("cahp-ruby-core-yosys.json")), 0.12)):
         cost = lambda lv: sum(F.mi355x_level_cost(r) for r in F.level_rotations(nl, lv, 1))
         assert cost(F.plan_levels(nl, 1)) <= (1 - least) * cost(nl.levelise())
+
+
+def test_planner_follows_the_library_cost_table():
+    """the level-cost figures live in the library (include/iyokan_hip.h: iyk_level_cost), the planner
+    holds none.  (1) The default cost IS the library's compiled-in table, stamped with the build it describes; (2) a PERTURBED
+    table — another GPU: 96 CUs, other milliseconds, another cross-over — yields a valid plan that is cheapest under THAT
+    table and cuts levels at ITS steps, not at 256 / 2048."""
+    from iyokan_amd import frontier as F
+    from iyokan_amd import hip
+
+    t = hip.level_cost_defaults()
+    assert t["round"] == 8 * t["pass"] and 0 < t["max_passes"] <= 8 and t["build_id"] == hip.build_id() and not t["calibrated"]
+    assert F.mi355x_level_cost.table == t and F.mi355x_level_cost.quanta == (t["round"], t["pass"])
+    assert F.mi355x_level_cost(t["round"]) == pytest.approx(t["round_ms"])
+    assert F.mi355x_level_cost(t["pass"] + 1) == pytest.approx(t["pass_ms"][1])
+    assert F.mi355x_level_cost(t["round"] + t["max_passes"] * t["pass"] + 1) == pytest.approx(2 * t["round_ms"])
+
+    odd = dict(t, round=768, max_passes=2, round_ms=9.0, pass_ms=[4.0, 7.5, 11.0, 14.5, 18.0, 21.5, 25.0, 28.5])
+    odd["pass"] = 96
+    cost = F.make_level_cost(odd)
+    nl = N.load_yosys_json(gold("cahp-ruby-core-yosys.json"))
+    asap = nl.levelise()
+    plan = F.plan_levels(nl, 1, cost)
+    assert len(plan) == len(asap) and sorted(i for lv in plan for i in lv) == sorted(i for lv in asap for i in lv)
+    where = {i: k for k, lv in enumerate(plan) for i in lv}
+    root = nl.roots()
+    for i, k in where.items():
+        for j in nl.ins[i]:
+            j = root[j]
+            assert nl.kinds[j] in ("INPUT", "DFF") or where[j] < k
+    total = lambda lv, c: sum(c(r) for r in F.level_rotations(nl, lv, 1))
+    assert total(plan, cost) < total(asap, cost)                       # it optimised the table it was given ...
+    default_plan = F.plan_levels(nl, 1)
+    assert total(plan, cost) <= total(default_plan, cost) + 1e-9       # ... better than the plan made for the default table
+    rots = F.level_rotations(nl, plan, 1)
+    assert sum(1 for r in rots if r and r % 96 == 0) > sum(1 for r in F.level_rotations(nl, default_plan, 1) if r and r % 96 == 0)

@@ -69,10 +69,10 @@ def main():
     if distributed:
         keys = bench.broadcast_keys(keys, dist, dev, rank)   # rank 0's key material, once, over RCCL
     hip.initialize(keys, device_ids=(local,))
-    level_cost = make_level_cost(hip.rotation_round())   # rounds of 8 waves per CU of THIS device
+    level_cost = make_level_cost(hip.calibrate(0))       # THIS device's table, measured (0.15 s): rounds, passes, threshold
     plan = FrontierPlan(nl, world, balance=args.plan == "balanced", cost=level_cost)
     be = HipBackend(plan.num_slots, p, dev)
-    ex = FrontierExecutor(plan, be, rank, world, dist if world > 1 else None)
+    ex = FrontierExecutor(plan, be, rank, world, dist if distributed else None)   # one rank too: the level exchange runs on RCCL
     if distributed and world == 1:
         dist.barrier()   # one-rank RCCL communicator (--spawn): at least one collective on it
     sim = N.PlainSimulator(nl)
@@ -101,13 +101,13 @@ def main():
             be.write_many([plan.slot[i] for i in plan.dffs], np.tile(zero, (len(plan.dffs), 1)))
             be.write_many([plan.slot[i] for i in plan.sources], np.tile(zero, (len(plan.sources), 1)))
         drive(c)
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ex.run()
         ex.sync()
-        if world > 1:
+        if distributed:
             dist.barrier()
         times.append(time.perf_counter() - t0)
         sim.evaluate()
@@ -118,8 +118,8 @@ def main():
         rot = nl.rotations()
         best = min(times[1:])
         print(json.dumps({"net": args.net, "n_gpus": world, "rccl_world_size": dist.get_world_size() if distributed else None, "levels": len(plan.levels), "rotations_per_clock": rot,
-                          "s_per_clock": best, "rotations_per_s": rot / best, "collectives_per_clock": len(plan.levels) if world > 1 else 0,
-                          "outputs_match_plaintext": ok, "ntt_path": hip.ntt_path(), "plan": args.plan,
+                          "s_per_clock": best, "rotations_per_s": rot / best, "collectives_per_clock": ex.collectives // (args.clocks + 1),
+                          "outputs_match_plaintext": ok, "ntt_path": hip.ntt_path(), "plan": args.plan, "cost_table": level_cost.table,
                           "model_s_per_clock": sum(level_cost(r) for r in level_rotations(nl, [L["boot"] for L in plan.levels], world)) / 1e3}))
     be.close()
     hip.cleanup()

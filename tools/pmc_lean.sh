@@ -1,6 +1,6 @@
 #!/bin/bash
 # Lean counter set of one blind-rotate launch: clock, issue / wait split, instruction mix.  One --pmc pass per group.
-#   bash tools/pmc_lean.sh <tag>   (env: GATES, IYK_HIP_TP_KERNEL / IYK_HIP_ROT_KERNEL)  -> gpurun_out/<tag>_pmc.txt
+#   bash tools/pmc_lean.sh <tag>   (env: GATES, IYK_HIP_NTT / IYK_HIP_ROT_KERNEL)  -> gpurun_out/<tag>_pmc.txt
 tag=${1:-pmc}
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
 out=gpurun_out/${tag}_pmc.txt

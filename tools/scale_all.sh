@@ -1,0 +1,38 @@
+#!/bin/bash
+# The whole scaling table in ONE command, for the first lease with more than one GPU:
+#   bash tools/scale_all.sh [outfile]          # default gpurun_out/scale_all.jsonl
+#   - bench.py --gpus {1,2,4,8}: 65 536 flat NANDs, 128-bit set, then the 80-bit set (configs #2 / #5; strong line + weak leg)
+#   - tools/bench_netlist.py --gpus {1,8}: config #3 (mux-ram-8-16-16) and config #4 (CAHP system), 10 clocks each
+# One JSON line per run, in that order.  bench.py / bench_netlist.py refuse (status 3, no JSON) to report an N-GPU number
+# from fewer than N devices; this script then stops with status 3 after writing what it has — a partial table is labelled
+# by its last line {"refused": ...}, never silently padded.  The reference takes its GPU count the same way
+# (/root/reference/src/main.cpp:147-148).  GPUS="1 2" restricts the counts (e.g. a 2-GPU box).
+cd "$(dirname "$0")/.." && export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+out=${1:-gpurun_out/scale_all.jsonl}
+mkdir -p "$(dirname "$out")"; : > "$out"
+GPUS=${GPUS:-"1 2 4 8"}
+NET_GPUS=${NET_GPUS:-"1 8"}
+run() {   # run <label> <cmd...>
+  local label=$1; shift
+  local line rc
+  line=$("$@" 2>/tmp/scale_all.err | tail -1); rc=${PIPESTATUS[0]}
+  if [ "$rc" -ne 0 ] || [ -z "$line" ]; then
+    echo "{\"refused\": \"$label\", \"status\": $rc, \"stderr\": \"$(tail -1 /tmp/scale_all.err | tr -d '"\\' | cut -c1-200)\"}" >> "$out"
+    echo "scale_all: $label failed with status $rc" >&2
+    [ "$rc" -eq 3 ] && exit 3
+    exit 1
+  fi
+  echo "$line" >> "$out"
+  echo "$label: $(echo "$line" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d.get('value') or d.get('s_per_clock'))")"
+}
+for params in 128bit 80bit; do
+  for n in $GPUS; do
+    run "bench $params x$n" python bench.py --gpus $n --params $params --steps ${STEPS:-4} --warmup 1 --cpu-sample 0
+  done
+done
+for net in mux-ram cahp-system; do
+  for n in $NET_GPUS; do
+    run "netlist $net x$n" python tools/bench_netlist.py --net $net --gpus $n --clocks ${CLOCKS:-10}
+  done
+done
+echo "scale_all: table complete -> $out"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Batch-size sweep of the rotation kernels (forced through IYK_HIP_ROT_KERNEL): average blind-rotate launch ms per batch.
-#   bash tools/sweep_rot.sh [sizes...]      KERNELS="lat3 w32 t16" selects kernels
+#   bash tools/sweep_rot.sh [sizes...]      KERNELS="lat3 w32 fft" selects kernels
 cd "$(dirname "$0")/.."
 sizes=${@:-"32 128 256 512 768 1024 1280 1536 2048"}
 kernels=${KERNELS:-"lat3 w32"}
