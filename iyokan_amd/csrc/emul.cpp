@@ -598,6 +598,80 @@ void blind_rotate_fft(const iyk_params* p, const u32* lin, const fft::cplx* bk_f
     for (u32 j = 1; j < (u32)NTT_N; ++j) tlwe1[j] = 0u - acc[NTT_N - j];
     tlwe1[NTT_N] = acc[NTT_N];
 }
+
+// one inverse transform of one wave (kernels_fft.hpp::fft_inverse1)
+void fft_inverse1_wave(fft::cplx (*a)[8], fft::cplx* xb)
+{
+    const fft::Consts& C = fft_consts();
+    ALL_LANES fft::inv_p1(a[lane], &C.t2t[0][lane & 7]);
+    ALL_LANES fft::x2_put_c(lane, a[lane], xb);
+    ALL_LANES fft::x2_get_b(lane, a[lane], xb);
+    ALL_LANES fft::inv_p2(a[lane]);
+    ALL_LANES fft::x1_put_b(lane, a[lane], xb);
+    ALL_LANES fft::x1_get_a(lane, a[lane], xb);
+    ALL_LANES fft::inv_p3(a[lane], C.u, &C.t1[0][lane]);
+}
+
+// wave-by-wave, lane-by-lane run of kernels_fft.hpp::blind_rotate_fft_lat_kernel: one rotation on 8 waves, doubled accumulator,
+// spectra and sums through "LDS" arrays in the kernel's layouts, the three phases in the order the barriers impose
+template <class G>
+void blind_rotate_fft_lat(const iyk_params* p, const u32* lin, const fft::cplx* bk_fft, u32* tlwe1)
+{
+    constexpr int L = G::L, XF = 2 * L;
+    constexpr size_t XB = fft::XCHG_BYTES / sizeof(fft::cplx);
+    std::vector<u32> acc2(4 * NTT_N);
+    std::vector<fft::cplx> s_xb(XF * XB), s_sum(4 * fft::M);
+    const u32 bbar = br_modswitch_b(lin[p->n]);
+    for (int e = 0; e < 2 * NTT_N; ++e) {
+        const int c = e >> 10, j = e & (NTT_N - 1);
+        const u32 idx = ((u32)j - bbar) & (2 * NTT_N - 1);
+        const u32 v = c ? ((idx & NTT_N) ? 0u - p->mu : p->mu) : 0u;
+        acc2[c * 2 * NTT_N + j] = v;
+        acc2[c * 2 * NTT_N + NTT_N + j] = 0u - v;
+    }
+    static thread_local fft::cplx a[64][8];
+    static thread_local u32 u[64][16];
+    for (u32 i = 0; i < p->n; ++i) {
+        const u32 ab = br_modswitch_a(lin[i]);
+        for (int wave = 0; wave < XF; ++wave) {   // forward
+            const int cF = wave / L, lvl = wave - cF * L;
+            fft::cplx* xb = s_xb.data() + (size_t)wave * XB;
+            ALL_LANES fft::diff16_doubled<G>(lane, ab, acc2.data() + cF * 2 * NTT_N, u[lane]);
+            ALL_LANES fft::digits8<G>(lvl, u[lane], a[lane]);
+            fft_forward_wave(a, xb);
+            ALL_LANES for (int q = 0; q < 8; ++q) xb[q * 64 + lane] = a[lane][q];
+        }
+        for (int wave = 0; wave < 8; ++wave)      // MAC: frequency block q = wave
+            ALL_LANES
+            {
+                const fft::Keys keys(bk_fft, 0, lane);
+                fft::cplx sacc[4];
+                for (int r = 0; r < XF; ++r) {
+                    const fft::cplx d = s_xb[(size_t)r * XB + wave * 64 + lane];
+                    for (int pc = 0; pc < 4; ++pc) {
+                        const fft::cplx k = keys.at((i * (u32)XF + (u32)r) * 4u * (u32)fft::M, pc, 0, (u32)wave * 1024u);
+                        if (r == 0) fft::cmac<true>(sacc[pc], d, k);
+                        else fft::cmac<false>(sacc[pc], d, k);
+                    }
+                }
+                for (int pc = 0; pc < 4; ++pc) s_sum[pc * fft::M + wave * 64 + lane] = sacc[pc];
+            }
+        for (int wave = 0; wave < 4; ++wave) {    // inverse of sum (c', half) = (wave >> 1, wave & 1)
+            fft::cplx* xb = s_xb.data() + (size_t)wave * XB;
+            ALL_LANES for (int q = 0; q < 8; ++q) a[lane][q] = s_sum[wave * fft::M + q * 64 + lane];
+            fft_inverse1_wave(a, xb);
+            ALL_LANES
+            {
+                const double e = fft::round_err8(a[lane]);
+                if (e > g_fft_worst) g_fft_worst = e;
+                fft::acc_update16_doubled(lane, a[lane], (wave & 1) ? 16 : 0, acc2.data() + (wave >> 1) * 2 * NTT_N);
+            }
+        }
+    }
+    tlwe1[0] = acc2[0];
+    for (u32 j = 1; j < (u32)NTT_N; ++j) tlwe1[j] = acc2[NTT_N + (NTT_N - j)];
+    tlwe1[NTT_N] = acc2[2 * NTT_N];
+}
 }  // namespace
 
 static int g_direct = 0;  // 80-bit set: Decomp<2, 10, 1> (IYK_HIP_DECOMP=direct on the device) instead of the split digits
@@ -675,6 +749,15 @@ int iyk_emul_blind_rotate_fft(const iyk_params* p, const uint32_t* lin, const do
     const fft::cplx* k = reinterpret_cast<const fft::cplx*>(bk_fft);
     if (p->l == 3 && p->Bgbit == 6) blind_rotate_fft<fft::Gadget<3, 6>>(p, lin, k, tlwe1);
     else if (p->l == 2 && p->Bgbit == 10) blind_rotate_fft<fft::Gadget<2, 10>>(p, lin, k, tlwe1);
+    else return -1;
+    return 0;
+}
+int iyk_emul_blind_rotate_fft_lat(const iyk_params* p, const uint32_t* lin, const double* bk_fft, uint32_t* tlwe1)
+{
+    if (p->N != 1024 || p->k != 1) return -1;
+    const fft::cplx* k = reinterpret_cast<const fft::cplx*>(bk_fft);
+    if (p->l == 3 && p->Bgbit == 6) blind_rotate_fft_lat<fft::Gadget<3, 6>>(p, lin, k, tlwe1);
+    else if (p->l == 2 && p->Bgbit == 10) blind_rotate_fft_lat<fft::Gadget<2, 10>>(p, lin, k, tlwe1);
     else return -1;
     return 0;
 }

@@ -278,6 +278,21 @@ int launch_br_fft(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
     return IYK_OK;
 }
 
+// narrow frontiers on the FFT path: one rotation per workgroup of 8 waves (kernels_fft.hpp, blind_rotate_fft_lat_kernel)
+template <class GD>
+int launch_br_fft_lat(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
+{
+    const Device& D = G.devs[st->gpu];
+    typedef BrLatFft<GD> M;
+    auto kern = G.debug ? blind_rotate_fft_lat_kernel<GD, true> : blind_rotate_fft_lat_kernel<GD, false>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3(M::THREADS), M::LDS_BYTES, st->s,
+                       (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE, njobs, (const fft::cplx*)D.bk_fft,
+                       (u32)G.bk_fft_bytes, (const fft::Consts*)D.fftc, o.at(first), G.p.n, G.p.mu, ABAR_STRIDE, o.trlwe,
+                       o.idx(first), D.fft_err);
+    HIP_TRY(hipGetLastError());
+    return IYK_OK;
+}
+
 // narrow frontiers: one rotation per workgroup of 8 waves (kernels.hpp, blind_rotate_fp_lat3_kernel)
 template <class DC>
 int launch_br_fp_lat3(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
@@ -293,7 +308,7 @@ int launch_br_fp_lat3(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
 
 // which rotation kernel a batch is forced onto: IYK_HIP_ROT_KERNEL = fft / w32 / lat3 (A/B, tests; read per batch).
 // IYK_HIP_LATENCY_KERNEL = 0 / 3 is the older spelling of w32 / lat3.  0 = no override.
-enum { ROT_AUTO = 0, ROT_W32 = 32, ROT_LAT3 = 3, ROT_FFT = 8 };
+enum { ROT_AUTO = 0, ROT_W32 = 32, ROT_LAT3 = 3, ROT_FFT = 8, ROT_LATFFT = 9 };
 int forced_rot_kernel()
 {
     if (const char* k = std::getenv("IYK_HIP_ROT_KERNEL")) {
@@ -301,6 +316,7 @@ int forced_rot_kernel()
         if (v == "w32") return ROT_W32;
         if (v == "lat3") return ROT_LAT3;
         if (v == "fft") return ROT_FFT;
+        if (v == "latfft") return ROT_LATFFT;
     }
     if (const char* lat = std::getenv("IYK_HIP_LATENCY_KERNEL")) {
         if (lat[0] == '0') return ROT_W32;
@@ -319,9 +335,9 @@ int dispatch_fp(iyk_hip_stream* st, int njobs, const RotOut& o)
 {
     int rc;
     const int forced = forced_rot_kernel();
-    if (forced == ROT_FFT) {
-        if (!G.use_fft) return fail(IYK_ERR_STATE, "IYK_HIP_ROT_KERNEL=fft needs the FFT key spectra (IYK_HIP_NTT=fft at init)");
-        return launch_br_fft<GD>(st, 0, njobs, o);
+    if (forced == ROT_FFT || forced == ROT_LATFFT) {
+        if (!G.use_fft) return fail(IYK_ERR_STATE, "IYK_HIP_ROT_KERNEL=fft / latfft needs the FFT key spectra (IYK_HIP_NTT=fft at init)");
+        return forced == ROT_FFT ? launch_br_fft<GD>(st, 0, njobs, o) : launch_br_fft_lat<GD>(st, 0, njobs, o);
     }
     if (forced == ROT_LAT3) return launch_br_fp_lat3<DC>(st, 0, njobs, o);
     if (forced == ROT_W32) return launch_br_fp<DC>(st, 0, njobs, o);
@@ -332,7 +348,7 @@ int dispatch_fp(iyk_hip_stream* st, int njobs, const RotOut& o)
     };
     if (rem > G.devs[st->gpu].cost.max_passes * G.devs[st->gpu].cus) return tp(0, njobs);
     if (full && (rc = tp(0, full))) return rc;
-    if (rem) return launch_br_fp_lat3<DC>(st, full, rem, o);
+    if (rem) return G.use_fft ? launch_br_fft_lat<GD>(st, full, rem, o) : launch_br_fp_lat3<DC>(st, full, rem, o);
     return IYK_OK;
 }
 
@@ -429,7 +445,9 @@ int set_fft_attrs()
 {
     int rc;
     if ((rc = set_lds(blind_rotate_fft_kernel<GD, false>, BR_FFT_LDS_BYTES))) return rc;
-    return set_lds(blind_rotate_fft_kernel<GD, true>, BR_FFT_LDS_BYTES);
+    if ((rc = set_lds(blind_rotate_fft_kernel<GD, true>, BR_FFT_LDS_BYTES))) return rc;
+    if ((rc = set_lds(blind_rotate_fft_lat_kernel<GD, false>, BrLatFft<GD>::LDS_BYTES))) return rc;
+    return set_lds(blind_rotate_fft_lat_kernel<GD, true>, BrLatFft<GD>::LDS_BYTES);
 }
 int set_kernel_attrs(const iyk_params& p, bool use_fp, int split)
 {
@@ -743,6 +761,7 @@ int iyk_hip_calibrate(int gpu_index)
         return G.split == 1 ? launch_br_fp<fp::Decomp<2, 10, 1>>(st, 0, count, o) : launch_br_fp<fp::Decomp<2, 10, 2>>(st, 0, count, o);
     };
     auto lat = [&](int count) {
+        if (G.use_fft) return G.p.l == 3 ? launch_br_fft_lat<fft::Gadget<3, 6>>(st, 0, count, o) : launch_br_fft_lat<fft::Gadget<2, 10>>(st, 0, count, o);
         if (G.p.l == 3) return launch_br_fp_lat3<fp::Decomp<3, 6, 1>>(st, 0, count, o);
         return G.split == 1 ? launch_br_fp_lat3<fp::Decomp<2, 10, 1>>(st, 0, count, o) : launch_br_fp_lat3<fp::Decomp<2, 10, 2>>(st, 0, count, o);
     };

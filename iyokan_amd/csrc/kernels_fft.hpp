@@ -138,6 +138,37 @@ __device__ __forceinline__ void fft_inverse2(int lane, fft::cplx (&a)[8], fft::c
     p3(b);
 }
 
+// One inverse transform (narrow-frontier kernel: one spectrum per wave); `after_p1` runs once the first exchange is under way
+template <class Hook>
+__device__ __forceinline__ void fft_inverse1(int lane, fft::cplx (&x)[8], const fft::Twist& u, const fft::cplx* t1_lane,
+                                             const fft::cplx* t2, fft::cplx* xb, Hook after_p1)
+{
+    {
+        const fft::cplx ta = t2[8], tb = t2[16];
+        __builtin_amdgcn_sched_barrier(0);
+        fft::dft8<true>(x);
+        xb[fft::x2_rbase(lane)] = x[0];
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        twiddle_and_store<1, true>(x, t2, 8, ta, tb, [&](int j0) { xb[fft::x2_rbase(lane) + j0] = x[j0]; });
+    }
+    lds_sync();
+    fft::x2_get_b(lane, x, xb);
+    after_p1();
+    lds_sync();
+    fft::inv_p2(x);
+    fft::x1_put_b(lane, x, xb);
+    lds_sync();
+    fft::x1_get_a(lane, x, xb);
+    fft::cplx tw[8];
+#pragma unroll
+    for (int k0 = 0; k0 < 8; ++k0) tw[k0] = t1_lane[64 * k0];
+    lds_sync();
+#pragma unroll
+    for (int k0 = 0; k0 < 8; ++k0) x[k0] = fft::cmulc(x[k0], tw[k0]);
+    fft::dft8<true>(x);
+    fft::twist8<true>(x, u);
+}
+
 // BK: [polys][1024] u32 torus -> cplx [polys][2][512]: the spectra of the signed 16-bit halves (lo, hi) of every
 // polynomial, arrangement F, scaled by 1/512 (the inverse transform's normalisation).  One wave per (polynomial, half).
 __global__ __launch_bounds__(64) void bk_fft_kernel(const u32* __restrict__ bk, fft::cplx* __restrict__ bk_fft,
@@ -292,6 +323,150 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
             u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (NTT_N + 1);
             for (int j = lane; j < NTT_N; j += 64) out[j] = (j == 0) ? acc_lds[0] : 0u - acc_lds[NTT_N - j];
             if (lane == 0) out[NTT_N] = acc_lds[NTT_N];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Narrow frontiers on the FFT path: ONE ROTATION PER WORKGROUP of 8 wavefronts (one CU each), three workgroup barriers per
+// CMUX step.  Replaces blind_rotate_fp_lat3_kernel's field transforms (12.0 k cycles per step) for the FFT key form:
+//   forward   wave w < 2 L: digit polynomial (c, lvl) = (w / L, w % L): rotated difference from the DOUBLED accumulator,
+//             digits, 512-point transform through the wave's own exchange buffer, spectrum left there as [k2][lane''];  barrier 1
+//   MAC       ALL 8 waves, wave q = frequency block k2 = q: each lane reads its frequency of the 2 L spectra (ds_read_b128),
+//             multiplies with the 2 L x 4 key values fetched a step ahead, stores the four sums — one writer per value;   barrier 2
+//   inverse   wave w < 4: spectrum (c', half) = (w >> 1, w & 1) -> inverse transform -> rint -> acc2[c'] += word << 16 half
+//             (the two halves of a polynomial add into the same words; integer additions commute);                        barrier 3
+// LDS (bytes): T1 8 K | acc2 [2][2048] u32 16 K (8 KB aligned polynomials) | 2 L exchange buffers of 9 K (<= 54 K), reused
+// for the spectra and by the inverse waves | sums cplx [4][512] 32 K | T2 1 K.
+template <class G>
+struct BrLatFft {
+    static constexpr int L = G::L, XF = 2 * G::L, WAVES = 8, THREADS = 64 * WAVES;
+    static_assert(XF <= WAVES && XF >= 4, "the wave roles assume 4 <= 2 L <= 8");
+    static constexpr size_t XB = fft::XCHG_BYTES / sizeof(fft::cplx);
+    static constexpr size_t LDS_BYTES = BR_FFT_T1_BYTES + 4 * NTT_N * sizeof(u32) + (size_t)XF * fft::XCHG_BYTES +
+                                        4 * fft::M * sizeof(fft::cplx) + BR_FFT_T2_BYTES;
+    static_assert(LDS_BYTES <= 160 * 1024, "FFT latency kernel does not fit the CU's LDS");
+};
+
+template <class G, bool CHECK>
+__global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_kernel(
+    const u32* __restrict__ abar_all, int njobs, const fft::cplx* __restrict__ bk_fft, u32 bk_bytes,
+    const fft::Consts* __restrict__ Cp, u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride, int trlwe_mode,
+    const int32_t* __restrict__ out_index, unsigned long long* __restrict__ max_err_bits)
+{
+    typedef BrLatFft<G> M;
+    constexpr int L = M::L, XF = M::XF;
+    const fft::Consts& C = *Cp;
+    extern __shared__ __attribute__((aligned(8192))) unsigned char smem[];
+    fft::cplx* s_t1 = reinterpret_cast<fft::cplx*>(smem);                                    // [k0][lane], 8 K
+    u32* acc2 = reinterpret_cast<u32*>(smem + BR_FFT_T1_BYTES);                              // [2][2 N]: polynomial, then its negation
+    fft::cplx* s_xb = reinterpret_cast<fft::cplx*>(smem + BR_FFT_T1_BYTES + 4 * NTT_N * sizeof(u32));   // [XF][XB]
+    fft::cplx* s_sum = s_xb + (size_t)XF * M::XB;                                            // [4][512]
+    fft::cplx* s_t2 = s_sum + 4 * fft::M;                                                    // [b][a]
+    static_assert(BR_FFT_T1_BYTES % 8192 == 0, "diff16_doubled needs 8 KB aligned accumulators");
+
+    for (int e = threadIdx.x; e < 8 * 64; e += M::THREADS) s_t1[e] = C.t1[e >> 6][e & 63];
+    if (threadIdx.x < 64) s_t2[threadIdx.x] = C.t2t[threadIdx.x >> 3][threadIdx.x & 7];
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane0 = threadIdx.x & 63;
+    const int job = blockIdx.x;
+    const u32* abar = abar_all + (size_t)job * abar_stride;
+    {   // initial accumulator (0, X^bbar * sum_j mu X^j) and its negation: 4096 words over 512 threads
+        const u32 bbar = abar[n];
+        for (int e = threadIdx.x; e < 2 * NTT_N; e += M::THREADS) {
+            const int c = e >> 10, j = e & (NTT_N - 1);
+            const u32 idx = ((u32)j - bbar) & (2 * NTT_N - 1);
+            const u32 v = c ? ((idx & NTT_N) ? 0u - mu : mu) : 0u;
+            acc2[c * 2 * NTT_N + j] = v;
+            acc2[c * 2 * NTT_N + NTT_N + j] = 0u - v;
+        }
+    }
+    const bool fwd = wave < XF;                      // transform wave: digit polynomial (cF, lvl)
+    const int cF = fwd ? wave / L : 0, lvl = fwd ? wave - cF * L : 0;
+    const bool inv = wave < 4;                       // inverse wave: spectrum (c', half) = (wave >> 1, wave & 1)
+    fft::cplx* xb = s_xb + (size_t)(fwd ? wave : 0) * M::XB;
+    fft::Twist U = C.u;
+    asm volatile("" : "+s"(U.c1), "+s"(U.s1), "+s"(U.c2), "+s"(U.s2), "+s"(U.c3), "+s"(U.s3));
+    const fft::Keys keys(bk_fft, bk_bytes, lane0);
+    fft::cplx kb[XF][4];                             // this wave's key values of one step: frequency block q = wave
+    auto load_keys = [&](u32 step) {
+#pragma unroll
+        for (int r = 0; r < XF; ++r)
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) kb[r][pc] = keys.at((step * (u32)XF + (u32)r) * 4u * (u32)fft::M, pc, 0, (u32)wave * 1024u);
+    };
+    load_keys(0);
+    double worst = 0.0;
+    __syncthreads();
+
+    u32 ab_next = abar[0];
+    for (u32 i = 0; i < n; ++i) {
+        const u32 ab = ab_next;
+        ab_next = abar[i + 1 < n ? i + 1 : i];
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        // ---- forward: digit polynomial (cF, lvl) -> spectrum in the wave's buffer, [k2][lane'']
+        if (fwd) {
+            u32 u[16];
+            fft::cplx a[8];
+            fft::diff16_doubled<G>(lane, ab, acc2 + cF * 2 * NTT_N, u);
+            fft::digits8<G>(lvl, u, a);
+            fft_forward(lane, a, U, s_t1 + lane, s_t2 + (lane & 7), xb);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xb[q * 64 + lane] = a[q];
+        }
+        wg_barrier_lds();
+        // ---- MAC: frequency block q = wave of all four sums
+        {
+            fft::cplx s[4];
+#pragma unroll
+            for (int r = 0; r < XF; ++r) {
+                const fft::cplx d = s_xb[(size_t)r * M::XB + wave * 64 + lane];
+#pragma unroll
+                for (int pc = 0; pc < 4; ++pc) {
+                    if (r == 0) fft::cmac<true>(s[pc], d, kb[r][pc]);
+                    else fft::cmac<false>(s[pc], d, kb[r][pc]);
+                }
+            }
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) s_sum[pc * fft::M + wave * 64 + lane] = s[pc];
+        }
+        wg_barrier_lds();
+        // next step's key values, off the critical path: the waves without inverse work fetch theirs now, the inverse waves
+        // after their first pass (8 x 24 KiB through the CU's one texture path would otherwise sit in front of the inverse)
+        if (!inv && i + 1 < n) load_keys(i + 1);
+        // ---- inverse of sum (c', half) -> accumulator polynomial c'
+        if (inv) {
+            fft::cplx a[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = s_sum[wave * fft::M + q * 64 + lane];
+            fft_inverse1(lane, a, U, s_t1 + lane, s_t2 + (lane & 7), xb, [&] {
+                if (i + 1 < n) load_keys(i + 1);
+            });
+            if (CHECK) {
+                const double e = fft::round_err8(a);
+                worst = e > worst ? e : worst;
+            }
+            fft::acc_update16_doubled(lane, a, (wave & 1) ? 16 : 0, acc2 + (wave >> 1) * 2 * NTT_N);
+        }
+        wg_barrier_lds();
+    }
+    if (CHECK && max_err_bits) {
+        unsigned long long b;
+        __builtin_memcpy(&b, &worst, 8);
+        atomicMax(max_err_bits, b);
+    }
+    {
+        const int tid = threadIdx.x;
+        if (trlwe_mode) {
+            u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (2 * NTT_N);
+            for (int j = tid; j < 2 * NTT_N; j += M::THREADS) out[j] = acc2[(j >> 10) * 2 * NTT_N + (j & (NTT_N - 1))];
+        }
+        else {
+            u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (NTT_N + 1);
+            for (int j = tid; j < NTT_N; j += M::THREADS) out[j] = (j == 0) ? acc2[0] : acc2[NTT_N + (NTT_N - j)];   // -a[N - j]: the negated half
+            if (tid == 0) out[NTT_N] = acc2[2 * NTT_N];
         }
     }
 }

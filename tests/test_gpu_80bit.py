@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 NTT_ENV = {"fft": "fft", "fp50": "fp", "goldilocks": "goldilocks"}
 
 
-@pytest.mark.parametrize("path,kernel,ks", [("fft", "fft", None), ("fft", None, None), ("fp50", "w32", None),
+@pytest.mark.parametrize("path,kernel,ks", [("fft", "fft", None), ("fft", "latfft", None), ("fft", None, None), ("fp50", "w32", None),
                                             ("fp50", "lat3", None), ("goldilocks", None, None), ("fp50", None, "0")])
 def test_80bit_gates_bit_exact(path, kernel, ks, keys80, oracle80, monkeypatch):
     """All three exact paths at the 80-bit set: complex FFT on 16-bit key halves with the 10-bit digits as they are (the

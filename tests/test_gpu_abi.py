@@ -199,7 +199,7 @@ def test_timing_log_covers_rotation_only_calls(gpu, keys128):
     st.destroy()
 
 
-@pytest.mark.parametrize("kernel", [None, "fft", "w32", "lat3"])
+@pytest.mark.parametrize("kernel", [None, "fft", "latfft", "w32", "lat3"])
 def test_cmux_memory_entry_points_256_jobs(gpu, keys128, oracle128, kernel, monkeypatch):
     """Every rotation kernel (default dispatch, then each one forced) through the TRLWE output mode and the output
     indirection.  VERDICT r01 item 6: the two GPU pieces of the CMUX memories composed on 300 jobs —

@@ -26,8 +26,9 @@ def _run_batch(hip, host, ops, in0, in1, in2, out):
     return got
 
 
+@pytest.mark.parametrize("kernel", ["fft", "latfft"])
 @pytest.mark.parametrize("which", ["128", "80"])
-def test_fft_kernel_all_kinds_and_adversarial_rows(which, request, monkeypatch):
+def test_fft_kernel_all_kinds_and_adversarial_rows(which, kernel, request, monkeypatch):
     """All gate kinds on fresh encryptions + the rows no encryption produces, 700 gates (partial workgroups, idle waves),
     with IYK_HIP_DEBUG=1: the kernel's own record of max |z - rint(z)| must stay below 2^-10 (DESIGN.md §2b proves < 2^-10
     for ANY key and digits; real keys give ~2^-20)."""
@@ -37,7 +38,7 @@ def test_fft_kernel_all_kinds_and_adversarial_rows(which, request, monkeypatch):
     keys = request.getfixturevalue("keys" + which)
     orc = request.getfixturevalue("oracle" + which)
     monkeypatch.setenv("IYK_HIP_NTT", "fft")
-    monkeypatch.setenv("IYK_HIP_ROT_KERNEL", "fft")
+    monkeypatch.setenv("IYK_HIP_ROT_KERNEL", kernel)     # fft: a wave per rotation; latfft: a workgroup of 8 waves per rotation
     monkeypatch.setenv("IYK_HIP_DEBUG", "1")
     monkeypatch.delenv("IYK_HIP_KS_KERNEL", raising=False)
     p = keys.params
@@ -67,8 +68,9 @@ def test_fft_kernel_all_kinds_and_adversarial_rows(which, request, monkeypatch):
     assert 0.0 < err < 2.0 ** -10, err
 
 
+@pytest.mark.parametrize("kernel", ["fft", "latfft"])
 @pytest.mark.parametrize("which", ["128", "80"])
-def test_fft_kernel_worst_case_key_and_digits(which, request, monkeypatch):
+def test_fft_kernel_worst_case_key_and_digits(which, kernel, request, monkeypatch):
     """The rounding bound's extremes on the device: 'bootstrapping keys' whose every word has both 16-bit halves at -2^15
     (0x80008000), all aligned / randomly mixed with +(2^15 - 1) halves / alternating, driven by rows that put every digit
     at its extreme from the first step — the norms ||d||_2 ||k||_2 of the bound are attained.  Still the oracle's words
@@ -78,7 +80,7 @@ def test_fft_kernel_worst_case_key_and_digits(which, request, monkeypatch):
 
     keys = request.getfixturevalue("keys" + which)
     monkeypatch.setenv("IYK_HIP_NTT", "fft")
-    monkeypatch.setenv("IYK_HIP_ROT_KERNEL", "fft")
+    monkeypatch.setenv("IYK_HIP_ROT_KERNEL", kernel)
     monkeypatch.setenv("IYK_HIP_DEBUG", "1")
     p = keys.params
     rng = np.random.default_rng(5)
@@ -120,8 +122,9 @@ def test_fft_kernel_worst_case_key_and_digits(which, request, monkeypatch):
 
 
 def test_fft_and_field_paths_agree_on_a_round_plus_remainder(keys128, monkeypatch):
-    """One full round (FFT kernel) + a remainder (narrow-frontier kernel, FP64 field) in the default configuration against
-    the same batch with IYK_HIP_NTT=fp (the field kernel for the round): identical arenas — two different exact products."""
+    """One full round + a remainder in the default configuration (both FFT kernels: a wave per rotation for the round, a
+    workgroup per rotation for the remainder) against the same batch with IYK_HIP_NTT=fp (the two field kernels): identical
+    arenas — two different exact products, four kernels."""
     from iyokan_amd import hip
 
     monkeypatch.delenv("IYK_HIP_ROT_KERNEL", raising=False)

@@ -284,7 +284,7 @@ def test_all_rotation_kernels_agree(gpu128, keys128, oracle128):
     results = {}
     old = os.environ.get("IYK_HIP_ROT_KERNEL")
     try:
-        for mode in ("fft", "w32", "lat3"):
+        for mode in ("fft", "latfft", "w32", "lat3"):
             os.environ["IYK_HIP_ROT_KERNEL"] = mode
             results[mode] = _run(hip, st, host, ops, in0, in1, in2, out)
     finally:
@@ -294,7 +294,7 @@ def test_all_rotation_kernels_agree(gpu128, keys128, oracle128):
             os.environ["IYK_HIP_ROT_KERNEL"] = old
     ref = host.copy()
     oracle128.gate_batch(ops, in0, in1, in2, out, ref, nthreads=os.cpu_count() or 1)
-    for mode in ("fft", "w32", "lat3"):
+    for mode in ("fft", "latfft", "w32", "lat3"):
         assert np.array_equal(results[mode], ref), mode
 
 
@@ -347,7 +347,7 @@ def test_adversarial_rows_bit_exact_on_every_kernel(gpu128, keys128, oracle128, 
     host[:nin] = rows
     ref = host.copy()
     oracle128.gate_batch(ops, in0, in1, in2, out, ref, nthreads=os.cpu_count() or 1)
-    for lat in ("fft", "w32", "lat3"):
+    for lat in ("fft", "latfft", "w32", "lat3"):
         for ks in ("0", "1"):
             monkeypatch.setenv("IYK_HIP_ROT_KERNEL", lat)
             monkeypatch.setenv("IYK_HIP_KS_KERNEL", ks)

@@ -198,10 +198,12 @@ def test_emulated_fft_path_bit_exact(which, request):
     rows = oracle_lib.adversarial_rows(p.n)
     lins += [np.ascontiguousarray(rows[r]) for r in (0, 3, 6, 7)]
     for lin in lins:
-        got = np.zeros(p.N + 1, dtype=np.uint32)
-        assert em.iyk_emul_blind_rotate_fft(ctypes.byref(p), lin.ctypes.data_as(u32p), bk.ctypes.data_as(dp),
-                                            got.ctypes.data_as(u32p)) == 0
-        assert np.array_equal(orc.bootstrap_lvl1(lin), got)
+        ref = orc.bootstrap_lvl1(lin)
+        # wave-per-rotation kernel, then the workgroup-per-rotation kernel (8 waves, doubled accumulator, frequency-split MAC)
+        for fn in (em.iyk_emul_blind_rotate_fft, em.iyk_emul_blind_rotate_fft_lat):
+            got = np.zeros(p.N + 1, dtype=np.uint32)
+            assert fn(ctypes.byref(p), lin.ctypes.data_as(u32p), bk.ctypes.data_as(dp), got.ctypes.data_as(u32p)) == 0
+            assert np.array_equal(ref, got), fn
     assert 0.0 < em.iyk_emul_fft_round_error(0) < 2.0 ** -10
 
 
