@@ -454,7 +454,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": {"fft": "u32 torus; products exact through a 512-point complex f64 FFT on signed 16-bit key halves (rounding bound 2^-10, rint)",
+            "dtype": {"fft": "u32 torus; products exact through a 512-point complex f64 FFT on signed 16-bit key halves (proven rounding error < 2^-5, rint)",
                       "fp50": "u32 torus; NTT in f64 mod p = 3*2^48+1097729 (exact FMA arithmetic)",
                       "goldilocks": "u32 torus; NTT in u64 mod 2^64-2^32+1"}[path],
             "data": "synthetic",

@@ -250,7 +250,7 @@ int iyk_hip_ntt_path(void);
 
 /* Round 4: return value 2 = the default since — the wave-per-rotation kernel multiplies through a 512-point COMPLEX FP64
  * FFT with every key word split into two signed 16-bit halves (csrc/fft512.hpp): every inverse-transform output is
- * provably within 2^-10 of the exact integer sum, so rint() makes the product the exact schoolbook
+ * provably within 2^-9.0 (128-bit set) / 2^-5.6 (80-bit set) of the exact integer sum for ANY key and digits, so rint() makes the product the exact schoolbook
  * one — the same ciphertext words as paths 1 and 0 — at about half the instructions per CMUX step.  The narrow-frontier
  * kernel stays on path 1's field, so both key forms are resident (iyk_hip_resident_key_bytes).  IYK_HIP_NTT = fft / fp /
  * goldilocks at iyk_hip_init selects 2 / 1 / 0; IYK_HIP_ROT_KERNEL = fft forces a batch onto the FFT kernel.

@@ -666,7 +666,8 @@ int iyk_hip_get_params(iyk_params* out)
 int iyk_hip_ntt_path(void) { return G.init.load() ? (G.use_fft ? 2 : G.use_fp ? 1 : 0) : IYK_ERR_STATE; }
 
 /* IYK_HIP_DEBUG=1 at init: the largest |z - rint(z)| any inverse transform of the FFT kernel has produced on this GPU since
- * init (the quantity DESIGN.md §2b bounds by 2^-10); 0 when nothing was recorded. */
+ * init (the quantity DESIGN.md §2b proves below 2^-9.0 / 2^-5.6 for any key and digits at the 128- / 80-bit set; observed
+ * ~2^-20); 0 when nothing was recorded. */
 int iyk_hip_fft_round_error(int gpu_index, double* out)
 {
     if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");

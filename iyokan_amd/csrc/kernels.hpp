@@ -1,11 +1,12 @@
 // kernels.hpp — HIP kernels of the gate-bootstrapping hot path for gfx950 (MI355X).
 //
-//   init        bk_ntt_fp_kernel / bk_ntt_kernel     torus-domain BK rows -> NTT domain (once per GPU)
+//   init        bk_ntt_fp_kernel / bk_ntt_kernel     torus-domain BK rows -> NTT domain (once per GPU; the FFT path's key form: kernels_fft.hpp)
 //   per batch   modswitch_kernel                      linear step + mod-switch of every rotation -> abar[job][n+1]
-//               blind_rotate_fp_t16_kernel<Decomp,NW> one wavefront per rotation, 16 points per lane, 3 waves / SIMD (kernels_t16.hpp): default
-//               blind_rotate_fp_kernel<Decomp>        one wavefront per rotation, 32 points per lane, 2 waves / SIMD (IYK_HIP_TP_KERNEL=w32)
-//               blind_rotate_fp_lat3_kernel<Decomp>   one rotation per workgroup of 8 wavefronts (16 / 8 points per lane): narrow
-//                                                     frontiers, <= 1024 rotations (3.6-3.9 ms per rotation instead of 20)
+//               (default rotation kernels: kernels_fft.hpp — blind_rotate_fft_kernel, blind_rotate_fft_lat_kernel)
+//               blind_rotate_fp_kernel<Decomp>        FP64 field, one wavefront per rotation, 32 points per lane, 2 waves / SIMD: the
+//                                                     full rounds of IYK_HIP_NTT=fp, the cross-check of the FFT path (19.7 ms per 2048)
+//               blind_rotate_fp_lat3_kernel<Decomp>   FP64 field, one rotation per workgroup of 8 wavefronts (16 / 8 points per lane):
+//                                                     narrow frontiers of IYK_HIP_NTT=fp (3.35 ms per rotation)
 //               blind_rotate_kernel<L,BGBIT>          one wavefront per rotation, Goldilocks integers (IYK_HIP_NTT=goldilocks)
 //               sample_extract_kernel                 TRLWE -> TLWE lvl1 (CMUX-memory helper entry point only)
 //               keyswitch_init_kernel + keyswitch_wave_kernel<T,NC,16>   lvl1 -> lvl0 identity key switch, 16 gates and whole rows
@@ -21,7 +22,7 @@
 #include "blind_rotate_core.hpp"
 #include "blind_rotate_fp.hpp"
 #include "blind_rotate_lat3.hpp"
-#include "blind_rotate_t16.hpp"
+#include "blind_rotate_t16.hpp"   // arrangement-P helpers of the 16-points-per-lane transform (used by the lat3 kernel)
 
 namespace iyk {
 

@@ -176,8 +176,8 @@ def _fft_keys(em, keys):
 def test_emulated_fft_path_bit_exact(which, request):
     """The complex-FFT kernel (key words split into signed 16-bit halves, 512-point FP64 FFT, rint): lane-by-lane emulation
     == oracle word for word on fresh encryptions AND on the adversarial rows, both parameter sets (the 80-bit set with its
-    10-bit digits as they are — no digit split), and every inverse-transform output within 2^-10 of an integer (the bound
-    DESIGN.md §2b proves; observed: ~2^-20)."""
+    10-bit digits as they are — no digit split), and every inverse-transform output within 2^-10 of an integer (a trip-wire
+    far inside the < 2^-5.6 that DESIGN.md §2b proves for any key and digits; observed: ~2^-20)."""
     import oracle_lib
 
     keys = request.getfixturevalue("keys" + which)

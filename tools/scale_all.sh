@@ -15,7 +15,8 @@ NET_GPUS=${NET_GPUS:-"1 8"}
 run() {   # run <label> <cmd...>
   local label=$1; shift
   local line rc
-  line=$("$@" 2>/tmp/scale_all.err | tail -1); rc=${PIPESTATUS[0]}
+  "$@" > /tmp/scale_all.out 2>/tmp/scale_all.err; rc=$?
+  line=$(tail -1 /tmp/scale_all.out)
   if [ "$rc" -ne 0 ] || [ -z "$line" ]; then
     echo "{\"refused\": \"$label\", \"status\": $rc, \"stderr\": \"$(tail -1 /tmp/scale_all.err | tr -d '"\\' | cut -c1-200)\"}" >> "$out"
     echo "scale_all: $label failed with status $rc" >&2
