@@ -264,9 +264,16 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
         if (i % (u32)(IYK_FFT_BARRIER_EVERY) == 0u) asm volatile("s_barrier" ::: "memory");
 
         fft::cplx S[2][2][8];   // [c'][half][k2]
+        u32 u[16];
+        // one row: (rotated difference at the first level of a polynomial,) digits, forward transform, MAC against the row's
+        // four key spectra, frequency block q = register q.  The key words come through a ring of KB_RING blocks (4 loads of
+        // 16 bytes per lane each): blocks 0 .. KB_AHEAD-1 of a row were issued during the previous row's MAC and landed during
+        // the transform; the rest are issued as ring slots free up, and the tail of a MAC issues the first blocks of the NEXT
+        // row (the rows of all steps are contiguous; past the last row the descriptor's bounds check returns zeros that nobody
+        // uses).  The sums start from zero: assigning them in the first row instead (a second code path, or the first row
+        // peeled out of the loop) made the register allocator copy or spill S (profiles/r04_fft_ab.txt).
 #pragma unroll
         for (int e = 0; e < 32; ++e) S[e >> 4][(e >> 3) & 1][e & 7] = {0.0, 0.0};
-        u32 u[16];
 #pragma unroll 1
         for (int r = 0; r < 2 * L; ++r) {
             int lane = lane0;
@@ -276,11 +283,6 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
             fft::cplx a[8];
             fft::digits8<G>(lvl, u, a);
             fft_forward(lane, a, U, s_t1 + lane, s_t2 + (lane & 7), xb);
-            // MAC against the row's four key spectra, frequency block q = register q.  The key words come through a ring of
-            // KB_RING blocks (4 loads of 16 bytes per lane each): blocks 0 .. KB_AHEAD-1 of this row were issued during the
-            // previous row's MAC and landed during the transform above; the rest are issued one block ahead of their use as
-            // ring slots free up, and the tail of this MAC issues the first blocks of the NEXT row (the rows of all steps are
-            // contiguous; past the last row the buffer descriptor's bounds check returns zeros that nobody uses).
 #ifdef IYK_FFT_TIMING_L1KEYS
             const u32 row_off = 0u;
 #else
