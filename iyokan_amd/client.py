@@ -33,6 +33,9 @@ def _lib():
         lib.iyk_client_decrypt_bits.argtypes = [ctypes.POINTER(IykParams), _u32p, _u32p, ctypes.c_uint64, _u8p]
         lib.iyk_client_phases.argtypes = [ctypes.POINTER(IykParams), _u32p, _u32p, ctypes.c_uint64, _u32p]
         lib.iyk_client_trivial.argtypes = [ctypes.POINTER(IykParams), ctypes.c_int, _u32p]
+        lib.iyk_client_encrypt_trlwe.argtypes = [ctypes.POINTER(IykParams), _u32p, ctypes.c_uint64, ctypes.c_int, _u32p,
+                                                 ctypes.c_uint64, _u32p]
+        lib.iyk_client_trlwe_phases.argtypes = [ctypes.POINTER(IykParams), _u32p, _u32p, ctypes.c_uint64, _u32p]
         _LIB = lib
     return _LIB
 
@@ -76,6 +79,53 @@ def decrypt_bits(keys: KeySet, ct) -> np.ndarray:
     _lib().iyk_client_decrypt_bits(ctypes.byref(keys.params), _p32(keys.s0), _p32(ct), ct.shape[0],
                                    bits.ctypes.data_as(_u8p))
     return bits
+
+
+def encrypt_trlwe(keys: KeySet, msg, seed=None) -> np.ndarray:
+    """trlweSymEncrypt<Lvl1> of message polynomials (count, N) torus words -> (count, 2N): a(X) then b(X)."""
+    msg = np.ascontiguousarray(msg, dtype=np.uint32).reshape(-1, keys.params.N)
+    out = np.zeros((msg.shape[0], 2 * keys.params.N), dtype=np.uint32)
+    _lib().iyk_client_encrypt_trlwe(ctypes.byref(keys.params), _p32(keys.s1), 0 if seed is None else int(seed),
+                                    int(seed is not None), _p32(msg), msg.shape[0], _p32(out))
+    return out
+
+
+def trlwe_phases(keys: KeySet, ct) -> np.ndarray:
+    """b - a * s1 of TRLWE lvl1 rows (count, 2N) -> (count, N); trlweSymDecrypt is `(int32) phase > 0` per coefficient."""
+    ct = np.ascontiguousarray(ct, dtype=np.uint32).reshape(-1, 2 * keys.params.N)
+    out = np.zeros((ct.shape[0], keys.params.N), dtype=np.uint32)
+    _lib().iyk_client_trlwe_phases(ctypes.byref(keys.params), _p32(keys.s1), _p32(ct), ct.shape[0], _p32(out))
+    return out
+
+
+def encrypt_ram_trlwe(keys: KeySet, bits, seed=None) -> np.ndarray:
+    """encryptRAM (/root/reference/src/packet.hpp:104-118): one TRLWE per bit, +-mu in coefficient 0."""
+    bits = np.asarray(bits, dtype=np.uint8).ravel()
+    msg = np.zeros((bits.size, keys.params.N), dtype=np.uint32)
+    mu = int(keys.params.mu)
+    msg[:, 0] = np.where(bits == 1, np.uint32(mu), np.uint32((1 << 32) - mu))
+    return encrypt_trlwe(keys, msg, seed)
+
+
+def decrypt_ram_trlwe(keys: KeySet, ct) -> np.ndarray:
+    """decryptRAM (:153-164): coefficient 0 of every TRLWE."""
+    return (trlwe_phases(keys, ct)[:, 0].view(np.int32) > 0).astype(np.uint8)
+
+
+def encrypt_rom_trlwe(keys: KeySet, bits, seed=None) -> np.ndarray:
+    """encryptROM (:78-97): N bits per TRLWE, +-mu per coefficient, 0 beyond the last bit."""
+    bits = np.asarray(bits, dtype=np.uint8).ravel()
+    N = keys.params.N
+    count = -(-bits.size // N)
+    mu = int(keys.params.mu)
+    msg = np.zeros(count * N, dtype=np.uint32)
+    msg[: bits.size] = np.where(bits == 1, np.uint32(mu), np.uint32((1 << 32) - mu))
+    return encrypt_trlwe(keys, msg.reshape(count, N), seed)
+
+
+def decrypt_rom_trlwe(keys: KeySet, ct) -> np.ndarray:
+    """decryptROM (:172-183): every coefficient of every TRLWE (the padding of the last block decrypts to noise signs)."""
+    return (trlwe_phases(keys, ct).view(np.int32) > 0).astype(np.uint8).ravel()
 
 
 def phases(keys: KeySet, ct) -> np.ndarray:

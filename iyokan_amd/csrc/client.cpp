@@ -210,6 +210,39 @@ int iyk_client_phases(const iyk_params* p, const uint32_t* s0, const uint32_t* c
     return 0;
 }
 
+// TRLWE lvl1 encryptions of message polynomials (count x N torus words in, count x 2N words out: a(X) then b(X)):
+// TFHEpp trlweSymEncrypt<Lvl1>(pmu, alpha1, key.lvl1) as PlainPacket::encrypt uses it for the CMUX memories' `ram` (one TRLWE
+// per bit: +-mu in coefficient 0) and `rom` (N bits per TRLWE) maps, /root/reference/src/packet.hpp:78-122
+int iyk_client_encrypt_trlwe(const iyk_params* p, const uint32_t* s1, uint64_t seed, int deterministic,
+                             const uint32_t* msg, uint64_t count, uint32_t* out)
+{
+    Rng rng(seed, deterministic);
+    const uint32_t N = p->N;
+    for (uint64_t g = 0; g < count; ++g) {
+        uint32_t* a = out + g * 2 * N;
+        trlwe_encrypt_zero(p, s1, rng, a, a + N);
+        for (uint32_t x = 0; x < N; ++x) a[N + x] += msg[g * N + x];
+    }
+    return 0;
+}
+
+// phase polynomials b - a * s1 of TRLWE lvl1 ciphertexts (count x 2N in, count x N out): trlweSymDecrypt's input
+int iyk_client_trlwe_phases(const iyk_params* p, const uint32_t* s1, const uint32_t* ct, uint64_t count, uint32_t* phases)
+{
+    const uint32_t N = p->N;
+    for (uint64_t g = 0; g < count; ++g) {
+        const uint32_t* a = ct + g * 2 * N;
+        uint32_t* ph = phases + g * N;
+        for (uint32_t x = 0; x < N; ++x) ph[x] = a[N + x];
+        for (uint32_t i = 0; i < N; ++i) {
+            if (!s1[i]) continue;
+            for (uint32_t x = 0; x < N - i; ++x) ph[x + i] -= a[x];
+            for (uint32_t x = N - i; x < N; ++x) ph[x + i - N] += a[x];
+        }
+    }
+    return 0;
+}
+
 // trivial ciphertext (a = 0, b = +-mu): HomCONSTANTONE / ZERO
 // (/root/reference/src/tfhepp_cufhe_wrapper.hpp:29-37)
 int iyk_client_trivial(const iyk_params* p, int bit, uint32_t* out)

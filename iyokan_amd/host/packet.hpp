@@ -556,11 +556,16 @@ T readFromArchiveFile(const std::string& path, const A&... a)
     return ret;
 }
 
-// ---- encrypt / decrypt of packets (PlainPacket::encrypt / TFHEPacket::decrypt, /root/reference/src/packet.hpp:225-285),
-// on the TLWE side the GPU path consumes; needs libiyokan_client.so (keygen / enc / dec stand-in for TFHEpp) ------
+// ---- encrypt / decrypt of packets (PlainPacket::encrypt / TFHEPacket::decrypt, /root/reference/src/packet.hpp:225-290);
+// needs libiyokan_client.so (keygen / enc / dec stand-in for TFHEpp).  Both forms of every memory image, as upstream: TLWE lvl0
+// rows (ramInTLWE / romInTLWE: what the MUX memories and this backend read) and TRLWE lvl1 (ram: one ciphertext per bit with
+// +-mu in coefficient 0; rom: N bits per ciphertext — what upstream's CMUX memories read), so that a request made here can
+// drive either kind of run and a result made upstream decrypts here ------
 extern "C" {
 int iyk_client_encrypt_bits(const iyk_params*, const uint32_t*, uint64_t, int, const uint8_t*, uint64_t, uint32_t*);
 int iyk_client_decrypt_bits(const iyk_params*, const uint32_t*, const uint32_t*, uint64_t, uint8_t*);
+int iyk_client_encrypt_trlwe(const iyk_params*, const uint32_t*, uint64_t, int, const uint32_t*, uint64_t, uint32_t*);
+int iyk_client_trlwe_phases(const iyk_params*, const uint32_t*, const uint32_t*, uint64_t, uint32_t*);
 }
 
 inline TLWEVec encryptBits(const iyk_params& p, const std::vector<uint32_t>& s0, const std::vector<Bit>& src, uint64_t seed = 0,
@@ -576,22 +581,57 @@ inline std::vector<Bit> decryptBits(const iyk_params& p, const std::vector<uint3
     if (!out.empty()) iyk_client_decrypt_bits(&p, s0.data(), src.data(), out.size(), out.data());
     return out;
 }
-// TLWE side only: bits, ramInTLWE, romInTLWE (the TRLWE copies feed the CPU-side CMUX memories upstream)
+// encryptRAM / encryptROM (:78-118): `perCt` bits per TRLWE (1: RAM, coefficient 0 only; N: ROM), +-mu, zero padding
+inline std::vector<uint32_t> encryptTRLWEBits(const iyk_params& p, const std::vector<uint32_t>& s1, const std::vector<Bit>& src,
+                                              size_t perCt, uint64_t seed, int deterministic)
+{
+    const size_t N = p.N, count = (src.size() + perCt - 1) / perCt;
+    std::vector<uint32_t> msg(count * N, 0u), out(count * 2 * N);
+    for (size_t i = 0; i < src.size(); ++i) msg[(i / perCt) * N + i % perCt] = src[i] ? p.mu : 0u - p.mu;
+    if (count) iyk_client_encrypt_trlwe(&p, s1.data(), seed, deterministic, msg.data(), count, out.data());
+    return out;
+}
+// decryptRAM / decryptROM (:153-183): the sign of coefficient 0 (RAM) or of every coefficient (ROM: a multiple of N bits)
+inline std::vector<Bit> decryptTRLWEBits(const iyk_params& p, const std::vector<uint32_t>& s1, const std::vector<uint32_t>& ct,
+                                         size_t perCt)
+{
+    const size_t N = p.N, count = ct.size() / (2 * N);
+    std::vector<uint32_t> ph(count * N);
+    if (count) iyk_client_trlwe_phases(&p, s1.data(), ct.data(), count, ph.data());
+    std::vector<Bit> out;
+    out.reserve(count * perCt);
+    for (size_t g = 0; g < count; ++g)
+        for (size_t i = 0; i < perCt; ++i) out.push_back((int32_t)ph[g * N + i] > 0 ? 1 : 0);
+    return out;
+}
+// s1 empty: TLWE forms only (the callers that only ever feed this backend; 8 KB per RAM bit saved)
 inline TFHEPacket encryptPacket(const iyk_params& p, const std::vector<uint32_t>& s0, const PlainPacket& plain, uint64_t seed = 0,
-                                int deterministic = 0)
+                                int deterministic = 0, const std::vector<uint32_t>& s1 = {})
 {
     TFHEPacket t;
     t.numCycles = plain.numCycles;
     uint64_t k = 0;
-    for (auto& kv : plain.ram) t.ramInTLWE.emplace(kv.first, encryptBits(p, s0, kv.second, seed + (++k), deterministic));
-    for (auto& kv : plain.rom) t.romInTLWE.emplace(kv.first, encryptBits(p, s0, kv.second, seed + (++k), deterministic));
+    for (auto& kv : plain.ram) {
+        t.ramInTLWE.emplace(kv.first, encryptBits(p, s0, kv.second, seed + (++k), deterministic));
+        if (!s1.empty()) t.ram.emplace(kv.first, encryptTRLWEBits(p, s1, kv.second, 1, seed + (++k), deterministic));
+    }
+    for (auto& kv : plain.rom) {
+        t.romInTLWE.emplace(kv.first, encryptBits(p, s0, kv.second, seed + (++k), deterministic));
+        if (!s1.empty()) t.rom.emplace(kv.first, encryptTRLWEBits(p, s1, kv.second, p.N, seed + (++k), deterministic));
+    }
     for (auto& kv : plain.bits) t.bits.emplace(kv.first, encryptBits(p, s0, kv.second, seed + (++k), deterministic));
     return t;
 }
-inline PlainPacket decryptPacket(const iyk_params& p, const std::vector<uint32_t>& s0, const TFHEPacket& t)
+// TFHEPacket::decrypt: the TRLWE maps first (needs s1), the TLWE maps fill in the names the TRLWE maps do not hold
+inline PlainPacket decryptPacket(const iyk_params& p, const std::vector<uint32_t>& s0, const TFHEPacket& t,
+                                 const std::vector<uint32_t>& s1 = {})
 {
     PlainPacket plain;
     plain.numCycles = t.numCycles;
+    if (!s1.empty()) {
+        for (auto& kv : t.ram) plain.ram.emplace(kv.first, decryptTRLWEBits(p, s1, kv.second, 1));
+        for (auto& kv : t.rom) plain.rom.emplace(kv.first, decryptTRLWEBits(p, s1, kv.second, p.N));
+    }
     for (auto& kv : t.ramInTLWE) plain.ram.emplace(kv.first, decryptBits(p, s0, kv.second));
     for (auto& kv : t.romInTLWE) plain.rom.emplace(kv.first, decryptBits(p, s0, kv.second));
     for (auto& kv : t.bits) plain.bits.emplace(kv.first, decryptBits(p, s0, kv.second));

@@ -509,6 +509,24 @@ static int packetSelfTest(const std::string& tomlFile, const std::string& archiv
     readFromArchive(encBack, es, p);
     CHECK(encBack == enc);
     CHECK(samePacketContent(decryptPacket(p, keys.s0, encBack), pkt));
+    {   // both forms of every memory image (TRLWE `ram` / `rom` beside the TLWE rows), as PlainPacket::encrypt upstream
+        const TFHEPacket enc2 = encryptPacket(p, keys.s0, pkt, 5, 1, keys.s1);
+        std::stringstream es2;
+        writeToArchive(es2, enc2, p);
+        TFHEPacket back2;
+        readFromArchive(back2, es2, p);
+        CHECK(back2 == enc2 && back2.ram.size() == pkt.ram.size() && back2.rom.size() == pkt.rom.size());
+        const PlainPacket dec2 = decryptPacket(p, keys.s0, back2, keys.s1);   // TRLWE maps first
+        CHECK(dec2.ram == pkt.ram && dec2.bits == pkt.bits);
+        for (auto& kv : pkt.rom) {   // a ROM's TRLWE form decrypts to a multiple of N bits: the image, then padding
+            const std::vector<Bit>& got = dec2.rom.at(kv.first);
+            CHECK(got.size() % p.N == 0 && got.size() >= kv.second.size() &&
+                  std::equal(kv.second.begin(), kv.second.end(), got.begin()));
+        }
+        TFHEPacket onlyTrlwe;
+        onlyTrlwe.ram = enc2.ram;
+        CHECK(decryptPacket(p, keys.s0, onlyTrlwe, keys.s1).ram == pkt.ram);
+    }
     std::stringstream ks;
     writeToArchive(ks, keys);
     KeyArchive kb;
@@ -649,6 +667,11 @@ int main(int argc, char** argv)
             mode = a;
             inFile = argv[++i];
         }
+        else if (a == "--tfhe-packet-read" && i + 2 < argc) {  // SK.bin PACKET.bin
+            mode = a;
+            bpFile = argv[++i];
+            inFile = argv[++i];
+        }
         else if (a == "--packet-selftest" && i + 1 < argc) {
             mode = a;
             inFile = argv[++i];
@@ -684,13 +707,13 @@ int main(int argc, char** argv)
     }
     if (mode == "--enc") {  // bpFile = SK, inFile = IN.toml, expect = REQ.bin
         const KeyArchive sk = readFromArchiveFile<KeyArchive>(bpFile);
-        writeToArchiveFile(expect, encryptPacket(sk.params, sk.s0, plainPacketFromTOMLFile(inFile)), sk.params);
+        writeToArchiveFile(expect, encryptPacket(sk.params, sk.s0, plainPacketFromTOMLFile(inFile), 0, 0, sk.s1), sk.params);   // both forms of every memory image, as iyokan-packet enc
         return 0;
     }
     if (mode == "--dec") {  // bpFile = SK, inFile = RES.bin; TOML on stdout
         const KeyArchive sk = readFromArchiveFile<KeyArchive>(bpFile);
         const TFHEPacket res = readFromArchiveFile<TFHEPacket>(inFile, sk.params);
-        std::fputs(plainPacketToTOML(decryptPacket(sk.params, sk.s0, res)).c_str(), stdout);
+        std::fputs(plainPacketToTOML(decryptPacket(sk.params, sk.s0, res, sk.s1)).c_str(), stdout);
         return 0;
     }
     if (mode == "--do-hip") {
@@ -727,6 +750,17 @@ int main(int argc, char** argv)
         }
         die("TFHEpp import: expected exactly one bk<lvl01param> and one iksk<lvl10param> blob of a known parameter set "
             "behind cereal pointer ids, and a binary SecretKey (see host/packet.hpp)");
+    }
+    if (mode == "--tfhe-packet-read") {   // an encrypted packet (128-bit set) + the secret key archive: decrypt, print sizes and bits
+        const KeyArchive sk = readFromArchiveFile<KeyArchive>(bpFile);
+        const TFHEPacket t = readFromArchiveFile<TFHEPacket>(inFile, sk.params);
+        const PlainPacket pl = decryptPacket(sk.params, sk.s0, t, sk.s1);
+        std::printf("ok ram=%zu ramInTLWE=%zu rom=%zu romInTLWE=%zu bits=%zu cycles=%d\n", t.ram.size(), t.ramInTLWE.size(),
+                    t.rom.size(), t.romInTLWE.size(), t.bits.size(), t.numCycles ? *t.numCycles : -1);
+        for (auto& kv : pl.ram) { std::printf("ram %s ", kv.first.c_str()); for (size_t i = 0; i < kv.second.size() && i < 64; ++i) std::putchar('0' + kv.second[i]); std::putchar('\n'); }
+        for (auto& kv : pl.rom) { std::printf("rom %s ", kv.first.c_str()); for (size_t i = 0; i < kv.second.size() && i < 64; ++i) std::putchar('0' + kv.second[i]); std::putchar('\n'); }
+        for (auto& kv : pl.bits) { std::printf("bits %s ", kv.first.c_str()); for (size_t i = 0; i < kv.second.size() && i < 64; ++i) std::putchar('0' + kv.second[i]); std::putchar('\n'); }
+        return 0;
     }
     if (mode == "--packet-read") {
         const PlainPacket pkt = readFromArchiveFile<PlainPacket>(inFile);

@@ -195,25 +195,49 @@ class TFHEPacket:
         return 2 * self.params.N if field in ("ram", "rom") else self.params.n + 1
 
     @classmethod
-    def encrypt(cls, keys, plain, seed=None):
-        """PlainPacket::encrypt, TLWE side (bits, ramInTLWE, romInTLWE)."""
+    def encrypt(cls, keys, plain, seed=None, trlwe=True):
+        """PlainPacket::encrypt (/root/reference/src/packet.hpp:225-262): every RAM / ROM image in BOTH forms — TLWE lvl0 rows
+        (`ramInTLWE`, `romInTLWE`: what the MUX memories and this backend read) and TRLWE lvl1 (`ram`: one per bit, `rom`: N bits
+        per ciphertext — what upstream's CMUX memories read), so that a request made here can drive either kind of run;
+        trlwe=False leaves the TRLWE maps empty (4 KB per RAM bit)."""
         from . import client
 
         t = cls(keys.params, plain.cycles)
         k = 0
-        for src, dst in ((plain.ram, t.ramInTLWE), (plain.rom, t.romInTLWE), (plain.bits, t.bits)):
-            for name, bits in src.items():
+        sd = lambda: None if seed is None else seed + k
+        for name, bits in plain.ram.items():
+            k += 1
+            t.ramInTLWE[name] = client.encrypt_bits(keys, bits, seed=sd())
+            if trlwe:
                 k += 1
-                dst[name] = client.encrypt_bits(keys, bits, seed=None if seed is None else seed + k)
+                t.ram[name] = client.encrypt_ram_trlwe(keys, bits, seed=sd())
+        for name, bits in plain.rom.items():
+            k += 1
+            t.romInTLWE[name] = client.encrypt_bits(keys, bits, seed=sd())
+            if trlwe:
+                k += 1
+                t.rom[name] = client.encrypt_rom_trlwe(keys, bits, seed=sd())
+        for name, bits in plain.bits.items():
+            k += 1
+            t.bits[name] = client.encrypt_bits(keys, bits, seed=sd())
         return t
 
     def decrypt(self, keys):
+        """TFHEPacket::decrypt (:264-290): the TRLWE maps first, the TLWE maps fill in names the TRLWE maps do not have
+        (unordered_map::emplace keeps the first); a ROM's TRLWE form decrypts to a multiple of N bits."""
         from . import client
 
         p = PlainPacket(cycles=self.cycles)
-        for src, dst in ((self.ramInTLWE, p.ram), (self.romInTLWE, p.rom), (self.bits, p.bits)):
-            for name, rows in src.items():
-                dst[name] = [int(b) for b in client.decrypt_bits(keys, rows)]
+        for name, rows in self.ram.items():
+            p.ram[name] = [int(b) for b in client.decrypt_ram_trlwe(keys, rows)]
+        for name, rows in self.ramInTLWE.items():
+            p.ram.setdefault(name, [int(b) for b in client.decrypt_bits(keys, rows)])
+        for name, rows in self.rom.items():
+            p.rom[name] = [int(b) for b in client.decrypt_rom_trlwe(keys, rows)]
+        for name, rows in self.romInTLWE.items():
+            p.rom.setdefault(name, [int(b) for b in client.decrypt_bits(keys, rows)])
+        for name, rows in self.bits.items():
+            p.bits[name] = [int(b) for b in client.decrypt_bits(keys, rows)]
         return p
 
     def to_archive(self) -> bytes:

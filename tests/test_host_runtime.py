@@ -32,7 +32,10 @@ def test_reader_rejects_bad_input(tmp_path):
 # ---- the C++ frontend (host/toml.hpp, packet.hpp, blueprint.hpp, plain_frontend.hpp) on the reference's vectors --------
 import sys
 
+import numpy as np
 import pytest
+
+from iyokan_amd import client
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from test_reference_vectors import CASES  # noqa: E402  (the table restating test.rb:385-540)
@@ -97,15 +100,76 @@ def test_cereal_portable_binary_archives(tmp_path):
 
 
 def test_tfhe_packet_archive_round_trip(keys80):
+    """PlainPacket::encrypt fills BOTH forms of every memory image (/root/reference/src/packet.hpp:225-262): TLWE lvl0 rows and
+    TRLWE lvl1 — `ram`: one ciphertext per bit, `rom`: N bits per ciphertext; TFHEPacket::decrypt prefers the TRLWE maps, so a
+    ROM comes back padded to a multiple of N (as upstream); without the TRLWE maps the sizes are exact."""
     from iyokan_amd.packet import PlainPacket, TFHEPacket
 
-    plain = PlainPacket(bits={"x": [1, 0, 1, 1], "reset": [0]}, ram={"ram": [0, 1] * 8}, rom={"rom": [1] * 5}, cycles=3)
+    p = keys80.params
+    plain = PlainPacket(bits={"x": [1, 0, 1, 1], "reset": [0]}, ram={"ram": [0, 1] * 8}, rom={"rom": [1, 0, 0, 1, 1]}, cycles=3)
     enc = TFHEPacket.encrypt(keys80, plain, seed=40)
     data = enc.to_archive()
-    back = TFHEPacket.from_archive(keys80.params, data)
+    back = TFHEPacket.from_archive(p, data)
     assert back.to_archive() == data
-    assert back.decrypt(keys80).same_content(plain)
-    assert set(back.ramInTLWE) == {"ram"} and back.ramInTLWE["ram"].shape == (16, keys80.params.n + 1)
+    assert set(back.ramInTLWE) == {"ram"} and back.ramInTLWE["ram"].shape == (16, p.n + 1)
+    assert back.ram["ram"].shape == (16, 2 * p.N) and back.rom["rom"].shape == (1, 2 * p.N)
+    dec = back.decrypt(keys80)
+    assert dec.bits == plain.bits and dec.ram == plain.ram and dec.cycles == 3
+    assert len(dec.rom["rom"]) == p.N and dec.rom["rom"][:5] == plain.rom["rom"]
+    tl = TFHEPacket.encrypt(keys80, plain, seed=40, trlwe=False)
+    assert tl.ram == {} and tl.rom == {} and TFHEPacket.from_archive(p, tl.to_archive()).decrypt(keys80).same_content(plain)
+    # the TRLWE form alone (what an upstream CMUX-memory run returns for a RAM): still decrypts
+    only = TFHEPacket(p, cycles=1)
+    only.ram["ram"] = enc.ram["ram"]
+    assert TFHEPacket.from_archive(p, only.to_archive()).decrypt(keys80).ram == plain.ram
+
+
+def test_tfhe_packet_hand_assembled_archive_both_readers(keys128, tmp_path):
+    """a reader pinned only by its own writer proves nothing about the FORMAT.  This archive is put
+    together here, field by field, from cereal's PortableBinary rules with struct.pack — endianness byte; per unordered_map a
+    u64 entry count, per entry a u64 string length + bytes and a u64 element count + the raw std::array words; the
+    std::optional<int> as a bool byte + i32 — in serialize() order ar(ram, ramInTLWE, rom, romInTLWE, bits, numCycles)
+    (/root/reference/src/packet.hpp:208-223), without TFHEPacket.to_archive.  Both readers (Python, C++) must accept it and
+    decrypt the same bits; the Python writer must reproduce it byte for byte."""
+    import struct
+
+    from iyokan_amd.packet import TFHEPacket
+
+    p = keys128.params
+    u64 = lambda v: struct.pack("<Q", v)
+    ram_bits, rom_bits, x_bits = [1, 0, 1], [1, 1, 0, 1, 0, 0, 1, 0], [0, 1, 1, 0, 1]
+    ram_t = client.encrypt_ram_trlwe(keys128, ram_bits, seed=1)          # (3, 2N) words
+    rom_t = client.encrypt_rom_trlwe(keys128, rom_bits, seed=2)          # (1, 2N)
+    ram_l = client.encrypt_bits(keys128, ram_bits, seed=3)               # (3, n + 1)
+    x_l = client.encrypt_bits(keys128, x_bits, seed=4)
+    words = lambda a: np.ascontiguousarray(a, dtype="<u4").tobytes()
+    hand = b"\x01"                                                       # little endian
+    hand += u64(1) + u64(4) + b"mem0" + u64(3) + words(ram_t)            # ram: {"mem0": 3 x TRLWELvl1}
+    hand += u64(1) + u64(4) + b"mem0" + u64(3) + words(ram_l)            # ramInTLWE
+    hand += u64(1) + u64(3) + b"rom" + u64(1) + words(rom_t)             # rom: 8 bits in one TRLWE
+    hand += u64(0)                                                       # romInTLWE: empty
+    hand += u64(1) + u64(1) + b"x" + u64(5) + words(x_l)                 # bits
+    hand += b"\x00" + struct.pack("<i", 7)                               # numCycles = 7 (cereal: bool nullopt, then the value)
+    pkt = TFHEPacket.from_archive(p, hand)
+    assert pkt.cycles == 7 and pkt.to_archive() == hand
+    dec = pkt.decrypt(keys128)
+    assert dec.ram == {"mem0": ram_bits} and dec.bits == {"x": x_bits} and dec.rom["rom"][:8] == rom_bits
+    for cut in (hand[:-1], hand + b"\0", hand[:9] + u64(1 << 40) + hand[17:]):
+        with pytest.raises(ValueError, match="Invalid archive"):
+            TFHEPacket.from_archive(p, cut)
+    # the C++ reader on the same bytes, with a secret-key archive assembled the same way (KeyArchive: 8 u32 parameters, two
+    # f64, then s0, s1, bk, ksk as u64-counted u32 vectors; bk / ksk empty in a secret-key archive)
+    sk = b"\x01" + struct.pack("<8I", p.n, p.N, p.k, p.l, p.Bgbit, p.t, p.basebit, p.mu) + struct.pack("<2d", p.alpha0, p.alpha1)
+    sk += u64(p.n) + words(keys128.s0) + u64(p.N) + words(keys128.s1) + u64(0) + u64(0)
+    (tmp_path / "sk.bin").write_bytes(sk)
+    (tmp_path / "pkt.bin").write_bytes(hand)
+    out = subprocess.run([_exe(), "--tfhe-packet-read", str(tmp_path / "sk.bin"), str(tmp_path / "pkt.bin")],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[0] == "ok ram=1 ramInTLWE=1 rom=1 romInTLWE=0 bits=1 cycles=7"
+    assert "ram mem0 101" in lines and "bits x 01101" in lines
+    assert [l for l in lines if l.startswith("rom rom ")][0].split()[2].startswith("11010010")
 
 
 def test_hostile_size_tags_are_refused_before_allocation(tmp_path):
