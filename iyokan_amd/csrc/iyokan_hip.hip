@@ -1,7 +1,7 @@
 // iyokan_hip.hip — implementation of the C ABI in include/iyokan_hip.h (libiyokan_hip.so).
 //
 // Host side of the MI355X backend: owns device-resident keys (NTT-domain BK, padded KSK,
-// twiddle tables) per GPU, streams with their (double-buffered) staging buffers, and turns a batch of
+// twiddle tables) per GPU, streams with their (ring of 8) staging buffers, and turns a batch of
 // gate descriptors into a fixed launch sequence: elementwise (NOT/COPY/CONST), modswitch, blind rotation
 // (wave-per-rotation kernel for full rounds of 2048 + a workgroup-per-rotation kernel for the remainder),
 // keyswitch_init + keyswitch.  Chooses the exact-arithmetic field at init (FP64 p = 3*2^48+1097729 where its
@@ -142,18 +142,22 @@ struct Global {
 
 }  // namespace
 
+// Staging slots per stream, used round-robin: a call may fill slot k + 1 while the work reading slot k is still in flight.
+// Eight, not two, since round 4: in an in-process multi-GPU run every destination stream takes one slot per SOURCE replica and
+// frontier (iyk_hip_arena_sync_slots_multi), and with two slots the host blocked from the third replica on.
+constexpr int STAGE_RING = 8;
+
 struct iyk_hip_stream {
     int gpu = 0;
     hipStream_t s = nullptr;
     bool owned = false;
-    // descriptor staging (pinned host + device), two halves used alternately so that enqueueing
-    // batch k+1 only has to wait for the H2D copy of batch k-1 (long finished), never for batch k
+    // descriptor staging (pinned host + device), STAGE_RING slots used round-robin so that enqueueing
+    // batch k+1 only has to wait for the work of batch k+1-STAGE_RING (long finished), never for batch k
     char* h_stage = nullptr;
     char* d_stage = nullptr;
-    size_t stage_cap = 0;             // bytes per half
+    size_t stage_cap = 0;             // bytes per slot
     int stage_sel = 0;
-    hipEvent_t stage_free = nullptr;  // work reading half 0 done
-    hipEvent_t stage_free1 = nullptr; // ... half 1
+    hipEvent_t stage_free[STAGE_RING] = {};  // work reading slot k done
     hipEvent_t xfer = nullptr, xfer2 = nullptr;  // cross-stream hand-offs of iyk_hip_arena_sync_slots
     // blind-rotation outputs (TLWE lvl1), one row per rotation job
     u32* d_rot = nullptr;
@@ -190,8 +194,8 @@ int ensure_stage(iyk_hip_stream* st, size_t bytes)
     st->d_stage = nullptr;
     st->stage_cap = 0;
     size_t cap = (bytes + bytes / 2 + 4096 + 255) & ~(size_t)255;
-    HIP_TRY(hipHostMalloc((void**)&st->h_stage, 2 * cap, hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void**)&st->d_stage, 2 * cap));
+    HIP_TRY(hipHostMalloc((void**)&st->h_stage, STAGE_RING * cap, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&st->d_stage, STAGE_RING * cap));
     st->stage_cap = cap;
     return IYK_OK;
 }
@@ -201,14 +205,14 @@ int acquire_stage(iyk_hip_stream* st, size_t bytes, size_t* off)
 {
     int rc = ensure_stage(st, bytes);
     if (rc) return rc;
-    st->stage_sel ^= 1;
-    HIP_TRY(hipEventSynchronize(st->stage_sel ? st->stage_free1 : st->stage_free));
-    *off = st->stage_sel ? st->stage_cap : 0;
+    st->stage_sel = (st->stage_sel + 1) % STAGE_RING;
+    HIP_TRY(hipEventSynchronize(st->stage_free[st->stage_sel]));   // blocks only if the work of STAGE_RING calls ago is still running
+    *off = (size_t)st->stage_sel * st->stage_cap;
     return IYK_OK;
 }
 int release_stage(iyk_hip_stream* st)
 {
-    HIP_TRY(hipEventRecord(st->stage_sel ? st->stage_free1 : st->stage_free, st->s));
+    HIP_TRY(hipEventRecord(st->stage_free[st->stage_sel], st->s));
     return IYK_OK;
 }
 
@@ -278,6 +282,22 @@ int launch_br_fft(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
     return IYK_OK;
 }
 
+#ifdef IYK_WITH_FFT2
+// the paired FFT kernel (kernels_fft.hpp, blind_rotate_fft2_kernel): two waves per rotation, 6 rotations per CU, 3 waves / SIMD
+template <class GD>
+int launch_br_fft2(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
+{
+    const Device& D = G.devs[st->gpu];
+    dim3 grid((njobs + BR2_ROT - 1) / BR2_ROT), block(64 * BR2_WAVES);
+    auto kern = G.debug ? blind_rotate_fft2_kernel<GD, true> : blind_rotate_fft2_kernel<GD, false>;
+    hipLaunchKernelGGL(kern, grid, block, BR_FFT2_LDS_BYTES, st->s, (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE,
+                       njobs, (const fft::cplx*)D.bk_fft, (u32)G.bk_fft_bytes, (const fft::Consts*)D.fftc, o.at(first),
+                       G.p.n, G.p.mu, ABAR_STRIDE, o.trlwe, o.idx(first), D.fft_err);
+    HIP_TRY(hipGetLastError());
+    return IYK_OK;
+}
+#endif
+
 // narrow frontiers on the FFT path: one rotation per workgroup of 8 waves (kernels_fft.hpp, blind_rotate_fft_lat_kernel)
 template <class GD>
 int launch_br_fft_lat(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
@@ -308,7 +328,7 @@ int launch_br_fp_lat3(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
 
 // which rotation kernel a batch is forced onto: IYK_HIP_ROT_KERNEL = fft / w32 / lat3 (A/B, tests; read per batch).
 // IYK_HIP_LATENCY_KERNEL = 0 / 3 is the older spelling of w32 / lat3.  0 = no override.
-enum { ROT_AUTO = 0, ROT_W32 = 32, ROT_LAT3 = 3, ROT_FFT = 8, ROT_LATFFT = 9 };
+enum { ROT_AUTO = 0, ROT_W32 = 32, ROT_LAT3 = 3, ROT_FFT = 8, ROT_LATFFT = 9, ROT_FFT2 = 12 };
 int forced_rot_kernel()
 {
     if (const char* k = std::getenv("IYK_HIP_ROT_KERNEL")) {
@@ -317,6 +337,7 @@ int forced_rot_kernel()
         if (v == "lat3") return ROT_LAT3;
         if (v == "fft") return ROT_FFT;
         if (v == "latfft") return ROT_LATFFT;
+        if (v == "fft2") return ROT_FFT2;
     }
     if (const char* lat = std::getenv("IYK_HIP_LATENCY_KERNEL")) {
         if (lat[0] == '0') return ROT_W32;
@@ -335,8 +356,13 @@ int dispatch_fp(iyk_hip_stream* st, int njobs, const RotOut& o)
 {
     int rc;
     const int forced = forced_rot_kernel();
-    if (forced == ROT_FFT || forced == ROT_LATFFT) {
-        if (!G.use_fft) return fail(IYK_ERR_STATE, "IYK_HIP_ROT_KERNEL=fft / latfft needs the FFT key spectra (IYK_HIP_NTT=fft at init)");
+    if (forced == ROT_FFT || forced == ROT_LATFFT || forced == ROT_FFT2) {
+        if (!G.use_fft) return fail(IYK_ERR_STATE, "IYK_HIP_ROT_KERNEL=fft / fft2 / latfft needs the FFT key spectra (IYK_HIP_NTT=fft at init)");
+#ifdef IYK_WITH_FFT2
+        if (forced == ROT_FFT2) return launch_br_fft2<GD>(st, 0, njobs, o);
+#else
+        if (forced == ROT_FFT2) return fail(IYK_ERR_STATE, "IYK_HIP_ROT_KERNEL=fft2: the paired kernel is an experiment, not in this build (-DIYK_WITH_FFT2)");
+#endif
         return forced == ROT_FFT ? launch_br_fft<GD>(st, 0, njobs, o) : launch_br_fft_lat<GD>(st, 0, njobs, o);
     }
     if (forced == ROT_LAT3) return launch_br_fp_lat3<DC>(st, 0, njobs, o);
@@ -446,6 +472,10 @@ int set_fft_attrs()
     int rc;
     if ((rc = set_lds(blind_rotate_fft_kernel<GD, false>, BR_FFT_LDS_BYTES))) return rc;
     if ((rc = set_lds(blind_rotate_fft_kernel<GD, true>, BR_FFT_LDS_BYTES))) return rc;
+#ifdef IYK_WITH_FFT2
+    if ((rc = set_lds(blind_rotate_fft2_kernel<GD, false>, BR_FFT2_LDS_BYTES))) return rc;
+    if ((rc = set_lds(blind_rotate_fft2_kernel<GD, true>, BR_FFT2_LDS_BYTES))) return rc;
+#endif
     if ((rc = set_lds(blind_rotate_fft_lat_kernel<GD, false>, BrLatFft<GD>::LDS_BYTES))) return rc;
     return set_lds(blind_rotate_fft_lat_kernel<GD, true>, BrLatFft<GD>::LDS_BYTES);
 }
@@ -511,7 +541,9 @@ void destroy_stream_resources(iyk_hip_stream* st)
     if (st->d_rot) (void)hipFree(st->d_rot);
     if (st->d_abar) (void)hipFree(st->d_abar);
     if (st->d_scratch) (void)hipFree(st->d_scratch);
-    for (hipEvent_t e : {st->stage_free, st->stage_free1, st->xfer, st->xfer2})
+    for (hipEvent_t e : st->stage_free)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {st->xfer, st->xfer2})
         if (e) (void)hipEventDestroy(e);
     if (st->log_on) {
         for (hipEvent_t e : st->log_events) (void)hipEventDestroy(e);
@@ -599,7 +631,10 @@ int stream_new(int gpu_index, void* wrap, bool do_wrap, iyk_hip_stream** out)
         e = hipStreamCreateWithFlags(&st->s, hipStreamNonBlocking);
         st->owned = (e == hipSuccess);
     }
-    hipEvent_t* plain[] = {&st->stage_free, &st->stage_free1, &st->xfer, &st->xfer2};
+    hipEvent_t* plain[STAGE_RING + 2];
+    for (int k = 0; k < STAGE_RING; ++k) plain[k] = &st->stage_free[k];
+    plain[STAGE_RING] = &st->xfer;
+    plain[STAGE_RING + 1] = &st->xfer2;
     for (hipEvent_t* ev : plain)
         if (e == hipSuccess) {
             what = "hipEventCreateWithFlags";
@@ -1094,7 +1129,8 @@ int iyk_hip_arena_download_slots(iyk_hip_stream* st, const uint32_t* d_arena, ui
 
 // One source replica, ndst destination replicas: gather the listed slots ONCE into the source's staging buffer, then every
 // destination pulls the rows (peer copy over xGMI where iyk_hip_init could enable peer access, else the runtime stages
-// the copy through host memory) and scatters them into its arena.  Event-ordered, never blocks the host.
+// the copy through host memory) and scatters them into its arena.  Event-ordered; the host blocks only when a stream's
+// STAGE_RING staging slots are all still in flight (more than eight transfers queued on one stream).
 int iyk_hip_arena_sync_slots_multi(iyk_hip_stream* st_src, const uint32_t* d_src, uint64_t src_slots, int ndst,
                                    iyk_hip_stream* const* st_dst, uint32_t* const* d_dst, const uint64_t* dst_slots,
                                    uint64_t count, const int32_t* slots)
