@@ -115,13 +115,39 @@ template <class G>
 IYK_HD void diff16_doubled(int L, u32 abar, const u32* acc2, u32 (&u)[16])
 {
 #if defined(__HIP_DEVICE_COMPILE__)
+    // all 24 LDS reads from ONE assembly block with one wait: this runs at the top of the step's critical path, where a wait
+    // per coefficient (the compiler's schedule) is sixteen exposed LDS round trips; the narrow-frontier kernel has the registers
     typedef const __attribute__((address_space(3))) u32* lds_u32;
     const u32 acc_base = (u32)(size_t)(lds_u32)acc2;
     const u32 base4 = ((u32)L - abar) << 2;
+    const u32 own_base = acc_base + ((u32)L << 2);
+    u32 rot[16];
+    u64 own[8];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) rot[q] = ((base4 + 256u * (u32)q) & 0x1FFCu) | acc_base;
+    asm volatile(
+        "ds_read_b32 %0, %0\n" "ds_read_b32 %1, %1\n" "ds_read_b32 %2, %2\n" "ds_read_b32 %3, %3\n"
+        "ds_read_b32 %4, %4\n" "ds_read_b32 %5, %5\n" "ds_read_b32 %6, %6\n" "ds_read_b32 %7, %7\n"
+        "ds_read_b32 %8, %8\n" "ds_read_b32 %9, %9\n" "ds_read_b32 %10, %10\n" "ds_read_b32 %11, %11\n"
+        "ds_read_b32 %12, %12\n" "ds_read_b32 %13, %13\n" "ds_read_b32 %14, %14\n" "ds_read_b32 %15, %15\n"
+        "ds_read2st64_b32 %16, %24 offset0:0 offset1:1\n"
+        "ds_read2st64_b32 %17, %24 offset0:2 offset1:3\n"
+        "ds_read2st64_b32 %18, %24 offset0:4 offset1:5\n"
+        "ds_read2st64_b32 %19, %24 offset0:6 offset1:7\n"
+        "ds_read2st64_b32 %20, %24 offset0:8 offset1:9\n"
+        "ds_read2st64_b32 %21, %24 offset0:10 offset1:11\n"
+        "ds_read2st64_b32 %22, %24 offset0:12 offset1:13\n"
+        "ds_read2st64_b32 %23, %24 offset0:14 offset1:15\n"
+        "s_waitcnt lgkmcnt(0)"
+        : "+v"(rot[0]), "+v"(rot[1]), "+v"(rot[2]), "+v"(rot[3]), "+v"(rot[4]), "+v"(rot[5]), "+v"(rot[6]), "+v"(rot[7]),
+          "+v"(rot[8]), "+v"(rot[9]), "+v"(rot[10]), "+v"(rot[11]), "+v"(rot[12]), "+v"(rot[13]), "+v"(rot[14]), "+v"(rot[15]),
+          "=&v"(own[0]), "=&v"(own[1]), "=&v"(own[2]), "=&v"(own[3]), "=&v"(own[4]), "=&v"(own[5]), "=&v"(own[6]), "=&v"(own[7])
+        : "v"(own_base)
+        : "memory");
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const u32 a = *(lds_u32)(size_t)(((base4 + 256u * (u32)q) & 0x1FFCu) | acc_base);
-        u[q] = G::prepare(a - acc2[L + 64 * q]);
+        const u32 o = (q & 1) ? (u32)(own[q >> 1] >> 32) : (u32)own[q >> 1];
+        u[q] = G::prepare(rot[q] - o);
     }
 #else
 #pragma unroll

@@ -67,18 +67,39 @@ __device__ __forceinline__ void twiddle_and_store(fft::cplx (&a)[8], const fft::
     }
 }
 
-// forward transform of 8 complex points per lane from arrangement A to arrangement F through the wave's exchange buffer
-__device__ __forceinline__ void fft_forward(int lane, fft::cplx (&a)[8], const fft::Twist& u, const fft::cplx* t1_lane,
-                                            const fft::cplx* t2, fft::cplx* xb)
+// Wait until the LDS word at byte address `flag` is >= `want` (a counter only ever raised by the partner wave).  One assembly
+// block: as a C++ loop around an atomic load it became an inner loop that made the register allocator spill ~60 VGPRs around
+// it (4x slower); plain LDS accesses suffice — LDS is coherent within the workgroup, a wave's DS operations execute in order.
+__device__ __forceinline__ void spin_until_at_least(u32 flag, u32 want)
 {
-    {
-        const fft::cplx ta = t1_lane[0], tb = t1_lane[64];
-        __builtin_amdgcn_sched_barrier(0);
-        fft::twist8<false>(a, u);
-        fft::dft8<false>(a);
-        twiddle_and_store<0, false>(a, t1_lane, 64, ta, tb, [&](int k0) { xb[fft::x1_wbase(lane) + 72 * k0] = a[k0]; });
-    }
+    u32 seen;
+    asm volatile(
+        "1:\n\t"
+        "ds_read_b32 %0, %1\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_ge_u32 vcc, %0, %2\n\t"
+        "s_cbranch_vccnz 2f\n\t"
+        "s_sleep 1\n\t"
+        "s_branch 1b\n"
+        "2:"
+        : "=&v"(seen)
+        : "v"(flag), "s"(want)
+        : "vcc", "memory");
+}
+
+// forward transform of 8 complex points per lane from arrangement A to arrangement F through an exchange buffer, in two parts:
+// A = twist, DFT8 over j2, T1, exchange-1 stores; B = exchange-1 reads, DFT8 over j1, T2, exchange 2, DFT8 over j0
+__device__ __forceinline__ void fft_forward_a(int lane, fft::cplx (&a)[8], const fft::Twist& u, const fft::cplx* t1_lane, fft::cplx* xb)
+{
+    const fft::cplx ta = t1_lane[0], tb = t1_lane[64];
+    __builtin_amdgcn_sched_barrier(0);
+    fft::twist8<false>(a, u);
+    fft::dft8<false>(a);
+    twiddle_and_store<0, false>(a, t1_lane, 64, ta, tb, [&](int k0) { xb[fft::x1_wbase(lane) + 72 * k0] = a[k0]; });
     lds_sync();
+}
+__device__ __forceinline__ void fft_forward_b(int lane, fft::cplx (&a)[8], const fft::cplx* t2, fft::cplx* xb)
+{
     fft::x1_get_b(lane, a, xb);
     {
         const fft::cplx ta = t2[8], tb = t2[16];
@@ -92,6 +113,12 @@ __device__ __forceinline__ void fft_forward(int lane, fft::cplx (&a)[8], const f
     fft::x2_get_c(lane, a, xb);
     lds_sync();
     fft::fwd_p3(a);
+}
+__device__ __forceinline__ void fft_forward(int lane, fft::cplx (&a)[8], const fft::Twist& u, const fft::cplx* t1_lane,
+                                            const fft::cplx* t2, fft::cplx* xb)
+{
+    fft_forward_a(lane, a, u, t1_lane, xb);
+    fft_forward_b(lane, a, t2, xb);
 }
 
 // Two independent inverse transforms (the lo and hi halves of one output polynomial) through ONE exchange buffer, software-
@@ -355,26 +382,6 @@ static_assert(BR_FFT2_LDS_BYTES <= 160 * 1024, "paired FFT rotation kernel does 
 #endif
 static_assert(8 % IYK_FFT2_RING == 0 && IYK_FFT2_AHEAD < IYK_FFT2_RING, "the key ring must divide the 8 frequency blocks");
 
-// Wait until the LDS word at byte address `flag` is >= `want` (a counter only ever raised by the partner wave).  One assembly
-// block: as a C++ loop around an atomic load it became an inner loop that made the register allocator spill ~60 VGPRs around
-// it (4x slower); plain LDS accesses suffice — LDS is coherent within the workgroup, a wave's DS operations execute in order.
-__device__ __forceinline__ void spin_until_at_least(u32 flag, u32 want)
-{
-    u32 seen;
-    asm volatile(
-        "1:\n\t"
-        "ds_read_b32 %0, %1\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_cmp_ge_u32 vcc, %0, %2\n\t"
-        "s_cbranch_vccnz 2f\n\t"
-        "s_sleep 1\n\t"
-        "s_branch 1b\n"
-        "2:"
-        : "=&v"(seen)
-        : "v"(flag), "s"(want)
-        : "vcc", "memory");
-}
-
 template <class G, bool CHECK>
 __global__ __launch_bounds__(64 * BR2_WAVES) __attribute__((amdgpu_waves_per_eu(3, 3))) void blind_rotate_fft2_kernel(
     const u32* __restrict__ abar_all, int njobs, const fft::cplx* __restrict__ bk_fft, u32 bk_bytes,
@@ -541,6 +548,9 @@ __global__ __launch_bounds__(64 * BR2_WAVES) __attribute__((amdgpu_waves_per_eu(
 //             multiplies with the 2 L x 4 key values fetched a step ahead, stores the four sums — one writer per value;   barrier 2
 //   inverse   wave w < 4: spectrum (c', half) = (w >> 1, w & 1) -> inverse transform -> rint -> acc2[c'] += word << 16 half
 //             (the two halves of a polynomial add into the same words; integer additions commute);                        barrier 3
+// Tried on top of this (profiles/r04_latfft_trace.txt, r04_lat16_ab.txt): part A of transforms 4, 5 on the idle waves 6, 7 and
+// the last inverse pass split over two waves (no gain: the split inverse is slower); every transform split over two waves on a
+// 16-wave workgroup (6 % slower: seven barriers).  A phase boundary costs ~1 k cycles; the kernel wants fewer, not more.
 // LDS (bytes): T1 8 K | acc2 [2][2048] u32 16 K (8 KB aligned polynomials) | 2 L exchange buffers of 9 K (<= 54 K), reused
 // for the spectra and by the inverse waves | sums cplx [4][512] 32 K | T2 1 K.
 template <class G>
@@ -552,6 +562,19 @@ struct BrLatFft {
                                         4 * fft::M * sizeof(fft::cplx) + BR_FFT_T2_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "FFT latency kernel does not fit the CU's LDS");
 };
+
+// Phase stamps for tools/ubench/latfft_trace.hip only (compiled with -DIYK_LATFFT_TRACE=<step>): s_memtime at the phase
+// boundaries of ONE step, written per wave to the buffer passed in place of out_index.  Not part of the product build.
+#ifdef IYK_LATFFT_TRACE
+#define IYK_FTRACE_DECL unsigned long long ftrace_[16] = {}
+#define IYK_FTRACE(k)                                                                                     \
+    do {                                                                                                  \
+        if (i == (u32)(IYK_LATFFT_TRACE)) ftrace_[k] = __builtin_readcyclecounter();                      \
+    } while (0)
+#else
+#define IYK_FTRACE_DECL
+#define IYK_FTRACE(k)
+#endif
 
 template <class G, bool CHECK>
 __global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_kernel(
@@ -605,39 +628,48 @@ __global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_ker
     double worst = 0.0;
     __syncthreads();
 
+    IYK_FTRACE_DECL;
     u32 ab_next = abar[0];
     for (u32 i = 0; i < n; ++i) {
         const u32 ab = ab_next;
         ab_next = abar[i + 1 < n ? i + 1 : i];
         int lane = lane0;
         asm volatile("" : "+v"(lane));
+        IYK_FTRACE(0);
         // ---- forward: digit polynomial (cF, lvl) -> spectrum in the wave's buffer, [k2][lane'']
         if (fwd) {
             u32 u[16];
             fft::cplx a[8];
             fft::diff16_doubled<G>(lane, ab, acc2 + cF * 2 * NTT_N, u);
             fft::digits8<G>(lvl, u, a);
+            IYK_FTRACE(1);
             fft_forward(lane, a, U, s_t1 + lane, s_t2 + (lane & 7), xb);
 #pragma unroll
             for (int q = 0; q < 8; ++q) xb[q * 64 + lane] = a[q];
+            IYK_FTRACE(2);
         }
         wg_barrier_lds();
+        IYK_FTRACE(3);
         // ---- MAC: frequency block q = wave of all four sums
         {
-            fft::cplx s[4];
+            fft::cplx s[4], d[XF];
+#pragma unroll
+            for (int r = 0; r < XF; ++r) d[r] = s_xb[(size_t)r * M::XB + wave * 64 + lane];   // all reads in flight, then the products
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < XF; ++r) {
-                const fft::cplx d = s_xb[(size_t)r * M::XB + wave * 64 + lane];
 #pragma unroll
                 for (int pc = 0; pc < 4; ++pc) {
-                    if (r == 0) fft::cmac<true>(s[pc], d, kb[r][pc]);
-                    else fft::cmac<false>(s[pc], d, kb[r][pc]);
+                    if (r == 0) fft::cmac<true>(s[pc], d[r], kb[r][pc]);
+                    else fft::cmac<false>(s[pc], d[r], kb[r][pc]);
                 }
             }
 #pragma unroll
             for (int pc = 0; pc < 4; ++pc) s_sum[pc * fft::M + wave * 64 + lane] = s[pc];
         }
+        IYK_FTRACE(4);
         wg_barrier_lds();
+        IYK_FTRACE(5);
         // next step's key values, off the critical path: the waves without inverse work fetch theirs now, the inverse waves
         // after their first pass (8 x 24 KiB through the CU's one texture path would otherwise sit in front of the inverse)
         if (!inv && i + 1 < n) load_keys(i + 1);
@@ -653,10 +685,20 @@ __global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_ker
                 const double e = fft::round_err8(a);
                 worst = e > worst ? e : worst;
             }
+            IYK_FTRACE(6);
             fft::acc_update16_doubled(lane, a, (wave & 1) ? 16 : 0, acc2 + (wave >> 1) * 2 * NTT_N);
+            IYK_FTRACE(7);
         }
         wg_barrier_lds();
+        IYK_FTRACE(8);
     }
+#ifdef IYK_LATFFT_TRACE
+    if (lane0 == 0 && blockIdx.x == 0) {
+        unsigned long long* tr = reinterpret_cast<unsigned long long*>(const_cast<int32_t*>(out_index));
+        for (int k = 0; k < 16; ++k) tr[wave * 16 + k] = ftrace_[k];
+    }
+    out_index = nullptr;
+#endif
     if (CHECK && max_err_bits) {
         unsigned long long b;
         __builtin_memcpy(&b, &worst, 8);
