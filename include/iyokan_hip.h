@@ -248,13 +248,15 @@ int iyk_hip_timing_log_end(iyk_hip_stream* st, uint64_t* batches, double* blind_
  * wave; the default where instantiated); both subtract the same rows mod 2^32, so they agree word for word. */
 int iyk_hip_ntt_path(void);
 
-/* Round 4: return value 2 = the default since — the wave-per-rotation kernel multiplies through a 512-point COMPLEX FP64
- * FFT with every key word split into two signed 16-bit halves (csrc/fft512.hpp): every inverse-transform output is
- * provably within 2^-9.0 (128-bit set) / 2^-5.6 (80-bit set) of the exact integer sum for ANY key and digits, so rint() makes the product the exact schoolbook
- * one — the same ciphertext words as paths 1 and 0 — at about half the instructions per CMUX step.  The narrow-frontier
- * kernel stays on path 1's field, so both key forms are resident (iyk_hip_resident_key_bytes).  IYK_HIP_NTT = fft / fp /
- * goldilocks at iyk_hip_init selects 2 / 1 / 0; IYK_HIP_ROT_KERNEL = fft forces a batch onto the FFT kernel.
- * With IYK_HIP_DEBUG=1 at init the FFT kernel also records the largest |z - rint(z)| it produced: */
+/* Round 4: return value 2 = the default since — both rotation kernels (a wave per rotation for full rounds, a workgroup per
+ * rotation for narrow frontiers) multiply through a 512-point COMPLEX FP64 FFT with every key word split into two signed
+ * 16-bit halves (csrc/fft512.hpp): every inverse-transform output is provably within 2^-9.0 (128-bit set) / 2^-5.6 (80-bit
+ * set) of the exact integer sum for ANY key and digits, so rint() makes the product the exact schoolbook
+ * one — the same ciphertext words as paths 1 and 0 — at two thirds of the instructions per CMUX step.  The field form of the
+ * key stays resident beside the spectra (iyk_hip_resident_key_bytes) so that the field kernels can be forced per batch as a
+ * cross-check.  IYK_HIP_NTT = fft / fp / goldilocks at iyk_hip_init selects 2 / 1 / 0; IYK_HIP_ROT_KERNEL = fft / latfft
+ * forces a batch onto one of the FFT kernels.  With IYK_HIP_DEBUG=1 at init the FFT kernels also record the largest
+ * |z - rint(z)| they produced: */
 int iyk_hip_fft_round_error(int gpu_index, double* out);
 
 /* Digit polynomials per accumulator polynomial and CMUX step.  l on the integer path and for the 128-bit set; 2 l = 4 for

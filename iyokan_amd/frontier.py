@@ -88,12 +88,12 @@ def level_rotations(nl, levels, world=1):
 
 
 def plan_levels(nl, world=1, cost=mi355x_level_cost):
-    """The cheapest, by `cost`, of levelise(), balanced_levels() at three cut granularities and beam_levels() — the greedy
-    is not monotone (a deferral can push a later level over a step), so the plain ASAP levels stay a candidate."""
+    """The cheapest, by `cost`, of levelise(), balanced_levels() at three cut granularities and beam_levels() with both of
+    its tie-breaks — the greedy is not monotone (a deferral can push a later level over a step), so the plain ASAP levels stay a candidate."""
     best, best_t = None, None
     big, small = getattr(cost, "quanta", (2048, 256))
-    for quanta in (None, (big, small), (small,), (big,), "beam"):
-        lv = nl.levelise() if quanta is None else beam_levels(nl, world, cost) if quanta == "beam" else balanced_levels(nl, world, cost, quanta)
+    for quanta in (None, (big, small), (small,), (big,), "id", "fanout"):
+        lv = nl.levelise() if quanta is None else beam_levels(nl, world, cost, tie=quanta) if isinstance(quanta, str) else balanced_levels(nl, world, cost, quanta)
         t = sum(cost(r) for r in level_rotations(nl, lv, world))
         if best is None or t < best_t - 1e-9:
             best, best_t = lv, t
@@ -129,13 +129,16 @@ def _slack_graph(nl):
     return depth, order, succ, npred, alap, rot
 
 
-def beam_levels(nl, world=1, cost=mi355x_level_cost, width=6):
+def beam_levels(nl, world=1, cost=mi355x_level_cost, width=6, tie="id"):
     """balanced_levels with the greedy's one choice per level — where to cut the ready set — searched instead: at every
     level each kept partial schedule is continued with every cut (all ready gates; the largest multiples of a round / a
     pass per rank, and one step below each, that still hold the critical gates), and the `width` cheapest by
     (milliseconds so far + the gates not yet run at the throughput kernel's rate) survive.  Deterministic; the greedy's own
-    schedule is one of the paths, a wider beam only adds others."""
+    schedule is one of the paths, a wider beam only adds others.  Ready gates of equal slack are taken by node number
+    (tie="id") or fewest successors first (tie="fanout"): which of them waits changes what later levels can hold, by 1-3 %
+    of a clock on the benchmark netlists, in either direction — plan_levels keeps the cheaper."""
     depth, order, succ, npred0, alap, rot = _slack_graph(nl)
+    rank = (lambda i: (alap[i], len(succ[i]), i)) if tie == "fanout" else (lambda i: (alap[i], i))
     big, small = getattr(cost, "quanta", (2048, 256))
     rate = cost(big) / big
     total_rot = sum(rot)
@@ -147,7 +150,7 @@ def beam_levels(nl, world=1, cost=mi355x_level_cost, width=6):
             free, boots = [], []
             for i in ready:
                 (free if rot[i] == 0 else boots).append(i)
-            boots.sort(key=lambda i: (alap[i], i))
+            boots.sort(key=rank)
             total = sum(rot[i] for i in boots)
             must = sum(rot[i] for i in boots if alap[i] <= k)
             cuts = {total}

@@ -32,6 +32,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <memory>
+#include <unordered_map>
+#include <vector>
 
 #include "../../include/iyokan_hip.h"
 #include "engine.hpp"
@@ -615,41 +618,57 @@ protected:
     HIPWorkerInfo& getWorkerInfo() override { return wi_[0]; }
 };
 
-inline std::vector<int> planFrontiers(TaskNetwork<HIPWorkerInfo>& net, int G, int width)
-{
-    const int n = (int)net.numNodes();
-    std::vector<int> rot(n), alap(n), indeg0(n);
+// The search itself, on plain vectors (test0_hip --plan-graph runs it without a GPU against frontier.beam_levels): node i
+// needs rot[i] rotations, may start no later than frontier alap[i], waits for indeg0[i] inputs and releases succ[i].
+struct PlanGraph {
     int depth = 0;
-    for (int i = 0; i < n; ++i) depth = std::max(depth, net.node(i).priority + 1);
+    std::vector<int> rot, alap, indeg0;
+    std::vector<std::vector<int>> succ;
+};
+
+// Ready nodes of equal slack are taken by node number, or (fewestSuccessorsFirst) by fan-out and then node number: which
+// of them waits changes what later frontiers can hold, by 1-3 % of a clock either way — planFrontiers keeps the cheaper.
+inline std::vector<int> planLevels(const PlanGraph& pg, int G, int width, double* totalMs = nullptr, bool fewestSuccessorsFirst = false)
+{
+    const int n = (int)pg.rot.size(), depth = pg.depth;
+    const std::vector<int>&rot = pg.rot, &alap = pg.alap, &indeg0 = pg.indeg0;
     long totalRot = 0;
-    for (int i = 0; i < n; ++i) {
-        auto& t = static_cast<TaskHIPGate&>(net.node(i));
-        rot[i] = t.rotations();
-        totalRot += rot[i];
-        alap[i] = depth - 1 - t.priority;
-        indeg0[i] = t.kind == GateKind::DFF ? 0 : (int)t.getInputSize();  // a DFF's input belongs to the next clock
-    }
+    for (int r : rot) totalRot += r;
+    // A partial schedule keeps only what differs from its parent: the gates it placed in its own level, the ready list,
+    // and the remaining-input counts of gates that are released in part (a map as wide as the frontier, not an n-sized
+    // vector).  Growing a partial therefore costs O(frontier), and the whole search O(depth * width * cuts * frontier).
     struct Partial {
         double ms = 0;
         long done = 0;
-        std::vector<int> indeg, ready, round;
+        std::shared_ptr<const Partial> parent;
+        std::vector<int> placed, ready;
+        std::unordered_map<int, int> pending;
     };
     const double rate = levelCostMs(rotationRound()) / (double)rotationRound();
-    std::vector<Partial> beam(1);
-    beam[0].indeg = indeg0;
-    beam[0].round.assign(n, -1);
+    std::vector<std::shared_ptr<Partial>> beam{std::make_shared<Partial>()};
     for (int i = 0; i < n; ++i)
-        if (indeg0[i] == 0) beam[0].ready.push_back(i);
-    auto release = [&](Partial& p, int id, std::vector<int>& into) {
-        for (int d : net.node(id).dependents)
-            if (net.node(d).kind != GateKind::DFF && --p.indeg[d] == 0) into.push_back(d);
+        if (indeg0[i] == 0) beam[0]->ready.push_back(i);
+    auto release = [&](Partial& p, int id) {
+        for (int d : pg.succ[id]) {
+            auto it = p.pending.find(d);
+            if (it == p.pending.end()) it = p.pending.emplace(d, indeg0[d]).first;
+            if (--it->second == 0) {
+                p.pending.erase(it);
+                p.ready.push_back(d);
+            }
+        }
     };
     for (int k = 0; k < depth; ++k) {
-        std::vector<Partial> grown;
-        for (Partial& p : beam) {
+        std::vector<std::shared_ptr<Partial>> grown;
+        for (const auto& pp : beam) {
+            const Partial& p = *pp;
             std::vector<int> free_, boots;
             for (int id : p.ready) (rot[id] == 0 ? free_ : boots).push_back(id);
-            std::sort(boots.begin(), boots.end(), [&](int a, int b) { return alap[a] != alap[b] ? alap[a] < alap[b] : a < b; });
+            std::sort(boots.begin(), boots.end(), [&](int a, int b) {
+                if (alap[a] != alap[b]) return alap[a] < alap[b];
+                if (fewestSuccessorsFirst && pg.succ[a].size() != pg.succ[b].size()) return pg.succ[a].size() < pg.succ[b].size();
+                return a < b;
+            });
             long total = 0, must = 0;
             for (int id : boots) {
                 total += rot[id];
@@ -660,45 +679,73 @@ inline std::vector<int> planFrontiers(TaskNetwork<HIPWorkerInfo>& net, int G, in
                 for (long q : {rotationRound() * G, rotationPass() * G})
                     for (long c : {(total / q) * q, (total / q) * q - q})
                         if (c >= must && c > 0 && std::find(cuts.begin(), cuts.end(), c) == cuts.end()) cuts.push_back(c);
+            std::sort(cuts.begin(), cuts.end());  // with the stable sort below: the order frontier.plan_levels (Python) walks
             for (long cut : cuts) {
-                Partial g;
-                g.ms = p.ms;
-                g.done = p.done;
-                g.indeg = p.indeg;
-                g.round = p.round;
+                auto g = std::make_shared<Partial>();
+                g->ms = p.ms;
+                g->done = p.done;
+                g->parent = pp;
+                g->pending = p.pending;
                 long acc = 0;
                 for (int id : free_) {
-                    g.round[id] = k;
-                    release(g, id, g.ready);
+                    g->placed.push_back(id);
+                    release(*g, id);
                 }
                 for (int id : boots) {
                     if (alap[id] <= k || acc + rot[id] <= cut) {
                         acc += rot[id];
-                        g.round[id] = k;
-                        release(g, id, g.ready);
+                        g->placed.push_back(id);
+                        release(*g, id);
                     }
                     else {
-                        g.ready.push_back(id);
+                        g->ready.push_back(id);
                     }
                 }
-                g.ms += levelCostMs((acc + G - 1) / G);
-                g.done += acc;
+                g->ms += levelCostMs((acc + G - 1) / G);
+                g->done += acc;
                 grown.push_back(std::move(g));
             }
         }
-        std::sort(grown.begin(), grown.end(), [&](const Partial& a, const Partial& b) {
-            const double sa = a.ms + (double)(totalRot - a.done) * rate / G, sb = b.ms + (double)(totalRot - b.done) * rate / G;
-            return sa != sb ? sa < sb : a.done > b.done;
+        std::stable_sort(grown.begin(), grown.end(), [&](const std::shared_ptr<Partial>& a, const std::shared_ptr<Partial>& b) {
+            const double sa = a->ms + (double)(totalRot - a->done) * rate / G, sb = b->ms + (double)(totalRot - b->done) * rate / G;
+            return sa != sb ? sa < sb : a->done > b->done;
         });
         if ((int)grown.size() > width) grown.resize(width);
         beam.swap(grown);
     }
-    const Partial* best = &beam[0];
-    for (const Partial& p : beam)
-        if (p.ms < best->ms) best = &p;
+    const Partial* best = beam[0].get();
+    for (const auto& p : beam)
+        if (p->ms < best->ms) best = p.get();
+    std::vector<int> round(n, -1);
+    int k = depth - 1;
+    for (const Partial* p = best; p && p->parent; p = p->parent.get(), --k)  // the root holds no level of its own
+        for (int id : p->placed) round[id] = k;
     for (int i = 0; i < n; ++i)
-        if (best->round[i] < 0) return {};  // not a complete schedule (a cycle the engine will report): run unplanned
-    return best->round;
+        if (round[i] < 0) return {};  // not a complete schedule (a cycle the engine will report): run unplanned
+    if (totalMs) *totalMs = best->ms;
+    return round;
+}
+
+inline std::vector<int> planFrontiers(TaskNetwork<HIPWorkerInfo>& net, int G, int width)
+{
+    const int n = (int)net.numNodes();
+    PlanGraph pg;
+    pg.rot.resize(n);
+    pg.alap.resize(n);
+    pg.indeg0.resize(n);
+    pg.succ.resize(n);
+    for (int i = 0; i < n; ++i) pg.depth = std::max(pg.depth, net.node(i).priority + 1);
+    for (int i = 0; i < n; ++i) {
+        auto& t = static_cast<TaskHIPGate&>(net.node(i));
+        pg.rot[i] = t.rotations();
+        pg.alap[i] = pg.depth - 1 - t.priority;
+        pg.indeg0[i] = t.kind == GateKind::DFF ? 0 : (int)t.getInputSize();  // a DFF's input belongs to the next clock
+        for (int d : t.dependents)
+            if (net.node(d).kind != GateKind::DFF) pg.succ[i].push_back(d);
+    }
+    double msId = 0, msFan = 0;
+    std::vector<int> byId = planLevels(pg, G, width, &msId), byFan = planLevels(pg, G, width, &msFan, true);
+    return !byFan.empty() && (byId.empty() || msFan < msId - 1e-9) ? byFan : byId;
 }
 
 // numWorkers is accepted for signature parity with the reference and ignored: ONE batching worker drives every GPU

@@ -26,6 +26,10 @@
 //                                   (/root/reference/src/iyokan-packet.cpp:144-178) on this repository's KeyArchive
 //   test0_hip --do-hip BP.toml --bkey EK.bin --in REQ.bin --out RES.bin -c N [--gpus G] [--snapshot F] [--resume F]
 //                                   doHIP(opt): everything from files, like `iyokan tfhe --enable-gpu` (/root/reference/src/main.cpp)
+//   test0_hip --plan-graph FILE [--gpus G] [--tie-fanout]
+//                                   planLevels (the search behind planFrontiers) on a DAG given as text — "n depth width", then
+//                                   per node "rot alap indeg nsucc succ..." — with the library's compiled-in cost table (no
+//                                   GPU): prints the schedule's milliseconds and every node's frontier
 //   test0_hip --hip-run BP.toml IN.toml -c N [--expect OUT.toml] [--gpus G] [--mux-ram-dir DIR] [--snapshot-at K]
 //                                   the same, ENCRYPTED, through HIPFrontend (keys made in-process, request packet
 //                                   encrypted here, result decrypted and compared); with --snapshot-at the run is cut at
@@ -617,12 +621,13 @@ static int hipRun(const std::string& bp, const std::string& in, int cycles, cons
 
 int main(int argc, char** argv)
 {
-    bool with_hip = false, use80 = false, skipReset = false;
+    bool with_hip = false, use80 = false, skipReset = false, tieFanout = false;
     int gpus = 1, cycles = -2, snapshotAt = 0;
     std::string mode, bpFile, inFile, expect, muxRamDir, bkey, outFile, snapshotFile, resumeFile;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--hip") with_hip = true;
+        else if (a == "--tie-fanout") tieFanout = true;
         else if (a == "--80bit") use80 = true;
         else if (a == "--skip-reset") skipReset = true;
         else if (a == "--fixtures" && i + 1 < argc) g_fixtures = argv[++i];
@@ -676,6 +681,10 @@ int main(int argc, char** argv)
             mode = a;
             inFile = argv[++i];
             if (i + 1 < argc && argv[i + 1][0] != '-') expect = argv[++i];
+        }
+        else if (a == "--plan-graph" && i + 1 < argc) {
+            mode = a;
+            inFile = argv[++i];
         }
         else if ((a == "--plain-run" || a == "--hip-run") && i + 2 < argc) {
             mode = a;
@@ -766,6 +775,28 @@ int main(int argc, char** argv)
         const PlainPacket pkt = readFromArchiveFile<PlainPacket>(inFile);
         std::printf("ok %zu %zu %zu\n", pkt.ram.size(), pkt.rom.size(), pkt.bits.size());
         return 0;
+    }
+    if (mode == "--plan-graph") {
+        std::ifstream in(inFile);
+        int n = 0, width = 6;
+        PlanGraph pg;
+        if (!(in >> n >> pg.depth >> width)) die("--plan-graph: bad header");
+        pg.rot.resize(n);
+        pg.alap.resize(n);
+        pg.indeg0.resize(n);
+        pg.succ.resize(n);
+        for (int i = 0; i < n; ++i) {
+            int ns = 0;
+            if (!(in >> pg.rot[i] >> pg.alap[i] >> pg.indeg0[i] >> ns)) die("--plan-graph: bad node");
+            pg.succ[i].resize(ns);
+            for (int& d : pg.succ[i])
+                if (!(in >> d) || d < 0 || d >= n) die("--plan-graph: bad successor");
+        }
+        double ms = 0;
+        const std::vector<int> round = planLevels(pg, gpus, width, &ms, tieFanout);
+        std::printf("ms %.9f\n", ms);
+        for (int r : round) std::printf("%d\n", r);
+        return round.empty() ? 1 : 0;
     }
     if (mode == "--plain-run") return plainRun(bpFile, inFile, cycles, skipReset, muxRamDir);
     if (mode == "--hip-run") {

@@ -1,8 +1,7 @@
-"""GPU: the complex-FFT rotation kernel (csrc/fft512.hpp, kernels_fft.hpp) — exact by a rounding bound, not by a field.
+"""GPU: the complex-FFT rotation kernels (csrc/fft512.hpp, kernels_fft.hpp) — exact by a rounding bound, not by a field.
 
-Every comparison is word for word against the oracle's exact integer arithmetic.  The kernel is forced
-(IYK_HIP_ROT_KERNEL=fft) wherever a batch is smaller than a round, because the size-based dispatch would hand those to the
-narrow-frontier kernel (still on the FP64 field)."""
+Every comparison is word for word against the oracle's exact integer arithmetic.  A kernel is forced (IYK_HIP_ROT_KERNEL =
+fft: a wave per rotation; latfft: a workgroup per rotation) wherever the size-based dispatch would pick the other one."""
 import os
 
 import numpy as np

@@ -195,3 +195,46 @@ def test_hostile_size_tags_are_refused_before_allocation(tmp_path):
         out = subprocess.run([_exe(), "--packet-read", str(f)], capture_output=True, text=True, timeout=60)
         assert out.returncode == rc, (name, out.returncode, out.stdout, out.stderr)
         assert text in out.stdout + out.stderr, (name, out.stdout, out.stderr)
+
+
+@pytest.mark.parametrize("name,kind", [("cahp-ruby-core-yosys.json", "yosys"), ("mux-ram-8-16-16.min.json", "l1"),
+                                       ("cahp-ruby-mux.toml", "blueprint")])
+@pytest.mark.parametrize("world", [1, 2])
+@pytest.mark.parametrize("tie", ["id", "fanout"])
+def test_cpp_planner_equals_the_python_planner(name, kind, world, tie, tmp_path):
+    """host/iyokan_hip.hpp planLevels (what planFrontiers runs; partial schedules kept as deltas) against
+    frontier.beam_levels on the benchmark netlists: the same DAG in the same numbering, the same compiled-in cost table (no
+    GPU, so both ask the library for its defaults), the same search order — the same frontier for every node, the same
+    milliseconds."""
+    from iyokan_amd import frontier as F
+    from iyokan_amd import netlist as N
+    from netlist_util import gold
+
+    if kind == "blueprint":
+        from iyokan_amd.system import load_blueprint
+
+        nl = load_blueprint(gold(name)).nl
+    else:
+        nl = (N.load_iyokanl1_json if kind == "l1" else N.load_yosys_json)(gold(name))
+    depth, order, succ, npred, alap, rot = F._slack_graph(nl)
+    lines = [f"{nl.num_nodes} {depth} 6"]          # nodes without a level (sources) are listed as already-placed nothing
+    placed = set(order)
+    for i in range(nl.num_nodes):
+        if i in placed:
+            lines.append(" ".join(map(str, [rot[i], alap[i] - 1, npred[i], len(succ[i])] + succ[i])))
+        else:
+            lines.append("0 0 0 0")
+    f = tmp_path / "graph.txt"
+    f.write_text("\n".join(lines) + "\n")
+    out = subprocess.run([_exe(), "--plan-graph", str(f), "--gpus", str(world)] + (["--tie-fanout"] if tie == "fanout" else []),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-500:] + out.stderr[-2000:]
+    rows = out.stdout.split()
+    assert rows[0] == "ms"
+    cpp_ms, cpp_round = float(rows[1]), [int(x) for x in rows[2:]]
+    levels = F.beam_levels(nl, world, tie=tie)
+    assert len(cpp_round) == nl.num_nodes
+    for k, lv in enumerate(levels):
+        for i in lv:
+            assert cpp_round[i] == k, (i, k, cpp_round[i])
+    assert cpp_ms == pytest.approx(sum(F.mi355x_level_cost(r) for r in F.level_rotations(nl, levels, world)), rel=1e-9)
