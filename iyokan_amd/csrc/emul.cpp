@@ -2,6 +2,8 @@
 // (blind_rotate_core.hpp).  TEST SUPPORT: lets tests/test_kernel_emulation.py check the
 // kernel's exact data flow (index maps, transposes, MAC, lift) against the oracle in this
 // GPU-less container.  Not loaded by the product path.  Built as libiyk_emul.so.
+#include <cmath>
+#include <algorithm>
 #include <cstdint>
 #include <array>
 #include <cstring>
@@ -13,6 +15,7 @@
 #include "blind_rotate_lat3.hpp"
 #include "blind_rotate_t16.hpp"
 #include "blind_rotate_fft.hpp"
+#include "fft256.hpp"
 
 using namespace iyk;
 
@@ -612,15 +615,62 @@ void fft_inverse1_wave(fft::cplx (*a)[8], fft::cplx* xb)
     ALL_LANES fft::inv_p3(a[lane], C.u, &C.t1[0][lane]);
 }
 
+const fft::Consts256& fft_consts256()
+{
+    static fft::Consts256* C = [] {
+        auto* c = new fft::Consts256();
+        fft::make_consts256(*c);
+        return c;
+    }();
+    return *C;
+}
+// kernels_fft.hpp::hfft_forward / hfft_inverse (half transforms of fft256.hpp), one loop over the lanes per hand-off
+template <int P>
+void hfft_forward_wave(fft::cplx (*x)[4], fft::cplx* xb)
+{
+    const fft::Consts& C = fft_consts();
+    const fft::Consts256& H = fft_consts256();
+    ALL_LANES fft::hfwd_p1(x[lane], C.u, &H.fwd[P][0][lane]);
+    ALL_LANES fft::xtop_put_other(lane, x[lane], xb);
+    ALL_LANES fft::xtop_get_own(lane, x[lane], xb);
+    ALL_LANES fft::hfwd_p2(x[lane], &H.fwd[P][0][lane]);
+    ALL_LANES fft::xmid_put_other(lane, x[lane], xb);
+    ALL_LANES fft::xmid_get_own(lane, x[lane], xb);
+    ALL_LANES fft::hfwd_p3<P>(x[lane], &H.fwd[P][0][lane]);
+    ALL_LANES fft::xlow_put_other(lane, x[lane], xb);
+    ALL_LANES fft::xlow_get_own(lane, x[lane], xb);
+    ALL_LANES fft::hfwd_p4<P>(x[lane]);
+}
+// c[lane][q] = C[r(lane) + 64 q] on entry (lane = (r0, r1, r2)); y[lane][n0] = z[2 lane + P + 128 n0] on exit
+template <int P>
+void hfft_inverse_wave(const fft::cplx (*c)[8], fft::cplx (*y)[4], fft::cplx* xb)
+{
+    const fft::Consts& C = fft_consts();
+    const fft::Consts256& H = fft_consts256();
+    ALL_LANES fft::hinv_pA<P>(c[lane], y[lane], &H.inv[P][0][lane]);
+    ALL_LANES fft::xlow_put_own(lane, y[lane], xb);
+    ALL_LANES fft::xlow_get_other(lane, y[lane], xb);
+    ALL_LANES fft::hinv_pB(y[lane], &H.inv[P][0][lane]);
+    ALL_LANES fft::xmid_put_own(lane, y[lane], xb);
+    ALL_LANES fft::xmid_get_other(lane, y[lane], xb);
+    ALL_LANES fft::hinv_pC(y[lane], &H.inv[P][0][lane]);
+    ALL_LANES fft::xtop_put_own(lane, y[lane], xb);
+    ALL_LANES fft::xtop_get_other(lane, y[lane], xb);
+    ALL_LANES fft::hinv_pD(y[lane], C.u);
+}
+
 // wave-by-wave, lane-by-lane run of kernels_fft.hpp::blind_rotate_fft_lat_kernel: one rotation on 8 waves, doubled accumulator,
-// spectra and sums through "LDS" arrays in the kernel's layouts, the three phases in the order the barriers impose
+// spectra and sums through "LDS" arrays in the kernel's layouts, the three phases in the order the barriers impose; rows
+// NFULL .. 2L-1 forward and every inverse in the halves of fft256.hpp, with the kernel's wave roles
 template <class G>
 void blind_rotate_fft_lat(const iyk_params* p, const u32* lin, const fft::cplx* bk_fft, u32* tlwe1)
 {
-    constexpr int L = G::L, XF = 2 * L;
-    constexpr size_t XB = fft::XCHG_BYTES / sizeof(fft::cplx);
+    constexpr int L = G::L, XF = 2 * L, NFULL = XF == 6 ? 4 : 0;
+    constexpr size_t XB = fft::XCHG_BYTES / sizeof(fft::cplx), HB = fft::XCHG256_BYTES / sizeof(fft::cplx);
+    auto half_buf = [](int row, int par) { return NFULL ? 2 * (row - NFULL) + par : row + 4 * par; };
     std::vector<u32> acc2(4 * NTT_N);
-    std::vector<fft::cplx> s_xb(XF * XB), s_sum(4 * fft::M);
+    std::vector<fft::cplx> s_xb(NFULL * XB + (8 - NFULL) * HB), s_sum(4 * fft::M);
+    fft::cplx* s_hb = s_xb.data() + NFULL * XB;
     const u32 bbar = br_modswitch_b(lin[p->n]);
     for (int e = 0; e < 2 * NTT_N; ++e) {
         const int c = e >> 10, j = e & (NTT_N - 1);
@@ -629,17 +679,29 @@ void blind_rotate_fft_lat(const iyk_params* p, const u32* lin, const fft::cplx* 
         acc2[c * 2 * NTT_N + j] = v;
         acc2[c * 2 * NTT_N + NTT_N + j] = 0u - v;
     }
-    static thread_local fft::cplx a[64][8];
-    static thread_local u32 u[64][16];
+    static thread_local fft::cplx a[64][8], x[64][4];
+    static thread_local u32 u[64][16], u8[64][8];
     for (u32 i = 0; i < p->n; ++i) {
         const u32 ab = br_modswitch_a(lin[i]);
-        for (int wave = 0; wave < XF; ++wave) {   // forward
-            const int cF = wave / L, lvl = wave - cF * L;
-            fft::cplx* xb = s_xb.data() + (size_t)wave * XB;
-            ALL_LANES fft::diff16_doubled<G>(lane, ab, acc2.data() + cF * 2 * NTT_N, u[lane]);
-            ALL_LANES fft::digits8<G>(lvl, u[lane], a[lane]);
-            fft_forward_wave(a, xb);
-            ALL_LANES for (int q = 0; q < 8; ++q) xb[q * 64 + lane] = a[lane][q];
+        for (int wave = 0; wave < 8; ++wave) {   // forward
+            const bool full = wave < NFULL;
+            const int fr = full ? wave : (NFULL ? NFULL + ((wave - NFULL) >> 1) : (wave & 3));
+            const int fp = full ? 0 : (NFULL ? ((wave - NFULL) & 1) : (wave >> 2));
+            const int cF = fr / L, lvl = fr - cF * L;
+            fft::cplx* xbf = full ? s_xb.data() + (size_t)wave * XB : s_hb + (size_t)(wave - NFULL) * HB;
+            if (full) {
+                ALL_LANES fft::diff16_doubled<G>(lane, ab, acc2.data() + cF * 2 * NTT_N, u[lane]);
+                ALL_LANES fft::digits8<G>(lvl, u[lane], a[lane]);
+                fft_forward_wave(a, xbf);
+                ALL_LANES for (int q = 0; q < 8; ++q) xbf[q * 64 + lane] = a[lane][q];
+            }
+            else {
+                ALL_LANES fft::diff8_doubled<G>(lane, fp, ab, acc2.data() + cF * 2 * NTT_N, u8[lane]);
+                ALL_LANES fft::digits4<G>(lvl, u8[lane], x[lane]);
+                if (fp) hfft_forward_wave<1>(x, xbf);
+                else hfft_forward_wave<0>(x, xbf);
+                ALL_LANES for (int q = 0; q < 4; ++q) xbf[q * 64 + fft::h_in_pos(lane)] = x[lane][q];
+            }
         }
         for (int wave = 0; wave < 8; ++wave)      // MAC: frequency block q = wave
             ALL_LANES
@@ -647,7 +709,14 @@ void blind_rotate_fft_lat(const iyk_params* p, const u32* lin, const fft::cplx* 
                 const fft::Keys keys(bk_fft, 0, lane);
                 fft::cplx sacc[4];
                 for (int r = 0; r < XF; ++r) {
-                    const fft::cplx d = s_xb[(size_t)r * XB + wave * 64 + lane];
+                    fft::cplx d;
+                    if (r < NFULL) d = s_xb[(size_t)r * XB + wave * 64 + lane];
+                    else {
+                        const fft::cplx e = s_hb[(size_t)half_buf(r, 0) * HB + (wave & 3) * 64 + lane];
+                        const fft::cplx o = s_hb[(size_t)half_buf(r, 1) * HB + (wave & 3) * 64 + lane];
+                        const double sg = wave < 4 ? 1.0 : -1.0;
+                        d = {fft::fma_(sg, o.re, e.re), fft::fma_(sg, o.im, e.im)};
+                    }
                     for (int pc = 0; pc < 4; ++pc) {
                         const fft::cplx k = keys.at((i * (u32)XF + (u32)r) * 4u * (u32)fft::M, pc, 0, (u32)wave * 1024u);
                         if (r == 0) fft::cmac<true>(sacc[pc], d, k);
@@ -656,15 +725,17 @@ void blind_rotate_fft_lat(const iyk_params* p, const u32* lin, const fft::cplx* 
                 }
                 for (int pc = 0; pc < 4; ++pc) s_sum[pc * fft::M + wave * 64 + lane] = sacc[pc];
             }
-        for (int wave = 0; wave < 4; ++wave) {    // inverse of sum (c', half) = (wave >> 1, wave & 1)
-            fft::cplx* xb = s_xb.data() + (size_t)wave * XB;
-            ALL_LANES for (int q = 0; q < 8; ++q) a[lane][q] = s_sum[wave * fft::M + q * 64 + lane];
-            fft_inverse1_wave(a, xb);
+        for (int wave = 0; wave < 8; ++wave) {    // inverse: output parity wave >> 2 of sum (c', half) = ((wave & 3) >> 1, wave & 1)
+            const int si = wave & 3, ip = wave >> 2;
+            fft::cplx* xbi = wave < NFULL ? s_xb.data() + (size_t)wave * XB : s_hb + (size_t)(wave - NFULL) * HB;
+            ALL_LANES for (int q = 0; q < 8; ++q) a[lane][q] = s_sum[si * fft::M + q * 64 + fft::h_in_pos(lane)];
+            if (ip) hfft_inverse_wave<1>(a, x, xbi);
+            else hfft_inverse_wave<0>(a, x, xbi);
             ALL_LANES
             {
-                const double e = fft::round_err8(a[lane]);
+                const double e = fft::round_err4(x[lane]);
                 if (e > g_fft_worst) g_fft_worst = e;
-                fft::acc_update16_doubled(lane, a[lane], (wave & 1) ? 16 : 0, acc2.data() + (wave >> 1) * 2 * NTT_N);
+                fft::acc_update8_doubled(lane, ip, x[lane], (si & 1) ? 16 : 0, acc2.data() + (si >> 1) * 2 * NTT_N);
             }
         }
     }
@@ -760,6 +831,56 @@ int iyk_emul_blind_rotate_fft_lat(const iyk_params* p, const uint32_t* lin, cons
     else if (p->l == 2 && p->Bgbit == 10) blind_rotate_fft_lat<fft::Gadget<2, 10>>(p, lin, k, tlwe1);
     else return -1;
     return 0;
+}
+/* The half transforms of fft256.hpp against the full ones of fft512.hpp on the same random input: forward — F_0 +- W^k' F_1
+ * against the [k2][lane''] spectrum; inverse — both parities against the full inverse's arrangement-A output.  Returns the
+ * largest absolute difference relative to the largest magnitude (both networks are exact up to rounding: ~1e-15). */
+double iyk_emul_fft256_selftest(unsigned seed)
+{
+    static thread_local fft::cplx a[64][8], b[64][8], x[2][64][4], y[64][4];
+    std::vector<fft::cplx> xb(fft::XCHG_BYTES / sizeof(fft::cplx)), spec(fft::M), half(2 * fft::H);
+    u64 st = 0x9E3779B97F4A7C15ull ^ seed;
+    auto rnd = [&]() {
+        st = st * 6364136223846793005ull + 1442695040888963407ull;
+        return (double)(int32_t)(st >> 40) / 256.0 - 32768.0;   // integers in [-2^15, 2^15)
+    };
+    std::vector<fft::cplx> z(fft::M);
+    for (auto& v : z) v = {rnd(), rnd()};
+    double worst = 0.0, big = 0.0;
+    // forward: full
+    ALL_LANES for (int m = 0; m < 8; ++m) a[lane][m] = z[lane + 64 * m];
+    fft_forward_wave(a, xb.data());
+    ALL_LANES for (int q = 0; q < 8; ++q) spec[q * 64 + lane] = a[lane][q];
+    // forward: halves; F'_p[r + 64 a] is left by lane (r0, r1, r2), register a
+    for (int p = 0; p < 2; ++p) ALL_LANES for (int n0 = 0; n0 < 4; ++n0) x[p][lane][n0] = z[2 * lane + p + 128 * n0];
+    hfft_forward_wave<0>(x[0], xb.data());
+    hfft_forward_wave<1>(x[1], xb.data());
+    for (int p = 0; p < 2; ++p)
+        ALL_LANES for (int q = 0; q < 4; ++q) half[p * fft::H + q * 64 + fft::h_in_pos(lane)] = x[p][lane][q];
+    for (int q = 0; q < 8; ++q)
+        ALL_LANES
+        {
+            const fft::cplx e = half[(q & 3) * 64 + lane], o = half[fft::H + (q & 3) * 64 + lane];
+            const fft::cplx want = spec[q * 64 + lane], got = q < 4 ? fft::cadd(e, o) : fft::csub(e, o);
+            worst = std::max(worst, std::max(std::fabs(got.re - want.re), std::fabs(got.im - want.im)));
+            big = std::max(big, std::max(std::fabs(want.re), std::fabs(want.im)));
+        }
+    // inverse: full (arrangement F in, A out), then both halves from the same spectrum
+    ALL_LANES for (int q = 0; q < 8; ++q) b[lane][q] = spec[q * 64 + lane];
+    fft_inverse1_wave(b, xb.data());
+    for (int p = 0; p < 2; ++p) {
+        ALL_LANES for (int q = 0; q < 8; ++q) a[lane][q] = spec[q * 64 + fft::h_in_pos(lane)];
+        if (p == 0) hfft_inverse_wave<0>(a, y, xb.data());
+        else hfft_inverse_wave<1>(a, y, xb.data());
+        ALL_LANES for (int n0 = 0; n0 < 4; ++n0)
+        {
+            const int j = 2 * lane + p + 128 * n0;
+            const fft::cplx want = b[j & 63][j >> 6], got = y[lane][n0];
+            worst = std::max(worst, std::max(std::fabs(got.re - want.re), std::fabs(got.im - want.im)));
+            big = std::max(big, std::max(std::fabs(want.re), std::fabs(want.im)));
+        }
+    }
+    return worst / big;
 }
 /* largest |z - rint(z)| over every inverse-transform output since the last reset */
 double iyk_emul_fft_round_error(int reset)

@@ -65,7 +65,7 @@ struct Device {
     u64* tw_inv = nullptr;
     fp::NttConsts* fpc = nullptr;  // FP path: 32-point twiddles + twists, read by scalar loads
     fft::cplx* bk_fft = nullptr;   // FFT path: key spectra of the signed 16-bit halves (kernels_fft.hpp), 16 bytes per point
-    fft::Consts* fftc = nullptr;
+    fft::ConstsAll* fftc = nullptr;   // fft512.hpp's constants, then fft256.hpp's
     unsigned long long* fft_err = nullptr;  // IYK_HIP_DEBUG: largest |z - rint(z)| seen by the FFT kernel (bits of a double)
     iyk_level_cost cost{};         // what a level of r rotations costs on this GPU (iyk_hip_level_cost_table)
     void release()
@@ -276,7 +276,7 @@ int launch_br_fft(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
     dim3 grid((njobs + BR_WAVES - 1) / BR_WAVES), block(64 * BR_WAVES);
     auto kern = G.debug ? blind_rotate_fft_kernel<GD, true> : blind_rotate_fft_kernel<GD, false>;
     hipLaunchKernelGGL(kern, grid, block, BR_FFT_LDS_BYTES, st->s, (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE,
-                       njobs, (const fft::cplx*)D.bk_fft, (u32)G.bk_fft_bytes, (const fft::Consts*)D.fftc, o.at(first),
+                       njobs, (const fft::cplx*)D.bk_fft, (u32)G.bk_fft_bytes, &D.fftc->c, o.at(first),
                        G.p.n, G.p.mu, ABAR_STRIDE, o.trlwe, o.idx(first), D.fft_err);
     HIP_TRY(hipGetLastError());
     return IYK_OK;
@@ -291,7 +291,7 @@ int launch_br_fft2(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
     dim3 grid((njobs + BR2_ROT - 1) / BR2_ROT), block(64 * BR2_WAVES);
     auto kern = G.debug ? blind_rotate_fft2_kernel<GD, true> : blind_rotate_fft2_kernel<GD, false>;
     hipLaunchKernelGGL(kern, grid, block, BR_FFT2_LDS_BYTES, st->s, (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE,
-                       njobs, (const fft::cplx*)D.bk_fft, (u32)G.bk_fft_bytes, (const fft::Consts*)D.fftc, o.at(first),
+                       njobs, (const fft::cplx*)D.bk_fft, (u32)G.bk_fft_bytes, &D.fftc->c, o.at(first),
                        G.p.n, G.p.mu, ABAR_STRIDE, o.trlwe, o.idx(first), D.fft_err);
     HIP_TRY(hipGetLastError());
     return IYK_OK;
@@ -307,7 +307,7 @@ int launch_br_fft_lat(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
     auto kern = G.debug ? blind_rotate_fft_lat_kernel<GD, true> : blind_rotate_fft_lat_kernel<GD, false>;
     hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3(M::THREADS), M::LDS_BYTES, st->s,
                        (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE, njobs, (const fft::cplx*)D.bk_fft,
-                       (u32)G.bk_fft_bytes, (const fft::Consts*)D.fftc, o.at(first), G.p.n, G.p.mu, ABAR_STRIDE, o.trlwe,
+                       (u32)G.bk_fft_bytes, (const fft::ConstsAll*)D.fftc, o.at(first), G.p.n, G.p.mu, ABAR_STRIDE, o.trlwe,
                        o.idx(first), D.fft_err);
     HIP_TRY(hipGetLastError());
     return IYK_OK;
@@ -556,7 +556,7 @@ void destroy_stream_resources(iyk_hip_stream* st)
 }
 
 int init_devices(std::vector<Device>& devs, const int* device_ids, int avail, const iyk_params& p, bool use_fp,
-                 bool use_fft, const fft::Consts& fftc, int split, const uint32_t* bk_torus, const std::vector<u32>& ksk_pad, const std::vector<u64>& twf,
+                 bool use_fft, const fft::ConstsAll& fftc, int split, const uint32_t* bk_torus, const std::vector<u32>& ksk_pad, const std::vector<u64>& twf,
                  const std::vector<u64>& twi, const fp::HostTables& fpt)
 {
     const size_t bk_words = (size_t)iyk_bk_words(&p);
@@ -597,12 +597,12 @@ int init_devices(std::vector<Device>& devs, const int* device_ids, int avail, co
         HIP_TRY(hipGetLastError());
         if (use_fft) {  // the wave-per-rotation kernel's key: spectra of the signed 16-bit halves, 2 x 8 KB per polynomial
             HIP_TRY(hipMalloc((void**)&D.bk_fft, polys * 2 * fft::M * sizeof(fft::cplx)));
-            HIP_TRY(hipMalloc((void**)&D.fftc, sizeof(fft::Consts)));
+            HIP_TRY(hipMalloc((void**)&D.fftc, sizeof(fft::ConstsAll)));
             HIP_TRY(hipMalloc((void**)&D.fft_err, sizeof(unsigned long long)));
             HIP_TRY(hipMemset(D.fft_err, 0, sizeof(unsigned long long)));
-            HIP_TRY(hipMemcpy(D.fftc, &fftc, sizeof(fft::Consts), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(D.fftc, &fftc, sizeof(fft::ConstsAll), hipMemcpyHostToDevice));
             hipLaunchKernelGGL(bk_fft_kernel, dim3((unsigned)(polys * 2)), dim3(64), 0, 0, d_bk, D.bk_fft,
-                               (const fft::Consts*)D.fftc, polys);
+                               &D.fftc->c, polys);
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipDeviceSynchronize());
@@ -880,8 +880,11 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
     if (direct && force && std::string(force) == "fft")
         return fail(IYK_ERR_INVALID, "IYK_HIP_DECOMP=direct applies to the FP64 field path (IYK_HIP_NTT=fp), not to IYK_HIP_NTT=fft");
     const bool use_fft = use_fp && !direct && !(force && std::string(force) == "fp");
-    auto fftc = std::make_unique<fft::Consts>();
-    if (use_fft) fft::make_consts(*fftc);
+    auto fftc = std::make_unique<fft::ConstsAll>();
+    if (use_fft) {
+        fft::make_consts(fftc->c);
+        fft::make_consts256(fftc->h);
+    }
     std::vector<u64> twf(NTT_N), twi(2 * NTT_N);  // twi: [k2][j1], then the transposed copy [j1][k2]
     fp::HostTables fpt{};
     if (use_fp) {

@@ -15,6 +15,7 @@
 #include <type_traits>
 
 #include "blind_rotate_fft.hpp"
+#include "fft256.hpp"
 #include "kernels.hpp"
 
 // A/B knobs of tools/ab_fft_variants.sh (defaults = the shipped kernel).  IYK_FFT_TIMING_* variants compute WRONG results on
@@ -101,7 +102,8 @@ __device__ __forceinline__ void fft_forward_a(int lane, fft::cplx (&a)[8], const
     twiddle_and_store<0, false>(a, t1_lane, 64, ta, tb, [&](int k0) { xb[fft::x1_wbase(lane) + 72 * k0] = a[k0]; });
     lds_sync();
 }
-__device__ __forceinline__ void fft_forward_b(int lane, fft::cplx (&a)[8], const fft::cplx* t2, fft::cplx* xb)
+template <class Hook>
+__device__ __forceinline__ void fft_forward_b(int lane, fft::cplx (&a)[8], const fft::cplx* t2, fft::cplx* xb, Hook during_x2)
 {
     fft::x1_get_b(lane, a, xb);
     {
@@ -114,6 +116,7 @@ __device__ __forceinline__ void fft_forward_b(int lane, fft::cplx (&a)[8], const
     }
     lds_sync();
     fft::x2_get_c(lane, a, xb);
+    during_x2();
     lds_sync();
     fft::fwd_p3(a);
 }
@@ -121,7 +124,7 @@ __device__ __forceinline__ void fft_forward(int lane, fft::cplx (&a)[8], const f
                                             const fft::cplx* t2, fft::cplx* xb)
 {
     fft_forward_a(lane, a, u, t1_lane, xb);
-    fft_forward_b(lane, a, t2, xb);
+    fft_forward_b(lane, a, t2, xb, [] {});
 }
 
 // Two independent inverse transforms (the lo and hi halves of one output polynomial) through ONE exchange buffer, software-
@@ -197,6 +200,119 @@ __device__ __forceinline__ void fft_inverse1(int lane, fft::cplx (&x)[8], const 
     for (int k0 = 0; k0 < 8; ++k0) x[k0] = fft::cmulc(x[k0], tw[k0]);
     fft::dft8<true>(x);
     fft::twist8<true>(x, u);
+}
+
+// Half transforms (fft256.hpp: 4 complex points per lane, four radix-4 passes, three wave-local exchanges through a 4 KB buffer).
+// tw = this lane's column of the parity's table (Consts256::fwd[P] / inv[P], stride 64) in LDS: all eleven values are read
+// up front, behind the data reads of the first pass (read where they are used, each sat behind its own wait: 5-6 k cycles
+// per half transform instead of ~2 k — profiles/r04_latfft_trace.txt, "halves, first build").
+__device__ __forceinline__ void hfft_twiddles(const fft::cplx* tw, fft::cplx (&t)[11])
+{
+#pragma unroll
+    for (int k = 0; k < 11; ++k) t[k] = tw[64 * k];
+}
+// The lane's 18 exchange addresses (LDS bytes), computed ONCE per kernel and pinned in registers: left to the compiler the
+// slot arithmetic of fft256.hpp (shifts, masks, XORs: ~12 instructions per exchange) was redone in every step.  The forward
+// transform uses the same slots with the roles of the two sides swapped, so one set serves both directions.
+struct HalfAddr {
+    u32 low[4], low_o[4], mid[4], mid_o[4], top, top_o;   // own side indexed by R, other side by the swapped digit
+};
+__device__ __forceinline__ HalfAddr half_addr(int lane, const fft::cplx* xb)
+{
+    typedef const __attribute__((address_space(3))) fft::cplx* lds_c;
+    const u32 base = (u32)(size_t)(lds_c)xb;
+    const int T = fft::h_top(lane), M_ = fft::h_mid(lane), L = fft::h_low(lane);
+    HalfAddr A;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        A.low[k] = base + 16u * (u32)fft::slot_low(T, M_, L, k);
+        A.low_o[k] = base + 16u * (u32)fft::slot_low(T, M_, k, L);
+        A.mid[k] = base + 16u * (u32)fft::slot_mid(T, M_, L, k);
+        A.mid_o[k] = base + 16u * (u32)fft::slot_mid(T, k, L, M_);
+        asm volatile("" : "+v"(A.low[k]), "+v"(A.low_o[k]), "+v"(A.mid[k]), "+v"(A.mid_o[k]));
+    }
+    A.top = base + 16u * (u32)fft::slot_top(T, M_, L, 0);     // + 1024 R
+    A.top_o = base + 16u * (u32)fft::slot_top(0, M_, L, T);   // + 256 T
+    asm volatile("" : "+v"(A.top), "+v"(A.top_o));
+    return A;
+}
+typedef double lds_v2d_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) lds_v2d_t* lds_v2d_p;
+__device__ __forceinline__ void lds_put1(u32 addr, fft::cplx v) { *(lds_v2d_p)(size_t)addr = lds_v2d_t{v.re, v.im}; }
+__device__ __forceinline__ fft::cplx lds_get1(u32 addr)
+{
+    const lds_v2d_t v = *(lds_v2d_p)(size_t)addr;
+    return {v.x, v.y};
+}
+__device__ __forceinline__ void lds_put4(const u32 (&addr)[4], const fft::cplx (&a)[4])
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lds_put1(addr[k], a[k]);
+}
+__device__ __forceinline__ void lds_get4(const u32 (&addr)[4], fft::cplx (&a)[4])
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = lds_get1(addr[k]);
+}
+template <int STRIDE>
+__device__ __forceinline__ void lds_put4s(u32 addr, const fft::cplx (&a)[4])
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lds_put1(addr + (u32)(STRIDE * k), a[k]);
+}
+template <int STRIDE>
+__device__ __forceinline__ void lds_get4s(u32 addr, fft::cplx (&a)[4])
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = lds_get1(addr + (u32)(STRIDE * k));
+}
+// h1, h2 run while the first / second exchange is under way (the narrow-frontier kernel issues its key loads there)
+template <int P, class H1, class H2>
+__device__ __forceinline__ void hfft_forward(const HalfAddr& A, fft::cplx (&x)[4], const fft::Twist& u, const fft::cplx (&t)[11], H1 h1, H2 h2)
+{
+    fft::hfwd_p1<1>(x, u, t);
+    lds_put4s<256>(A.top_o, x);      // xtop_put_other
+    lds_sync();
+    lds_get4s<1024>(A.top, x);       // xtop_get_own
+    h1();
+    lds_sync();
+    fft::hfwd_p2<1>(x, t);
+    lds_put4(A.mid_o, x);            // xmid_put_other
+    lds_sync();
+    lds_get4(A.mid, x);              // xmid_get_own
+    h2();
+    lds_sync();
+    fft::hfwd_p3<P, 1>(x, t);
+    lds_put4(A.low_o, x);            // xlow_put_other
+    lds_sync();
+    lds_get4(A.low, x);              // xlow_get_own
+    lds_sync();
+    fft::hfwd_p4<P>(x);
+}
+// c[q] = C[r + 64 q] of the lane's r (fft::h_in_pos) -> y[n0] = z[2 lane + P + 128 n0]; h1 .. h3 run while an exchange is under way
+template <int P, class H1, class H2, class H3>
+__device__ __forceinline__ void hfft_inverse(const HalfAddr& A, const fft::cplx (&c)[8], fft::cplx (&y)[4], const fft::Twist& u,
+                                             const fft::cplx (&t)[11], H1 h1, H2 h2, H3 h3)
+{
+    fft::hinv_pA<P, 1>(c, y, t);
+    lds_put4(A.low, y);              // xlow_put_own
+    lds_sync();
+    lds_get4(A.low_o, y);            // xlow_get_other
+    h1();
+    lds_sync();
+    fft::hinv_pB<1>(y, t);
+    lds_put4(A.mid, y);              // xmid_put_own
+    lds_sync();
+    lds_get4(A.mid_o, y);            // xmid_get_other
+    h2();
+    lds_sync();
+    fft::hinv_pC<1>(y, t);
+    lds_put4s<1024>(A.top, y);       // xtop_put_own
+    lds_sync();
+    lds_get4s<256>(A.top_o, y);      // xtop_get_other
+    h3();
+    lds_sync();
+    fft::hinv_pD(y, u);
 }
 
 // BK: [polys][1024] u32 torus -> cplx [polys][2][512]: the spectra of the signed 16-bit halves (lo, hi) of every
@@ -544,26 +660,35 @@ __global__ __launch_bounds__(64 * BR2_WAVES) __attribute__((amdgpu_waves_per_eu(
 
 // ------------------------------------------------------------------------------------------------------------------------
 // Narrow frontiers on the FFT path: ONE ROTATION PER WORKGROUP of 8 wavefronts (one CU each), three workgroup barriers per
-// CMUX step.  Replaces blind_rotate_fp_lat3_kernel's field transforms (12.0 k cycles per step) for the FFT key form:
-//   forward   wave w < 2 L: digit polynomial (c, lvl) = (w / L, w % L): rotated difference from the DOUBLED accumulator,
-//             digits, 512-point transform through the wave's own exchange buffer, spectrum left there as [k2][lane''];  barrier 1
-//   MAC       ALL 8 waves, wave q = frequency block k2 = q: each lane reads its frequency of the 2 L spectra (ds_read_b128),
-//             multiplies with the 2 L x 4 key values fetched a step ahead, stores the four sums — one writer per value;   barrier 2
-//   inverse   wave w < 4: spectrum (c', half) = (w >> 1, w & 1) -> inverse transform -> rint -> acc2[c'] += word << 16 half
-//             (the two halves of a polynomial add into the same words; integer additions commute);                        barrier 3
-// Tried on top of this (profiles/r04_latfft_trace.txt, r04_lat16_ab.txt): part A of transforms 4, 5 on the idle waves 6, 7 and
-// the last inverse pass split over two waves (no gain: the split inverse is slower); every transform split over two waves on a
-// 16-wave workgroup (6 % slower: seven barriers).  A phase boundary costs ~1 k cycles; the kernel wants fewer, not more.
-// LDS (bytes): T1 8 K | acc2 [2][2048] u32 16 K (8 KB aligned polynomials) | 2 L exchange buffers of 9 K (<= 54 K), reused
-// for the spectra and by the inverse waves | sums cplx [4][512] 32 K | T2 1 K.
+// CMUX step, and — since a lone wave issues only every ~8.8 cycles, half of what its SIMD takes — as much of every phase as
+// possible on BOTH waves of each SIMD (waves w and w + 4), by the hand-off-free half transforms of fft256.hpp:
+//   forward   2 L digit polynomials ("rows").  128-bit set (2 L = 6): rows 0 .. 3 as full 512-point transforms on waves 0 .. 3
+//             (spectrum left in the wave's buffer as [k2][lane'']), rows 4, 5 as two half transforms each on waves 4 .. 7 (even /
+//             odd coefficients; F_0 and W^k' F_1 left in the wave's buffer as [a][lane'']).  80-bit set (2 L = 4): all four rows
+//             as halves, wave w = row w & 3, parity w >> 2.  Rotated difference from the DOUBLED accumulator.            barrier 1
+//   MAC       ALL 8 waves, wave q = frequency block k2 = q: each lane reads its frequency of the 2 L spectra (split rows: two
+//             reads and F_0 +- W^k' F_1), multiplies with the 2 L x 4 key values fetched a step ahead, stores the four sums —
+//             one writer per value;                                                                                         barrier 2
+//   inverse   ALL 8 waves: wave w = spectrum (c', half) = ((w & 3) >> 1, w & 1), output parity w >> 2 -> half inverse -> rint
+//             -> acc2[c'] += word << 16 half at its 8 coefficients per lane (the two halves of a polynomial add into the same
+//             words; integer additions commute);                                                                          barrier 3
+// Round-4 history (profiles/r04_latfft_trace.txt, r04_lat16_ab.txt): full transforms only (six forward waves, four inverse
+// waves: 11.8 k cycles per step, 3.36 ms per rotation); splits that duplicate work or add hand-offs — part A on idle waves, the
+// last inverse pass over two waves, every DFT8 pass over two waves of a 16-wave workgroup — were all slower.
+// LDS (bytes): T1 8 K | acc2 [2][2048] u32 16 K (8 KB aligned polynomials) | buffers: NFULL x 9 K + (8 - NFULL) x 4 K (the
+// inverse uses the first 4 K of each) | sums cplx [4][512] 32 K | T2 1 K | half-transform lane constants 44 K.
 template <class G>
 struct BrLatFft {
     static constexpr int L = G::L, XF = 2 * G::L, WAVES = 8, THREADS = 64 * WAVES;
-    static_assert(XF <= WAVES && XF >= 4, "the wave roles assume 4 <= 2 L <= 8");
-    static constexpr size_t XB = fft::XCHG_BYTES / sizeof(fft::cplx);
-    static constexpr size_t LDS_BYTES = BR_FFT_T1_BYTES + 4 * NTT_N * sizeof(u32) + (size_t)XF * fft::XCHG_BYTES +
-                                        4 * fft::M * sizeof(fft::cplx) + BR_FFT_T2_BYTES;
+    static_assert(XF == 4 || XF == 6, "the wave roles are written for 2 L = 4 or 6");
+    static constexpr int NFULL = XF == 6 ? 4 : 0;            // rows transformed whole (waves 0 .. NFULL-1); the rest in halves
+    static constexpr size_t XB = fft::XCHG_BYTES / sizeof(fft::cplx), HB = fft::XCHG256_BYTES / sizeof(fft::cplx);
+    static constexpr size_t BUF_BYTES = (size_t)NFULL * fft::XCHG_BYTES + (size_t)(WAVES - NFULL) * fft::XCHG256_BYTES;
+    static constexpr size_t LDS_BYTES = BR_FFT_T1_BYTES + 4 * NTT_N * sizeof(u32) + BUF_BYTES + 4 * fft::M * sizeof(fft::cplx) +
+                                        BR_FFT_T2_BYTES + sizeof(fft::Consts256);
     static_assert(LDS_BYTES <= 160 * 1024, "FFT latency kernel does not fit the CU's LDS");
+    // the wave that transforms half `par` of split row `row` (row >= NFULL), as an index into the 4 KB buffers
+    __host__ __device__ static constexpr int half_buf(int row, int par) { return NFULL ? 2 * (row - NFULL) + par : row + 4 * par; }
 };
 
 // Phase stamps for tools/ubench/latfft_trace.hip only (compiled with -DIYK_LATFFT_TRACE=<step>): s_memtime at the phase
@@ -582,22 +707,29 @@ struct BrLatFft {
 template <class G, bool CHECK>
 __global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_kernel(
     const u32* __restrict__ abar_all, int njobs, const fft::cplx* __restrict__ bk_fft, u32 bk_bytes,
-    const fft::Consts* __restrict__ Cp, u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride, int trlwe_mode,
+    const fft::ConstsAll* __restrict__ Cp, u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride, int trlwe_mode,
     const int32_t* __restrict__ out_index, unsigned long long* __restrict__ max_err_bits)
 {
     typedef BrLatFft<G> M;
-    constexpr int L = M::L, XF = M::XF;
-    const fft::Consts& C = *Cp;
+    constexpr int L = M::L, XF = M::XF, NFULL = M::NFULL;
+    const fft::Consts& C = Cp->c;
     extern __shared__ __attribute__((aligned(8192))) unsigned char smem[];
     fft::cplx* s_t1 = reinterpret_cast<fft::cplx*>(smem);                                    // [k0][lane], 8 K
     u32* acc2 = reinterpret_cast<u32*>(smem + BR_FFT_T1_BYTES);                              // [2][2 N]: polynomial, then its negation
-    fft::cplx* s_xb = reinterpret_cast<fft::cplx*>(smem + BR_FFT_T1_BYTES + 4 * NTT_N * sizeof(u32));   // [XF][XB]
-    fft::cplx* s_sum = s_xb + (size_t)XF * M::XB;                                            // [4][512]
+    fft::cplx* s_xb = reinterpret_cast<fft::cplx*>(smem + BR_FFT_T1_BYTES + 4 * NTT_N * sizeof(u32));   // NFULL x XB, then 4 KB buffers
+    fft::cplx* s_hb = s_xb + (size_t)NFULL * M::XB;                                          // [8 - NFULL][256]
+    fft::cplx* s_sum = reinterpret_cast<fft::cplx*>(smem + BR_FFT_T1_BYTES + 4 * NTT_N * sizeof(u32) + M::BUF_BYTES);   // [4][512]
     fft::cplx* s_t2 = s_sum + 4 * fft::M;                                                    // [b][a]
+    fft::cplx* s_h = s_t2 + 64;                                                              // Consts256: inv[2][11][64], fwd[2][11][64]
     static_assert(BR_FFT_T1_BYTES % 8192 == 0, "diff16_doubled needs 8 KB aligned accumulators");
 
-    for (int e = threadIdx.x; e < 8 * 64; e += M::THREADS) s_t1[e] = C.t1[e >> 6][e & 63];
-    if (threadIdx.x < 64) s_t2[threadIdx.x] = C.t2t[threadIdx.x >> 3][threadIdx.x & 7];
+    if (NFULL)
+        for (int e = threadIdx.x; e < 8 * 64; e += M::THREADS) s_t1[e] = C.t1[e >> 6][e & 63];
+    if (NFULL && threadIdx.x < 64) s_t2[threadIdx.x] = C.t2t[threadIdx.x >> 3][threadIdx.x & 7];
+    {
+        const fft::cplx* src = &Cp->h.inv[0][0][0];
+        for (int e = threadIdx.x; e < (int)(sizeof(fft::Consts256) / sizeof(fft::cplx)); e += M::THREADS) s_h[e] = src[e];
+    }
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane0 = threadIdx.x & 63;
@@ -613,21 +745,37 @@ __global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_ker
             acc2[c * 2 * NTT_N + NTT_N + j] = 0u - v;
         }
     }
-    const bool fwd = wave < XF;                      // transform wave: digit polynomial (cF, lvl)
-    const int cF = fwd ? wave / L : 0, lvl = fwd ? wave - cF * L : 0;
-    const bool inv = wave < 4;                       // inverse wave: spectrum (c', half) = (wave >> 1, wave & 1)
-    fft::cplx* xb = s_xb + (size_t)(fwd ? wave : 0) * M::XB;
+    // forward role: waves below NFULL transform row = wave whole; the others one half (row fr, parity fp) of a split row
+    const bool full = wave < NFULL;
+    const int fr = full ? wave : (NFULL ? NFULL + ((wave - NFULL) >> 1) : (wave & 3));
+    const int fp = full ? 0 : (NFULL ? ((wave - NFULL) & 1) : (wave >> 2));
+    const int cF = fr / L, lvl = fr - cF * L;
+    fft::cplx* xbf = full ? s_xb + (size_t)wave * M::XB : s_hb + (size_t)(wave - NFULL) * M::HB;
+    // inverse role: spectrum si = (c', half), output parity ip; its 4 KB of exchange space = the start of the wave's own
+    // (then dead) forward buffer, so that one set of exchange addresses serves both phases
+    const int si = wave & 3, ip = wave >> 2;
+    const HalfAddr HA = half_addr(lane0, xbf);
+    int in_pos = fft::h_in_pos(lane0);
+    asm volatile("" : "+v"(in_pos));
     fft::Twist U = C.u;
     asm volatile("" : "+s"(U.c1), "+s"(U.s1), "+s"(U.c2), "+s"(U.s2), "+s"(U.c3), "+s"(U.s3));
     const fft::Keys keys(bk_fft, bk_bytes, lane0);
     fft::cplx kb[XF][4];                             // this wave's key values of one step: frequency block q = wave
-    auto load_keys = [&](u32 step) {
+    // One row of a step's key values (4 x 1 KiB per wave).  The eight waves of the CU share ONE texture path (16 cycles per
+    // 1 KiB wave load: 3 k cycles per step for all of them) and a wave that issues into a full queue stalls — with everything
+    // it would have issued next; now that every wave is busy in every phase there is no idle wave to issue them.  So they go
+    // out one row at a time, each behind an LDS exchange: rows 0 .. XF-3 of step i + 1 during the inverse phase of step i,
+    // the last two rows at the top of the forward phase (>= 2.5 k cycles before the MAC that uses them).  Past the last step
+    // the loads run off the end of the buffer descriptor and return zeros.
+    auto load_row = [&](u32 step, int R) {
 #pragma unroll
         for (int r = 0; r < XF; ++r)
 #pragma unroll
-            for (int pc = 0; pc < 4; ++pc) kb[r][pc] = keys.at((step * (u32)XF + (u32)r) * 4u * (u32)fft::M, pc, 0, (u32)wave * 1024u);
+            for (int pc = 0; pc < 4; ++pc)
+                if (r == R) kb[r][pc] = keys.at((step * (u32)XF + (u32)r) * 4u * (u32)fft::M, pc, 0, (u32)wave * 1024u);
     };
-    load_keys(0);
+#pragma unroll
+    for (int r = 0; r < XF - 2; ++r) load_row(0, r);
     double worst = 0.0;
     __syncthreads();
 
@@ -639,26 +787,54 @@ __global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_ker
         int lane = lane0;
         asm volatile("" : "+v"(lane));
         IYK_FTRACE(0);
-        // ---- forward: digit polynomial (cF, lvl) -> spectrum in the wave's buffer, [k2][lane'']
-        if (fwd) {
+        // ---- forward
+        if (full) {   // row = wave -> spectrum in the wave's buffer, [k2][lane'']
             u32 u[16];
             fft::cplx a[8];
+            load_row(i, XF - 2);
             fft::diff16_doubled<G>(lane, ab, acc2 + cF * 2 * NTT_N, u);
             fft::digits8<G>(lvl, u, a);
             IYK_FTRACE(1);
-            fft_forward(lane, a, U, s_t1 + lane, s_t2 + (lane & 7), xb);
+            fft_forward_a(lane, a, U, s_t1 + lane, xbf);
+            load_row(i, XF - 1);
+            fft_forward_b(lane, a, s_t2 + (lane & 7), xbf, [] {});
 #pragma unroll
-            for (int q = 0; q < 8; ++q) xb[q * 64 + lane] = a[q];
+            for (int q = 0; q < 8; ++q) xbf[q * 64 + lane] = a[q];
+            IYK_FTRACE(2);
+        }
+        else {        // half fp of row fr -> F_0 resp. W^k' F_1 in the wave's buffer, [a][lane''] (frequency r + 64 a of lane (r0, r1, r2))
+            u32 u[8];
+            fft::cplx x[4];
+            fft::cplx t[11];
+            load_row(i, XF - 2);
+            hfft_twiddles(s_h + (2 + fp) * 11 * 64 + lane, t);
+            fft::diff8_doubled<G>(lane, fp, ab, acc2 + cF * 2 * NTT_N, u);
+            fft::digits4<G>(lvl, u, x);
+            IYK_FTRACE(1);
+            auto k1 = [&] { load_row(i, XF - 1); };
+            auto k2 = [] {};
+            if (fp) hfft_forward<1>(HA, x, U, t, k1, k2);
+            else hfft_forward<0>(HA, x, U, t, k1, k2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xbf[q * 64 + in_pos] = x[q];
             IYK_FTRACE(2);
         }
         wg_barrier_lds();
         IYK_FTRACE(3);
         // ---- MAC: frequency block q = wave of all four sums
         {
-            fft::cplx s[4], d[XF];
+            fft::cplx s[4], d[XF], o[XF - NFULL];
 #pragma unroll
-            for (int r = 0; r < XF; ++r) d[r] = s_xb[(size_t)r * M::XB + wave * 64 + lane];   // all reads in flight, then the products
+            for (int r = 0; r < NFULL; ++r) d[r] = s_xb[(size_t)r * M::XB + wave * 64 + lane];   // all reads in flight, then the products
+#pragma unroll
+            for (int r = NFULL; r < XF; ++r) {
+                d[r] = s_hb[(size_t)M::half_buf(r, 0) * M::HB + (wave & 3) * 64 + lane];
+                o[r - NFULL] = s_hb[(size_t)M::half_buf(r, 1) * M::HB + (wave & 3) * 64 + lane];
+            }
             __builtin_amdgcn_sched_barrier(0);
+            const double sg = wave < 4 ? 1.0 : -1.0;   // A[k' + 256 b] = F_0[k'] + (-1)^b W^k' F_1[k']
+#pragma unroll
+            for (int r = NFULL; r < XF; ++r) d[r] = {fft::fma_(sg, o[r - NFULL].re, d[r].re), fft::fma_(sg, o[r - NFULL].im, d[r].im)};
 #pragma unroll
             for (int r = 0; r < XF; ++r) {
 #pragma unroll
@@ -673,23 +849,24 @@ __global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_ker
         IYK_FTRACE(4);
         wg_barrier_lds();
         IYK_FTRACE(5);
-        // next step's key values, off the critical path: the waves without inverse work fetch theirs now, the inverse waves
-        // after their first pass (8 x 24 KiB through the CU's one texture path would otherwise sit in front of the inverse)
-        if (!inv && i + 1 < n) load_keys(i + 1);
-        // ---- inverse of sum (c', half) -> accumulator polynomial c'
-        if (inv) {
-            fft::cplx a[8];
+        // ---- inverse: output parity ip of sum si -> accumulator polynomial si >> 1
+        {
+            fft::cplx c[8], y[4], t[11];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) a[q] = s_sum[wave * fft::M + q * 64 + lane];
-            fft_inverse1(lane, a, U, s_t1 + lane, s_t2 + (lane & 7), xb, [&] {
-                if (i + 1 < n) load_keys(i + 1);
-            });
+            for (int q = 0; q < 8; ++q) c[q] = s_sum[si * fft::M + q * 64 + in_pos];
+            hfft_twiddles(s_h + (0 + ip) * 11 * 64 + lane, t);
+            auto k1 = [&] { load_row(i + 1, 0); };
+            auto k2 = [&] { load_row(i + 1, 1); };
+            auto k3 = [&] { if (XF > 4) load_row(i + 1, 2); };
+            if (ip) hfft_inverse<1>(HA, c, y, U, t, k1, k2, k3);
+            else hfft_inverse<0>(HA, c, y, U, t, k1, k2, k3);
             if (CHECK) {
-                const double e = fft::round_err8(a);
+                const double e = fft::round_err4(y);
                 worst = e > worst ? e : worst;
             }
             IYK_FTRACE(6);
-            fft::acc_update16_doubled(lane, a, (wave & 1) ? 16 : 0, acc2 + (wave >> 1) * 2 * NTT_N);
+            fft::acc_update8_doubled(lane, ip, y, (si & 1) ? 16 : 0, acc2 + (si >> 1) * 2 * NTT_N);
+            if (XF > 4) load_row(i + 1, 3);
             IYK_FTRACE(7);
         }
         wg_barrier_lds();

@@ -238,10 +238,23 @@ def test_emulated_fft_path_worst_case_magnitudes(which, request):
         lin0[0] = 0x7FE00000          # abar_0 = 1023: (X^1023 - 1) tv = -2 mu on 1023 coefficients: extreme digits at once
         lin0[1:8] = 0x33300000
         for lin in (lin0, np.ascontiguousarray(rows[6]), np.ascontiguousarray(rows[7])):
-            got = np.zeros(p.N + 1, dtype=np.uint32)
-            assert em.iyk_emul_blind_rotate_fft(ctypes.byref(p), lin.ctypes.data_as(u32p), bk.ctypes.data_as(dp),
-                                                got.ctypes.data_as(u32p)) == 0
-            assert np.array_equal(orc.bootstrap_lvl1(lin), got), kind
+            ref = orc.bootstrap_lvl1(lin)
+            # both networks: three radix-8 passes (wave per rotation), and the radix-4 halves of the workgroup-per-rotation kernel
+            for fn in (em.iyk_emul_blind_rotate_fft, em.iyk_emul_blind_rotate_fft_lat):
+                got = np.zeros(p.N + 1, dtype=np.uint32)
+                assert fn(ctypes.byref(p), lin.ctypes.data_as(u32p), bk.ctypes.data_as(dp), got.ctypes.data_as(u32p)) == 0
+                assert np.array_equal(ref, got), (kind, fn)
         worst = max(worst, em.iyk_emul_fft_round_error(0))
         orc.close()
     assert worst < 2.0 ** -10, worst
+
+
+def test_half_transforms_equal_the_full_transform():
+    """csrc/fft256.hpp (the narrow-frontier kernel's hand-off-free halves: 4 points per lane, four radix-4 passes) against
+    csrc/fft512.hpp on the same random integer input, lane by lane through the kernels' own exchange slots: forward
+    F_0 +- W^k' F_1 = the [k2][lane''] spectrum, inverse even / odd coefficients = the full inverse's; to rounding (both are
+    exact networks with <= 9 butterfly and <= 6 multiplicative layers)."""
+    em = _emul()
+    em.iyk_emul_fft256_selftest.restype = ctypes.c_double
+    for seed in range(8):
+        assert em.iyk_emul_fft256_selftest(seed) < 4e-15

@@ -17,19 +17,20 @@ int main(int argc, char** argv)
     typedef fft::Gadget<3, 6> G;
     typedef BrLatFft<G> M;
     const int njobs = argc > 1 ? atoi(argv[1]) : 64, n = 636;
-    auto C = new fft::Consts();
-    fft::make_consts(*C);
+    auto C = new fft::ConstsAll();
+    fft::make_consts(C->c);
+    fft::make_consts256(C->h);
     const size_t keyc = (size_t)n * 6 * 4 * fft::M;
     std::vector<fft::cplx> bk(keyc);
     unsigned long long s = 12345;
     for (auto& v : bk) { s = s * 6364136223846793005ull + 1442695040888963407ull; v = {(double)((long long)(s >> 20) % 100000) / 512.0, (double)((long long)(s >> 30) % 100000) / 512.0}; }
     std::vector<u32> abar((size_t)njobs * 1024);
     for (auto& v : abar) { s = s * 6364136223846793005ull + 1442695040888963407ull; v = (u32)(s >> 40) & 2047u; }
-    fft::cplx* d_bk; fft::Consts* d_c; u32 *d_abar, *d_out; unsigned long long* d_tr;
-    CK(hipMalloc(&d_bk, keyc * sizeof(fft::cplx))); CK(hipMalloc(&d_c, sizeof(fft::Consts)));
+    fft::cplx* d_bk; fft::ConstsAll* d_c; u32 *d_abar, *d_out; unsigned long long* d_tr;
+    CK(hipMalloc(&d_bk, keyc * sizeof(fft::cplx))); CK(hipMalloc(&d_c, sizeof(fft::ConstsAll)));
     CK(hipMalloc(&d_abar, abar.size() * 4)); CK(hipMalloc(&d_out, (size_t)njobs * 1025 * 4)); CK(hipMalloc(&d_tr, M::WAVES * 16 * 8));
     CK(hipMemcpy(d_bk, bk.data(), keyc * sizeof(fft::cplx), hipMemcpyHostToDevice));
-    CK(hipMemcpy(d_c, C, sizeof(fft::Consts), hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_c, C, sizeof(fft::ConstsAll), hipMemcpyHostToDevice));
     CK(hipMemcpy(d_abar, abar.data(), abar.size() * 4, hipMemcpyHostToDevice));
     auto kern = blind_rotate_fft_lat_kernel<G, false>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)M::LDS_BYTES));
