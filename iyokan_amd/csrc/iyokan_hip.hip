@@ -105,8 +105,10 @@ iyk_level_cost default_level_cost(int cus, bool fft)
     c.pass = cus;
     c.calibrated = 0;
     c.round_ms = fft ? 15.0f : 19.7f;
-    const float pass_ms[8] = {3.33f, 6.96f, 10.23f, 13.52f, 16.79f, 20.1f, 23.4f, 26.7f};
-    for (int j = 0; j < 8; ++j) c.pass_ms[j] = pass_ms[j];
+    // workgroup-per-rotation kernels: the FFT one with its half transforms (profiles/r04_sweep_kernels.txt), the field one
+    const float pass_fft[8] = {3.03f, 5.79f, 8.33f, 10.94f, 13.7f, 16.4f, 19.1f, 21.9f};
+    const float pass_fp[8] = {3.33f, 6.96f, 10.23f, 13.52f, 16.79f, 20.1f, 23.4f, 26.7f};
+    for (int j = 0; j < 8; ++j) c.pass_ms[j] = fft ? pass_fft[j] : pass_fp[j];
     c.max_passes = 0;
     while (c.max_passes < 8 && c.pass_ms[c.max_passes] < c.round_ms) ++c.max_passes;
     std::snprintf(c.build_id, sizeof c.build_id, "%s", IYK_BUILD_ID);
