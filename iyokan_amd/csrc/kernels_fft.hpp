@@ -779,6 +779,14 @@ __global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_ker
     double worst = 0.0;
     __syncthreads();
 
+    // The inverse's eleven lane constants stay in registers for the whole kernel (44 VGPRs the kernel has: 228 of 256): the LDS
+    // pipe is 54 % busy (profiles/r04_latfft_pmc_sq.txt) and every wave spends a quarter of its time waiting for it, so 11 reads
+    // per wave and step less are worth 3-7 % (2.81 -> 2.70 ms at 64 rotations, 3.17 -> 2.95 at 256 in the trace build).  The
+    // forward halves' constants as well would need 272 (7 of them: 256, no gain; all 11: spills, slower).
+    fft::cplx tinv[11];
+    hfft_twiddles(s_h + (0 + ip) * 11 * 64 + lane0, tinv);
+#pragma unroll
+    for (int k = 0; k < 11; ++k) asm volatile("" : "+v"(tinv[k].re), "+v"(tinv[k].im));
     IYK_FTRACE_DECL;
     u32 ab_next = abar[0];
     for (u32 i = 0; i < n; ++i) {
@@ -854,7 +862,8 @@ __global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_ker
             fft::cplx c[8], y[4], t[11];
 #pragma unroll
             for (int q = 0; q < 8; ++q) c[q] = s_sum[si * fft::M + q * 64 + in_pos];
-            hfft_twiddles(s_h + (0 + ip) * 11 * 64 + lane, t);
+#pragma unroll
+            for (int k = 0; k < 11; ++k) t[k] = tinv[k];
             auto k1 = [&] { load_row(i + 1, 0); };
             auto k2 = [&] { load_row(i + 1, 1); };
             auto k3 = [&] { if (XF > 4) load_row(i + 1, 2); };
