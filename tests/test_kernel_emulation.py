@@ -258,3 +258,18 @@ def test_half_transforms_equal_the_full_transform():
     em.iyk_emul_fft256_selftest.restype = ctypes.c_double
     for seed in range(8):
         assert em.iyk_emul_fft256_selftest(seed) < 4e-15
+
+
+def test_fft256_design_model():
+    """tools/fft256_model.py: the half transforms' index algebra in numpy against the O(n^2) definition, and every LDS
+    exchange of both directions conflict-free under the ds_write_b128 / ds_read_b128 lane grouping of the CDNA4 guide."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fft256_model.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.strip().splitlines()
+    assert float(lines[0].split()[-1]) < 1e-7 and float(lines[1].split()[2]) < 1e-6     # naive O(n^2) sums of magnitude ~10^3
+    ways = [l for l in lines if "write-way" in l]
+    assert len(ways) == 6 and all(l.endswith("write-way 1 read-way 1") for l in ways)
