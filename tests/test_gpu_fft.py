@@ -149,3 +149,40 @@ def test_fft_and_field_paths_agree_on_a_round_plus_remainder(keys128, monkeypatc
             hip.cleanup()
     assert np.array_equal(got["fft"], got["fp"])
     assert np.array_equal(client.decrypt_bits(keys128, got["fft"][nin:]), 1 - (bits[ia] & bits[ib]))
+
+
+@pytest.mark.parametrize("which", ["128", "80"])
+def test_both_fft_kernels_give_identical_arenas_over_several_passes(which, request, monkeypatch):
+    """1 100 mixed gates (MUX included: 2 rotations) forced through the workgroup-per-rotation kernel — five passes of one rotation
+    per CU, the last one partial, every transform in the decimation halves of csrc/fft256.hpp — and through the wave-per-rotation
+    kernel (three radix-8 passes): two different FFT networks, one exact product — identical arenas, and the oracle's bits."""
+    from iyokan_amd import hip
+
+    keys = request.getfixturevalue("keys" + which)
+    p = keys.params
+    rng = np.random.default_rng(2024)
+    nin, G = 128, 1100
+    bits = rng.integers(0, 2, size=nin).astype(np.uint8)
+    kinds = rng.choice(["AND", "NAND", "OR", "XOR", "XNOR", "MUX", "ORNOT", "ANDNOT"], size=G)
+    ops = np.array([OPS[k] for k in kinds], dtype=np.int32)
+    in0, in1, in2 = (rng.integers(0, nin, size=G).astype(np.int32) for _ in range(3))
+    in2 = np.where(ops == OPS["MUX"], in2, -1).astype(np.int32)
+    out = np.arange(nin, nin + G, dtype=np.int32)
+    host = np.zeros((nin + G, p.n + 1), dtype=np.uint32)
+    host[:nin] = client.encrypt_bits(keys, bits, seed=99)
+    monkeypatch.setenv("IYK_HIP_NTT", "fft")
+    monkeypatch.delenv("IYK_HIP_DEBUG", raising=False)
+    got = {}
+    hip.initialize(keys, device_ids=(0,))
+    try:
+        for kernel in ("latfft", "fft"):
+            monkeypatch.setenv("IYK_HIP_ROT_KERNEL", kernel)
+            got[kernel] = _run_batch(hip, host, ops, in0, in1, in2, out)
+    finally:
+        hip.cleanup()
+    assert np.array_equal(got["latfft"], got["fft"])
+    a, b, s = bits[in0], bits[in1], bits[np.where(in2 >= 0, in2, 0)]
+    want = {"AND": a & b, "NAND": 1 - (a & b), "OR": a | b, "XOR": a ^ b, "XNOR": 1 - (a ^ b), "ORNOT": a | (1 - b),
+            "ANDNOT": a & (1 - b), "MUX": np.where(s == 1, b, a)}
+    expect = np.array([want[k][g] for g, k in enumerate(kinds)], dtype=np.uint8)
+    assert np.array_equal(client.decrypt_bits(keys, got["fft"][nin:]), expect)
