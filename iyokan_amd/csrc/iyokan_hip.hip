@@ -104,9 +104,9 @@ iyk_level_cost default_level_cost(int cus, bool fft)
     c.round = BR_WAVES * cus;
     c.pass = cus;
     c.calibrated = 0;
-    c.round_ms = fft ? 15.0f : 19.7f;
+    c.round_ms = fft ? 15.5f : 19.7f;
     // workgroup-per-rotation kernels: the FFT one with its half transforms (profiles/r04_sweep_kernels.txt), the field one
-    const float pass_fft[8] = {3.03f, 5.79f, 8.33f, 10.94f, 13.7f, 16.4f, 19.1f, 21.9f};
+    const float pass_fft[8] = {2.60f, 5.13f, 7.66f, 10.19f, 12.74f, 15.30f, 17.85f, 20.40f};
     const float pass_fp[8] = {3.33f, 6.96f, 10.23f, 13.52f, 16.79f, 20.1f, 23.4f, 26.7f};
     for (int j = 0; j < 8; ++j) c.pass_ms[j] = fft ? pass_fft[j] : pass_fp[j];
     c.max_passes = 0;

@@ -2,8 +2,9 @@
 //
 //   init        bk_fft_kernel                           torus-domain BK rows -> two spectra (signed 16-bit halves) per polynomial
 //   per batch   blind_rotate_fft_kernel<G, CHECK>       one wavefront per rotation, 8 complex points per lane, 2 waves / SIMD:
-//                                                       full rounds (14.1 ms per 2048 rotations at the 128-bit set)
-//               blind_rotate_fft_lat_kernel<G, CHECK>   one rotation per workgroup of 8 wavefronts: narrow frontiers (3.4 ms)
+//                                                       full rounds (14.1 ms per 2048 rotations at the 128-bit set, 15.5 sustained)
+//               blind_rotate_fft_lat_kernel<G, CHECK>   one rotation per workgroup of 8 wavefronts, transforms split over the two
+//                                                       waves of a SIMD in the halves of fft256.hpp: narrow frontiers (2.6 ms)
 //               (blind_rotate_fft2_kernel: two waves per rotation, 3 waves / SIMD — an experiment, only with -DIYK_WITH_FFT2)
 //
 // LDS map of blind_rotate_fft_kernel (bytes): T1 lane constants cplx [8][64] 8 K | accumulators [wave][2][1024] u32 64 K
