@@ -1,0 +1,4 @@
+// compile-only shim (tests/shims/README.md): like the real header, brings in the standard type it serialises
+#pragma once
+#include <optional>
+#include "../cereal.hpp"
