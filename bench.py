@@ -65,7 +65,7 @@ def parse_args():
     return ap.parse_args()
 
 
-COUNTER_FILES = ("r04_counters.json", "r04_counters_80bit.json", "r03_counters.json", "r03_counters_80bit.json", "r03_counters_80bit_direct.json", "r02_counters.json",
+COUNTER_FILES = ("r05_counters.json", "r05_counters_80bit.json", "r04_counters.json", "r04_counters_80bit.json", "r03_counters.json", "r03_counters_80bit.json", "r03_counters_80bit_direct.json", "r02_counters.json",
                  "r01_traffic.json")  # newest first
 DEFAULT_LEVELS = {"128bit": 3, "80bit": 4}   # (r04 files always carry the field: the FFT path runs the 80-bit set at 2)   # iyk_hip_decomposition_levels of counter files older than the field
 
@@ -97,14 +97,33 @@ def counters(args, gates, build_id, levels):
     return None, why
 
 
+FP64_VECTOR_PEAK_FLOPS = 78.6e12   # MI355X vector FP64 (MI355X_MICROARCH.md): 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
+
+
+def fp64_flops_per_step(params, path):
+    """FP64 floating-point operations ONE CMUX step of ONE rotation performs on the FFT path, counted from the algorithm as the
+    kernel computes it (fused multiply-add = 2, add or multiply = 1), per 64-lane wave = per rotation:
+      forward transform (csrc/fft512.hpp, three twisted DFT8 passes of Linzer-Feig butterflies): 3 passes x 12 butterflies x 6
+          instructions, all FMAs except the 8 of pass 1's level 1 whose tangent is 1 (adds): (216 x 2 - 8) per lane = 424
+      MAC of a row: 8 frequencies x 4 key spectra x 4 FMAs per lane = 256
+      inverse transform (three DFT8 of 48 adds + 2 rotations (2 adds + 2 multiplies), conj T2: 7, conj T1: 8 and the uniform twist: 6
+          complex products of 2 multiplies + 2 FMAs, + one rotation): 3 x 56 + 7 x 6 + 8 x 6 + 6 x 6 + 4 = 298; rounding: 16 adds
+    per step: rows x (424 + 256) + 4 x (298 + 16) per lane, x 64 lanes.  Integer work (digits, rotated difference, recombination) and
+    conversions are not counted.  None on the field paths (their arithmetic is exact FMA / integer modular work, not flops)."""
+    if path != "fft":
+        return None
+    rows = params.trgsw_rows
+    return 64 * (rows * (424 + 256) + 4 * (298 + 16))
+
+
 def useful_valu_per_step(params, path):
     """VALU instructions one CMUX step of one rotation NEEDS at the kernel's stated per-operation costs:
-    FFT path: per forward transform 3 DFT8 x 56 + twist 28 + T1 32 + T2 28 + 16 x (bit-field + convert) = 288; per row 8 x 4
+    FFT path (round 5): per forward transform 3 twisted DFT8 x 72 + 16 x (bit-field + convert) = 248; per row 8 x 4
     complex MACs x 4 FMAs = 128; per inverse transform 256, + 3 per coefficient to round, shift and combine; 7 per
     coefficient for (X^a - 1) acc.  Field paths: radix-2 butterflies of 8 (fp50) / ~30 (Goldilocks) instructions."""
     rows, N = params.trgsw_rows, params.N            # (k+1) l digit polynomials
     if path == "fft":
-        return rows * (288 + 128) + 4 * 256 + 3 * 2 * 16 + 7 * 2 * 16
+        return rows * (248 + 128) + 4 * 256 + 3 * 2 * 16 + 7 * 2 * 16
     per_bfly, per_mac = (8, 7) if path == "fp50" else (30, 30)
     lanes = 64
     bflies = (rows + params.k + 1) * (N // 2) * 10
@@ -233,6 +252,24 @@ def cpu_baseline(keys, params, op_code, sample, data_seed, budget_s=24.0):
             "ms_per_gate_per_thread": threads / rate * 1e3}
 
 
+def word_check(params_name, op, first_gate, rows):
+    """The output ciphertexts of the TIMED step against the oracle's committed digests (tests/golden/fullsize_nand_fresh_*.bin:
+    first 8 bytes of sha256 of every output TLWE of this very workload — key seed 1, bits default_rng(1000), encryption seed 2,
+    gate g = NAND(in[g], in[65536 + g]) — made by tests/golden/make_fullsize_digests.py with the CPU oracle in the build
+    container).  rows = this rank's block, starting at gate first_gate.  Returns True / False, or None when the workload is not
+    the committed one (another gate kind or size)."""
+    import hashlib
+
+    path = os.path.join(ROOT, "tests", "golden", f"fullsize_nand_fresh_{'128' if params_name == '128bit' else '80'}.bin")
+    if op != "NAND" or not os.path.exists(path):
+        return None
+    want = np.fromfile(path, dtype=np.uint8).reshape(-1, 8)
+    if first_gate + len(rows) > len(want):
+        return None
+    got = np.frombuffer(b"".join(hashlib.sha256(r.tobytes()).digest()[:8] for r in rows), dtype=np.uint8).reshape(-1, 8)
+    return bool(np.array_equal(got, want[first_gate: first_gate + len(rows)]))
+
+
 EXIT_BAD_WORLD = 3   # --gpus does not match the ranks that exist / the devices that are visible
 
 
@@ -319,6 +356,8 @@ def main():
     hip.initialize(keys, device_ids=(local_rank,))
 
     # ---- synthetic inputs: fresh encryptions, distinct per rank (seeded); layout [in0 | in1 | out] ----
+    # (rank 0's are SURVEY 8(d) config 2's: data seed 2 — the workload the committed oracle digests were made on; at N > 1 every
+    # rank times its own block of its own 65 536 fresh gates: same work per gate, no shared inputs to distribute)
     rng = np.random.default_rng(1000 + rank)
     bits = rng.integers(0, 2, size=2 * G_alloc).astype(np.uint8)
     enc = client.encrypt_bits(keys, bits, seed=2 + rank)
@@ -371,6 +410,8 @@ def main():
     want = np.array([PLAIN[args.op](int(a), int(b)) for a, b in zip(bits[:G_mine], bits[G_alloc: G_alloc + G_mine])],
                     dtype=np.uint8)
     decrypt_ok = bool(np.array_equal(client.decrypt_bits(keys, got), want))
+    # ... and, on rank 0 (whose inputs are the committed workload's), the WORDS of the timed step against the oracle's digests
+    words_ok = word_check(args.params, args.op, 0, got) if (rank == 0 and G_alloc == 65536 and G_total == 65536) else None
 
     weak = None
     if world > 1 and not args.no_weak:
@@ -417,30 +458,58 @@ def main():
         else:
             issue["counters_dropped"] = pmc_why
         kernel = {"fft": "blind_rotate_fft_kernel", "fp50": "blind_rotate_fp_kernel", "goldilocks": "blind_rotate_kernel"}[path]
-        roofline = {
-            # achieved / peak / unit / frac ALWAYS mean the SURVEY 8(d) contract: algorithmic key bytes of the dominant kernel
-            # per launch / its measured launch time against the HBM peak (one meaning per key).  `binding` says
-            # whether that ceiling can bind at all: with the key stream served by L1 / L2 (traffic_over_algorithmic << 1) it
-            # cannot, values above 1 are possible, and the number to read is issue{} — instruction issue, the measured bound.
-            "bound": "hbm",
-            "frac_kind": "contract: SURVEY 8(d) algorithmic bytes / launch time vs 8 TB/s",
-            "kernel": kernel,
-            "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_BYTES_PER_S,
+        # --- the three prices of the same launch --------------------------------------------------------------------------------
+        # (1) hbm_contract: SURVEY 8(d)'s figure — algorithmic key bytes / launch time vs 8 TB/s.  It cannot bind: every wave of a
+        #     launch walks the same key rows in lock-step, the stream is served by L1 / L2 (traffic_over_algorithmic << 1), values
+        #     above 1 happen.  Kept because the contract asks for it; `binding` says what it is worth.
+        hbm_contract = {
+            "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK_BYTES_PER_S,
             "binding": (t_over_a >= 0.5) if t_over_a is not None else None,
-            "contract_frac": achieved / HBM_PEAK_BYTES_PER_S,
-            "traffic": traffic,
             "algorithmic_bytes_per_launch": br_bytes_per_gate * G_mine,
             "key_bytes_streamed_per_rotation": key_stream_bytes(params, path),
             "traffic_over_algorithmic": t_over_a,
             "measured_hbm_GBps": (traffic / br_avg_s / 1e9) if (traffic and br_avg_s > 0) else None,
+            "gate_bytes": b_gate, "gate_frac": value / world * b_gate / HBM_PEAK_BYTES_PER_S,
+        }
+        # (2) fp64: flops counted from the algorithm (fp64_flops_per_step's docstring is the formula) / launch time vs the part's
+        #     vector FP64 peak: a hardware-spec'd compute fraction anyone can recompute from the launch time alone
+        fl = fp64_flops_per_step(params, path)
+        fp64 = None
+        if fl and br_avg_s > 0:
+            flops = fl * steps_per_launch
+            fp64 = {"flops_per_step_per_rotation": fl, "flops_per_launch": flops, "achieved": flops / br_avg_s / 1e12,
+                    "peak": FP64_VECTOR_PEAK_FLOPS / 1e12, "unit": "TFLOP/s", "frac": flops / br_avg_s / FP64_VECTOR_PEAK_FLOPS,
+                    "formula": "64 lanes x (rows x (424 forward + 256 MAC) + 4 x (298 inverse + 16 rounding)) x n steps x rotations; "
+                               "FMA = 2 (bench.py: fp64_flops_per_step)"}
+        # (3) issue: instructions of ANY kind the launch issued (SQ_INSTS of a committed --pmc pass on this build) against one per
+        #     4 cycles per SIMD at 2.4 GHz — the measured bound of this kernel.  The HEADLINE frac when the
+        #     counter file matches the loaded build; otherwise the headline falls back to (2), which needs no counters.
+        if issue.get("frac") is not None:
+            insts = pmc["all_insts_per_launch"]
+            head = {"bound": "valu-issue", "frac_kind": "issue: SQ_INSTS (all instruction kinds) per launch / (1024 SIMDs x launch time / "
+                    "4 cycles at 2.4 GHz); counters from " + pmc["_file"],
+                    "achieved": insts / br_avg_s / 1e9, "peak": N_SIMDS / VALU_PEAK_NS, "unit": "G wave-instructions/s",
+                    "frac": issue["frac"]}
+        elif fp64:
+            head = {"bound": "fp64-valu", "frac_kind": "fp64: algorithm-counted FP64 flops / launch time vs 78.6 TFLOP/s vector FP64 peak "
+                    "(no counter file matches this build: " + str(pmc_why) + ")",
+                    "achieved": fp64["achieved"], "peak": fp64["peak"], "unit": "TFLOP/s", "frac": fp64["frac"]}
+        else:
+            head = {"bound": "hbm", "frac_kind": "contract: SURVEY 8(d) algorithmic bytes / launch time vs 8 TB/s",
+                    "achieved": hbm_contract["achieved"], "peak": hbm_contract["peak"], "unit": "GB/s", "frac": hbm_contract["frac"]}
+        roofline = dict(head)
+        roofline.update({
+            "kernel": kernel,
+            "contract_frac": hbm_contract["frac"],   # SURVEY 8(d)'s "% of HBM roofline", non-binding (see hbm_contract)
+            "binding": hbm_contract["binding"],
+            "traffic": traffic,                        # HBM bytes per launch: rocprofv3 2 * FETCH_SIZE + WRITE_SIZE (gfx950 correction)
             "avg_launch_ms": br_avg_s * 1e3,
             "keyswitch_avg_launch_ms": ks_ms / max(nb, 1),
-            "gate_bytes": b_gate,
-            "gate_frac": value / world * b_gate / HBM_PEAK_BYTES_PER_S,
+            "hbm_contract": hbm_contract,
+            "fp64": fp64,
             "issue": issue,
             "build_id": hip.build_id(),
-        }
+        })
         line = {
             "metric": baseline_metric() if args.params == "128bit" else "TFHE gate bootstraps/sec (80-bit params)",
             "value": value,
@@ -467,6 +536,9 @@ def main():
                 "gates_per_step_per_gpu": G_mine,
                 "parallelism": f"frontier sharded over {world} GPU(s), no data-path collective (flat DAG)",
                 "decrypt_check": decrypt_ok,
+                "word_check": words_ok,
+                "word_check_note": "sha256 digests of the timed step's output ciphertexts (rank 0's block) == the CPU oracle's committed "
+                                   "digests for this workload (tests/golden/fullsize_nand_fresh_*.bin); null = not the committed workload",
             },
             "roofline": roofline,
             "weak": weak,
@@ -484,6 +556,8 @@ def main():
         dist.destroy_process_group()
     if not decrypt_ok:
         raise SystemExit("decrypt check failed")
+    if rank == 0 and words_ok is False:
+        raise SystemExit("word check failed: the timed step's ciphertexts differ from the oracle's")
 
 
 if __name__ == "__main__":

@@ -171,6 +171,12 @@ int iyk_hip_trlwe_upload(iyk_hip_stream* st, uint32_t* d_trlwe, uint64_t trlwe_s
 int iyk_hip_trlwe_download(iyk_hip_stream* st, const uint32_t* d_trlwe, uint64_t trlwe_slots, uint64_t first,
                            uint64_t count, uint32_t* host_trlwe);
 
+/* Page-locked host memory for callers that stage whole batches themselves (iyk_hip_arena_upload / _download with a pageable
+ * buffer work but are synchronous in effect: the runtime stages pageable memory itself and the device-to-host direction waits
+ * for the stream).  cuFHE's Ctxt allocates its host side the same way.  No GPU index: page-locked memory is visible to all. */
+int iyk_hip_host_alloc(uint64_t bytes, void** out);
+int iyk_hip_host_free(void* p);
+
 /* ---- the hot path ---------------------------------------------------------------------- */
 
 /* Evaluate `count` mutually independent gates on arena slots, asynchronously on `st`.
@@ -191,7 +197,12 @@ int iyk_hip_gate_batch(iyk_hip_stream* st, uint32_t* d_arena, uint64_t arena_slo
 
 /* One gate on HOST ciphertexts, same shape as cufhe::Nand(out, in0, in1, st): H2D of the
  * inputs, kernels, D2H of the result, all ordered on `st`; poll with iyk_hip_stream_query.
- * `out` must stay valid (and should be pinned for true asynchrony) until the stream is idle. */
+ * The inputs are copied before the call returns.  `out` must stay valid until the stream is idle and is WRITTEN when
+ * iyk_hip_stream_query first returns 1 for the stream (or iyk_hip_stream_sync returns): the transfers go through a pinned
+ * mirror inside the stream, so that neither the call nor the poll ever waits for the gate — the ciphertexts themselves may be
+ * ordinary memory (TFHEpp::TLWE in a std::shared_ptr, as upstream's tasks hold them).  One gate in flight per stream
+ * (the reference's shape: one Ctxt set per worker, /root/reference/src/iyokan_cufhe.hpp:290-312); a second call before the
+ * first was seen idle finishes the first one first. */
 int iyk_hip_gate_host(iyk_hip_stream* st, int op, const uint32_t* in0, const uint32_t* in1,
                       const uint32_t* in2, uint32_t* out);
 

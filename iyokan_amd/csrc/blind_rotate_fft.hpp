@@ -65,7 +65,46 @@ IYK_HD void diff16(int L, u32 abar, const u32* acc_c, u32 (&u)[16])
         const u32 a = *(lds_u32)(size_t)((idx4 & 0xFFCu) | acc_base);
         u[q] = G::prepare((a ^ neg) + ((0u - acc_c[L + 64 * q]) - neg));
     }
+#elif defined(__HIP_DEVICE_COMPILE__) && !defined(IYK_FFT_DIFF_R04)
+    // Round 5: 7 vector instructions per coefficient instead of the 10-11 the round-4 form compiled to (ISA count, tools/isa_blocks.py:
+    // 165 -> ~125 per polynomial).  idx4 = byte index of the rotated coefficient (its bit 12 = the wrap of X^N = -1):
+    //     address  (idx4 & 0xFFC) | base            add + v_and_or / v_bfi
+    //     mask     v_bfe_i32(idx4, 12, 1)           one sign-extending extract instead of shift-add, shift, arithmetic shift
+    //     value    ((rot + mask) ^ mask) + (K - own), flipped: add, sub, v_xad, xor   (-x = ~(x - 1): no separate "+1")
+    // Reads stay in four assembly blocks of 4 + 2 with one wait each.
+    typedef const __attribute__((address_space(3))) u32* lds_u32;
+    const u32 acc_base = (u32)(size_t)(lds_u32)acc_c;
+    const u32 base4 = ((u32)L - abar) << 2;
+    const u32 own_base = acc_base + ((u32)L << 2);
+    u32 lowmask = 0xFFCu;
+    asm volatile("" : "+v"(lowmask));   // in a VGPR: v_and_or takes one scalar operand (acc_base) only
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        u32 idx[4], r[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            idx[e] = base4 + 256u * (u32)(4 * h + e);
+            r[e] = (idx[e] & lowmask) | acc_base;
+        }
+        u64 o01, o23;
+        asm volatile(
+            "ds_read_b32 %0, %0\n" "ds_read_b32 %1, %1\n" "ds_read_b32 %2, %2\n" "ds_read_b32 %3, %3\n"
+            "ds_read2st64_b32 %4, %6 offset0:0 offset1:1\n"
+            "ds_read2st64_b32 %5, %6 offset0:2 offset1:3\n"
+            "s_waitcnt lgkmcnt(0)"
+            : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "=&v"(o01), "=&v"(o23)
+            : "v"(own_base + 1024u * (u32)h)
+            : "memory");
+        const u32 own[4] = {(u32)o01, (u32)(o01 >> 32), (u32)o23, (u32)(o23 >> 32)};   // acc_c[L + 64 q]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const u32 mask = (u32)__builtin_amdgcn_sbfe((i32)idx[e], 12u, 1u);
+            const u32 t = r[e] + mask;
+            u[4 * h + e] = ((t ^ mask) + (BrConsts<G::L, G::BGBIT>::offset_plus_round() - own[e])) ^ G::flip();
+        }
+    }
 #elif defined(__HIP_DEVICE_COMPILE__)
+    // (round 4's form, kept for the A/B: -DIYK_FFT_DIFF_R04)
     // The LDS reads are issued from four assembly blocks with one wait each (left to the compiler, every rotated word was read
     // and waited for in turn: 16 exposed LDS round trips per polynomial and step; all 32 reads in one block would hold 32
     // registers the kernel does not have).  Then 4 instructions per coefficient:
@@ -193,11 +232,14 @@ struct Keys {
     }
     // poly in [0, 4) = 2 c' + half, q < 8 compile-time constants; row_off in cplx
     // extra: additional wave-uniform byte offset (the narrow-frontier kernel's frequency block)
-    IYK_HD cplx at(u32 row_off, int poly, int q, u32 extra = 0u) const
+    IYK_HD cplx at(u32 row_off, int poly, int q, u32 extra = 0u) const { return at_lane(lane_off, row_off, poly, q, extra); }
+    // the same with the lane's byte offset (16 * lane) passed in: computed INSIDE the loop body that loads, the + 1024 (q & 3)
+    // folds into the instruction's immediate offset; hoisted out of the loop it is four address registers alive all the time
+    IYK_HD cplx at_lane(u32 lane_off_, u32 row_off, int poly, int q, u32 extra = 0u) const
     {
         typedef u32 v4u __attribute__((ext_vector_type(4)));
         const u32 soff = (row_off + (u32)poly * 512u) * 16u + (q >= 4 ? 4096u : 0u) + extra;
-        const v4u w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off + (u32)(q & 3) * 1024u, soff, 0);
+        const v4u w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off_ + (u32)(q & 3) * 1024u, soff, 0);
         cplx r;
         u64 lo = ((u64)w[1] << 32) | w[0], hi = ((u64)w[3] << 32) | w[2];
         __builtin_memcpy(&r.re, &lo, 8);
@@ -211,6 +253,10 @@ struct Keys {
     IYK_HD cplx at(u32 row_off, int poly, int q, u32 extra = 0u) const
     {
         return base[(size_t)row_off + (size_t)poly * 512 + (size_t)q * 64 + lane + extra / 16];
+    }
+    IYK_HD cplx at_lane(u32 lane_off_, u32 row_off, int poly, int q, u32 extra = 0u) const
+    {
+        return base[(size_t)row_off + (size_t)poly * 512 + (size_t)q * 64 + lane_off_ / 16 + extra / 16];
     }
 #endif
 };

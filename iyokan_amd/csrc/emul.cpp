@@ -539,6 +539,19 @@ void fft_forward_wave(fft::cplx (*a)[8], fft::cplx* xb)
     ALL_LANES fft::x2_get_c(lane, a[lane], xb);
     ALL_LANES fft::fwd_p3(a[lane]);
 }
+// round 5: the forward transform of the throughput kernel and of the key spectra (three twisted DFT8 passes of Linzer-Feig
+// butterflies, kernels_fft.hpp::fft_forward_lf); same arrangements, same exchanges
+void fft_forward_lf_wave(fft::cplx (*a)[8], fft::cplx* xb)
+{
+    const fft::Consts& C = fft_consts();
+    ALL_LANES fft::fwd_q1(a[lane], C.lu);
+    ALL_LANES fft::x1_put_a(lane, a[lane], xb);
+    ALL_LANES fft::x1_get_b(lane, a[lane], xb);
+    ALL_LANES fft::fwd_q23(a[lane], &C.lf2[0][lane >> 3], 8);
+    ALL_LANES fft::x2_put_b(lane, a[lane], xb);
+    ALL_LANES fft::x2_get_c(lane, a[lane], xb);
+    ALL_LANES fft::fwd_q23(a[lane], &C.lf3[0][lane], 64);
+}
 void fft_inverse_wave(fft::cplx (*a)[8], fft::cplx* xb)
 {
     const fft::Consts& C = fft_consts();
@@ -568,7 +581,7 @@ void blind_rotate_fft(const iyk_params* p, const u32* lin, const fft::cplx* bk_f
             const int c = r >= L ? 1 : 0, lvl = r - c * L;
             if (lvl == 0) ALL_LANES fft::diff16<G>(lane, ab, acc.data() + c * NTT_N, u[lane]);
             ALL_LANES fft::digits8<G>(lvl, u[lane], a[lane]);
-            fft_forward_wave(a, xb);
+            fft_forward_lf_wave(a, xb);
             const u32 row_off = (i * (u32)(2 * L) + (u32)r) * 4u * (u32)fft::M;
             ALL_LANES
             {
@@ -808,7 +821,7 @@ int iyk_emul_bk_fft(const iyk_params* p, const uint32_t* bk, double* bk_fft)
             const u32 kr = bk[poly * NTT_N + lane + 64 * m], ki = bk[poly * NTT_N + lane + 64 * m + 512];
             a[lane][m] = {(double)(half ? fft::key_hi(kr) : fft::key_lo(kr)), (double)(half ? fft::key_hi(ki) : fft::key_lo(ki))};
         }
-        fft_forward_wave(a, xbuf.data());
+        fft_forward_lf_wave(a, xbuf.data());
         ALL_LANES for (int k2 = 0; k2 < 8; ++k2)
             out[q * fft::M + (size_t)k2 * 64 + lane] = {a[lane][k2].re * (1.0 / 512.0), a[lane][k2].im * (1.0 / 512.0)};
     }
@@ -881,6 +894,47 @@ double iyk_emul_fft256_selftest(unsigned seed)
         }
     }
     return worst / big;
+}
+/* The Linzer-Feig forward network (round 5) against a direct long-double evaluation A[k] = sum_j z[j] psi^(j (4 k + 1)) and
+ * against the round-4 network on the same random input (integers of 16 bits).  which = 0: largest |LF - direct| relative to
+ * sqrt(512) * ||z||_2 / sqrt(512) = ||z||_2 ... returned as max_abs_err / ||A||_2 * sqrt(512), i.e. in units where the proof's rho_F
+ * applies (l2-relative, conservatively taken at the worst entry); which = 1: the same for the round-4 network; which = 2:
+ * largest |LF - r04| / largest |A|. */
+double iyk_emul_fft_lf_selftest(unsigned seed, int which)
+{
+    static thread_local fft::cplx a[64][8], b[64][8];
+    std::vector<fft::cplx> xb(fft::XCHG_BYTES / sizeof(fft::cplx));
+    u64 st = 0xD1B54A32D192ED03ull ^ seed;
+    auto rnd = [&]() {
+        st = st * 6364136223846793005ull + 1442695040888963407ull;
+        return (double)(int32_t)(st >> 40) / 256.0 - 32768.0;
+    };
+    std::vector<fft::cplx> z(fft::M);
+    for (auto& v : z) v = {rnd(), rnd()};
+    ALL_LANES for (int m = 0; m < 8; ++m) a[lane][m] = b[lane][m] = z[lane + 64 * m];
+    fft_forward_lf_wave(a, xb.data());
+    fft_forward_wave(b, xb.data());
+    const long double pi = 3.14159265358979323846264338327950288L;
+    long double norm2 = 0.0L, err_lf = 0.0L, err_old = 0.0L, diff = 0.0L, big = 0.0L;
+    for (int k = 0; k < fft::M; ++k) {
+        long double re = 0.0L, im = 0.0L;
+        for (int j = 0; j < fft::M; ++j) {
+            const long double ang = pi * (long double)(((long long)j * (4 * k + 1)) % 2048) / 1024.0L;
+            const long double c = cosl(ang), sn = sinl(ang);
+            re += (long double)z[j].re * c - (long double)z[j].im * sn;
+            im += (long double)z[j].re * sn + (long double)z[j].im * c;
+        }
+        const int pos = fft::freq_pos(k);   // [k2][lane'']
+        const fft::cplx g = a[pos & 63][pos >> 6], o = b[pos & 63][pos >> 6];
+        norm2 += re * re + im * im;
+        err_lf += (g.re - re) * (g.re - re) + (g.im - im) * (g.im - im);
+        err_old += (o.re - re) * (o.re - re) + (o.im - im) * (o.im - im);
+        diff = std::max(diff, std::max(fabsl((long double)g.re - o.re), fabsl((long double)g.im - o.im)));
+        big = std::max(big, std::max(fabsl(re), fabsl(im)));
+    }
+    if (which == 0) return (double)sqrtl(err_lf / norm2);    // l2-relative error of the LF network
+    if (which == 1) return (double)sqrtl(err_old / norm2);   // ... of the round-4 network
+    return (double)(diff / big);
 }
 /* largest |z - rint(z)| over every inverse-transform output since the last reset */
 double iyk_emul_fft_round_error(int reset)

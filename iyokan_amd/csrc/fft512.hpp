@@ -107,10 +107,31 @@ IYK_HD void dft8(cplx (&x)[8])
 struct Twist {
     double c1, s1, c2, s2, c3, s3;   // cos / sin of pi/16, 2 pi/16, 3 pi/16
 };
+// Round 5, forward direction: every pass is a TWISTED 8-point DFT X[k] = sum_m x[m] (zeta w^k)^m, w = e^(i pi/4) — the pass's
+// share of psi^j rides in zeta instead of a separate twiddle layer — built from Linzer-Feig butterflies
+//     (a, b) -> (a + W b, a - W b),  W = c (1 + i t):   p = b + i t b (2 FMAs),  a +- c p (4 FMAs)      6 instructions
+// (a plain butterfly + complex product is 8).  Twiddles: zeta^4 at level 1, zeta^2 and i zeta^2 at level 2, zeta, i zeta, zeta w,
+// i zeta w at level 3 (the factor i is a swap of operands): FOUR (t, c) = (tan, cos) pairs per pass.  The tangent form holds for
+// every angle but an exact odd multiple of pi/2, which no zeta below produces (closest: 90.7 degrees, t = -81.5); its rounding
+// error is bounded independently of t (Lemma 1').
+//   pass 1 (over j2, lane L, -> k0):          zeta1 = psi^64                       wave-uniform: SGPRs
+//   pass 2 (over j1, lane' = (k0, j0), -> k1): zeta2 = psi^(8 (4 k0 + 1))           eight distinct values: lf2[.][k0]
+//   pass 3 (over j0, lane'' = (k0, k1), -> k2): zeta3 = psi^(4 k0 + 1 + 32 k1)      lf3[.][lane'']
+// 3 x 72 = 216 instructions and 8 table reads per transform against 256 and 15 with separate twiddle layers.
+struct alignas(16) Lf {
+    double t, c;
+};
+enum { LF_Z4 = 0, LF_Z2 = 1, LF_Z1 = 2, LF_Z1W = 3 };   // zeta^4, zeta^2, zeta, zeta w
+struct LfU {                                              // pass 1: zeta^4 = e^(i pi/4) is t = 1, c = 1/sqrt 2
+    double t2, c2, t1, c1, t1w, c1w;
+};
 struct Consts {
     Twist u;
     cplx t2t[8][8];    // [b][a]: exp(2 pi i a b / 64) (symmetric in value; the layout says which index a lane owns)
     cplx t1[8][64];    // [k0][L]: psi^(L (4 k0 + 1))
+    LfU lu;            // forward pass 1
+    Lf lf2[4][8];      // forward pass 2: [which][k0]
+    Lf lf3[4][64];     // forward pass 3: [which][lane'']
 };
 
 inline void make_consts(Consts& C)
@@ -124,6 +145,21 @@ inline void make_consts(Consts& C)
         for (int b = 0; b < 8; ++b) C.t2t[b][a] = e(2 * ((a * b) % 64), 64);
     for (int k0 = 0; k0 < 8; ++k0)
         for (int L = 0; L < 64; ++L) C.t1[k0][L] = e((L * (4 * k0 + 1)) % 2048, 1024);
+    // (tan, cos) of the angle pi * num / 1024 (+ pi/4 for zeta w), rounded once from long double
+    auto lf = [&](long double num, bool plus_w) {
+        const long double a = pi * num / 1024.0L + (plus_w ? pi / 4.0L : 0.0L);
+        return Lf{(double)tanl(a), (double)cosl(a)};
+    };
+    const Lf u2 = lf(2 * 64, false), u1 = lf(64, false), u1w = lf(64, true);
+    C.lu = {u2.t, u2.c, u1.t, u1.c, u1w.t, u1w.c};
+    for (int k0 = 0; k0 < 8; ++k0) {
+        const long double z = 8 * (4 * k0 + 1);
+        C.lf2[LF_Z4][k0] = lf(4 * z, false), C.lf2[LF_Z2][k0] = lf(2 * z, false), C.lf2[LF_Z1][k0] = lf(z, false), C.lf2[LF_Z1W][k0] = lf(z, true);
+    }
+    for (int L = 0; L < 64; ++L) {   // lane'' = 8 k0 + k1
+        const long double z = 4 * (L >> 3) + 1 + 32 * (L & 7);
+        C.lf3[LF_Z4][L] = lf(4 * z, false), C.lf3[LF_Z2][L] = lf(2 * z, false), C.lf3[LF_Z1][L] = lf(z, false), C.lf3[LF_Z1W][L] = lf(z, true);
+    }
 }
 
 // ---- LDS exchanges (16-byte slots; the caller fences between a write and the dependent read) -----------------------
@@ -209,6 +245,80 @@ IYK_HD void fwd_p2(cplx (&a)[8], const cplx* t2_lane)
     for (int k1 = 1; k1 < 8; ++k1) a[k1] = cmul(a[k1], t2_lane[8 * k1]);
 }
 IYK_HD void fwd_p3(cplx (&a)[8]) { dft8<false>(a); }
+
+// ---- round 5: the forward passes as twisted DFT8s of Linzer-Feig butterflies (see Lf above) ------------------------------------
+// (a, b) <- (a + W b, a - W b), W = c (1 + i t)
+IYK_HD void lf_bfly(cplx& a, cplx& b, double t, double c)
+{
+    const double pr = fma_(-t, b.im, b.re), pi = fma_(t, b.re, b.im);
+    b = {fma_(-c, pr, a.re), fma_(-c, pi, a.im)};
+    a = {fma_(c, pr, a.re), fma_(c, pi, a.im)};
+}
+// the same with W = i c (1 + i t): W b = i c p = (-c p.im, c p.re)
+IYK_HD void lf_bfly_i(cplx& a, cplx& b, double t, double c)
+{
+    const double pr = fma_(-t, b.im, b.re), pi = fma_(t, b.re, b.im);
+    b = {fma_(c, pi, a.re), fma_(-c, pr, a.im)};
+    a = {fma_(-c, pi, a.re), fma_(c, pr, a.im)};
+}
+// X[k] = sum_m x[m] (zeta w^k)^m in natural order, in place.  Levels (x reduced mod z^8 - zeta^8 = (z^4 - zeta^4)(z^4 + zeta^4), ...):
+//   1: (m, m + 4) with zeta^4                       -> k even | k odd
+//   2: (m, m + 2) with zeta^2 | i zeta^2            -> k = 0 mod 4, 2 mod 4 | 1 mod 4, 3 mod 4
+//   3: (m, m + 1) with zeta, i zeta, zeta w, i zeta w -> X[0], X[4] | X[2], X[6] | X[1], X[5] | X[3], X[7]
+// l3a / l3b run between level 2 and the first / second half of level 3 (the kernel fetches the level-3 constants late)
+// IYK_LF_FENCE (opt-in, -DIYK_FFT_LF_FENCE): the scheduler may not mix more than two butterflies.  Written when the forward phase
+// was short of registers; with the half-block key ring it is not, and the unfenced schedule measures 0.5-0.8 % faster
+// (profiles/r05_fft_ab.txt: unf vs lf5).
+#if defined(__HIP_DEVICE_COMPILE__) && defined(IYK_FFT_LF_FENCE)
+#define IYK_LF_FENCE __builtin_amdgcn_sched_barrier(0)
+#else
+#define IYK_LF_FENCE ((void)0)
+#endif
+template <class F>
+IYK_HD void tdft8_levels12(cplx (&x)[8], Lf z4, Lf z2, F between)
+{
+    lf_bfly(x[0], x[4], z4.t, z4.c);
+    lf_bfly(x[1], x[5], z4.t, z4.c);
+    IYK_LF_FENCE;
+    lf_bfly(x[2], x[6], z4.t, z4.c);
+    lf_bfly(x[3], x[7], z4.t, z4.c);
+    between();
+    IYK_LF_FENCE;
+    lf_bfly(x[0], x[2], z2.t, z2.c);
+    lf_bfly_i(x[4], x[6], z2.t, z2.c);
+    IYK_LF_FENCE;
+    lf_bfly(x[1], x[3], z2.t, z2.c);
+    lf_bfly_i(x[5], x[7], z2.t, z2.c);
+    IYK_LF_FENCE;
+}
+// level 3 leaves X[0], X[4], X[2], X[6], X[1], X[5], X[3], X[7] in x[0 .. 7]; the callers store / rename through lf_out()
+IYK_HD void tdft8_level3(cplx (&x)[8], Lf z1, Lf z1w)
+{
+    lf_bfly(x[0], x[1], z1.t, z1.c);
+    lf_bfly_i(x[2], x[3], z1.t, z1.c);
+    IYK_LF_FENCE;
+    lf_bfly(x[4], x[5], z1w.t, z1w.c);
+    lf_bfly_i(x[6], x[7], z1w.t, z1w.c);
+}
+IYK_HD constexpr int lf_out(int r) { return ((r & 1) << 2) | (r & 2) | ((r >> 2) & 1); }   // frequency held by x[r] after level 3
+IYK_HD void lf_natural(cplx (&x)[8])
+{
+    const cplx t1 = x[1], t3 = x[3], t4 = x[4], t6 = x[6];
+    x[1] = t4, x[4] = t1, x[3] = t6, x[6] = t3;
+}
+IYK_HD void tdft8(cplx (&x)[8], Lf z4, Lf z2, Lf z1, Lf z1w)
+{
+    tdft8_levels12(x, z4, z2, [] {});
+    tdft8_level3(x, z1, z1w);
+    lf_natural(x);
+}
+// forward passes, new form (same arrangements and exchanges as fwd_p1 .. fwd_p3)
+IYK_HD void fwd_q1(cplx (&a)[8], const LfU& u) { tdft8(a, Lf{1.0, RSQRT2}, Lf{u.t2, u.c2}, Lf{u.t1, u.c1}, Lf{u.t1w, u.c1w}); }
+// tab = &lf2[0][lane' >> 3] with stride 8, or &lf3[0][lane''] with stride 64
+IYK_HD void fwd_q23(cplx (&a)[8], const Lf* tab, int stride)
+{
+    tdft8(a, tab[LF_Z4 * stride], tab[LF_Z2 * stride], tab[LF_Z1 * stride], tab[LF_Z1W * stride]);
+}
 
 // inverse, part 1 (arrangement F): IDFT8 over k2, conj T2 (row k1 = lane'' & 7)
 IYK_HD void inv_p1(cplx (&a)[8], const cplx* t2_lane)

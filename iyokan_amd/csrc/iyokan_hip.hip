@@ -67,7 +67,9 @@ struct Device {
     fft::cplx* bk_fft = nullptr;   // FFT path: key spectra of the signed 16-bit halves (kernels_fft.hpp), 16 bytes per point
     fft::ConstsAll* fftc = nullptr;   // fft512.hpp's constants, then fft256.hpp's
     unsigned long long* fft_err = nullptr;  // IYK_HIP_DEBUG: largest |z - rint(z)| seen by the FFT kernel (bits of a double)
-    iyk_level_cost cost{};         // what a level of r rotations costs on this GPU (iyk_hip_level_cost_table)
+    iyk_level_cost cost{};         // what a level of r rotations costs on this GPU (iyk_hip_level_cost_table); read / written under G.mu
+    int max_passes = 0;            // cost.max_passes as the dispatch reads it: __atomic loads / stores, lock-free (a calibration may run
+                                   // beside a batch; a plain int keeps Device copyable)
     void release()
     {
         if (ordinal < 0) return;
@@ -98,19 +100,25 @@ struct Device {
 // iyk_hip_level_cost_*).  Compiled-in milliseconds: MI355X, 128-bit set, this source revision (profiles/r04_sweep_*.txt);
 // iyk_hip_calibrate() overwrites them with what the GPU at hand measures.  `fft`: the wave-per-rotation kernel of the
 // default path; the field path's round is longer.
-iyk_level_cost default_level_cost(int cus, bool fft)
+// path: 2 = complex FFT, 1 = FP64 field, 0 = Goldilocks integers (ONE kernel, no narrow-frontier dispatch: max_passes = 0, a level
+// costs whole rounds); set80: the 80-bit parameter set (n = 500, two digit levels: shorter rounds and passes).  ADVICE r04: the
+// defaults used to be the 128-bit FFT figures whatever ran.
+iyk_level_cost default_level_cost(int cus, int path, bool set80)
 {
     iyk_level_cost c{};
     c.round = BR_WAVES * cus;
     c.pass = cus;
     c.calibrated = 0;
-    c.round_ms = fft ? 15.5f : 19.7f;
+    // full rounds, sustained (profiles/r04_bench_final.json, r04_80bit_bench_final.json, r03_bench*.json)
+    c.round_ms = path == 2 ? (set80 ? 9.6f : 15.5f) : path == 1 ? (set80 ? 20.0f : 19.7f) : (set80 ? 52.0f : 86.0f);
     // workgroup-per-rotation kernels: the FFT one with its half transforms (profiles/r04_sweep_kernels.txt), the field one
     const float pass_fft[8] = {2.60f, 5.13f, 7.66f, 10.19f, 12.74f, 15.30f, 17.85f, 20.40f};
+    const float pass_fft80[8] = {1.80f, 3.60f, 5.40f, 7.20f, 9.00f, 10.80f, 12.60f, 14.40f};
     const float pass_fp[8] = {3.33f, 6.96f, 10.23f, 13.52f, 16.79f, 20.1f, 23.4f, 26.7f};
-    for (int j = 0; j < 8; ++j) c.pass_ms[j] = fft ? pass_fft[j] : pass_fp[j];
+    for (int j = 0; j < 8; ++j) c.pass_ms[j] = path == 2 ? (set80 ? pass_fft80[j] : pass_fft[j]) : pass_fp[j];
     c.max_passes = 0;
-    while (c.max_passes < 8 && c.pass_ms[c.max_passes] < c.round_ms) ++c.max_passes;
+    if (path != 0)
+        while (c.max_passes < 8 && c.pass_ms[c.max_passes] < c.round_ms) ++c.max_passes;
     std::snprintf(c.build_id, sizeof c.build_id, "%s", IYK_BUILD_ID);
     return c;
 }
@@ -171,8 +179,14 @@ struct iyk_hip_stream {
     // optional log of per-batch kernel durations (bench.py): event triples per batch
     bool log_on = false;
     std::vector<hipEvent_t> log_events;  // br0, br1, ks1 per logged batch
-    // scratch arena for iyk_hip_gate_host: slot 0 = out, 1..3 = inputs
+    // scratch arena for iyk_hip_gate_host: slot 0 = out, 1..3 = inputs; h_gate = its PINNED host mirror (round 5): the caller's
+    // ciphertexts are ordinary (pageable) memory, and an asynchronous copy to or from pageable memory is synchronous in effect —
+    // the device-to-host one waits for the gate's kernels, which serialised the one-gate-per-stream flavour into one gate at a
+    // time.  Operands are copied into h_gate at the call, the result lands in h_gate, and the stream hands it to gate_out_user
+    // when a query / sync first sees the stream idle.
     u32* d_scratch = nullptr;
+    u32* h_gate = nullptr;
+    u32* gate_out_user = nullptr;
 };
 
 namespace {
@@ -284,22 +298,6 @@ int launch_br_fft(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
     return IYK_OK;
 }
 
-#ifdef IYK_WITH_FFT2
-// the paired FFT kernel (kernels_fft.hpp, blind_rotate_fft2_kernel): two waves per rotation, 6 rotations per CU, 3 waves / SIMD
-template <class GD>
-int launch_br_fft2(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
-{
-    const Device& D = G.devs[st->gpu];
-    dim3 grid((njobs + BR2_ROT - 1) / BR2_ROT), block(64 * BR2_WAVES);
-    auto kern = G.debug ? blind_rotate_fft2_kernel<GD, true> : blind_rotate_fft2_kernel<GD, false>;
-    hipLaunchKernelGGL(kern, grid, block, BR_FFT2_LDS_BYTES, st->s, (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE,
-                       njobs, (const fft::cplx*)D.bk_fft, (u32)G.bk_fft_bytes, &D.fftc->c, o.at(first),
-                       G.p.n, G.p.mu, ABAR_STRIDE, o.trlwe, o.idx(first), D.fft_err);
-    HIP_TRY(hipGetLastError());
-    return IYK_OK;
-}
-#endif
-
 // narrow frontiers on the FFT path: one rotation per workgroup of 8 waves (kernels_fft.hpp, blind_rotate_fft_lat_kernel)
 template <class GD>
 int launch_br_fft_lat(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
@@ -330,7 +328,7 @@ int launch_br_fp_lat3(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
 
 // which rotation kernel a batch is forced onto: IYK_HIP_ROT_KERNEL = fft / w32 / lat3 (A/B, tests; read per batch).
 // IYK_HIP_LATENCY_KERNEL = 0 / 3 is the older spelling of w32 / lat3.  0 = no override.
-enum { ROT_AUTO = 0, ROT_W32 = 32, ROT_LAT3 = 3, ROT_FFT = 8, ROT_LATFFT = 9, ROT_FFT2 = 12 };
+enum { ROT_AUTO = 0, ROT_W32 = 32, ROT_LAT3 = 3, ROT_FFT = 8, ROT_LATFFT = 9 };
 int forced_rot_kernel()
 {
     if (const char* k = std::getenv("IYK_HIP_ROT_KERNEL")) {
@@ -339,7 +337,6 @@ int forced_rot_kernel()
         if (v == "lat3") return ROT_LAT3;
         if (v == "fft") return ROT_FFT;
         if (v == "latfft") return ROT_LATFFT;
-        if (v == "fft2") return ROT_FFT2;
     }
     if (const char* lat = std::getenv("IYK_HIP_LATENCY_KERNEL")) {
         if (lat[0] == '0') return ROT_W32;
@@ -358,13 +355,8 @@ int dispatch_fp(iyk_hip_stream* st, int njobs, const RotOut& o)
 {
     int rc;
     const int forced = forced_rot_kernel();
-    if (forced == ROT_FFT || forced == ROT_LATFFT || forced == ROT_FFT2) {
-        if (!G.use_fft) return fail(IYK_ERR_STATE, "IYK_HIP_ROT_KERNEL=fft / fft2 / latfft needs the FFT key spectra (IYK_HIP_NTT=fft at init)");
-#ifdef IYK_WITH_FFT2
-        if (forced == ROT_FFT2) return launch_br_fft2<GD>(st, 0, njobs, o);
-#else
-        if (forced == ROT_FFT2) return fail(IYK_ERR_STATE, "IYK_HIP_ROT_KERNEL=fft2: the paired kernel is an experiment, not in this build (-DIYK_WITH_FFT2)");
-#endif
+    if (forced == ROT_FFT || forced == ROT_LATFFT) {
+        if (!G.use_fft) return fail(IYK_ERR_STATE, "IYK_HIP_ROT_KERNEL=fft / latfft needs the FFT key spectra (IYK_HIP_NTT=fft at init)");
         return forced == ROT_FFT ? launch_br_fft<GD>(st, 0, njobs, o) : launch_br_fft_lat<GD>(st, 0, njobs, o);
     }
     if (forced == ROT_LAT3) return launch_br_fp_lat3<DC>(st, 0, njobs, o);
@@ -374,7 +366,7 @@ int dispatch_fp(iyk_hip_stream* st, int njobs, const RotOut& o)
     auto tp = [&](int first, int count) {
         return G.use_fft ? launch_br_fft<GD>(st, first, count, o) : launch_br_fp<DC>(st, first, count, o);
     };
-    if (rem > G.devs[st->gpu].cost.max_passes * G.devs[st->gpu].cus) return tp(0, njobs);
+    if (rem > __atomic_load_n(&G.devs[st->gpu].max_passes, __ATOMIC_RELAXED) * G.devs[st->gpu].cus) return tp(0, njobs);
     if (full && (rc = tp(0, full))) return rc;
     if (rem) return G.use_fft ? launch_br_fft_lat<GD>(st, full, rem, o) : launch_br_fp_lat3<DC>(st, full, rem, o);
     return IYK_OK;
@@ -474,10 +466,6 @@ int set_fft_attrs()
     int rc;
     if ((rc = set_lds(blind_rotate_fft_kernel<GD, false>, BR_FFT_LDS_BYTES))) return rc;
     if ((rc = set_lds(blind_rotate_fft_kernel<GD, true>, BR_FFT_LDS_BYTES))) return rc;
-#ifdef IYK_WITH_FFT2
-    if ((rc = set_lds(blind_rotate_fft2_kernel<GD, false>, BR_FFT2_LDS_BYTES))) return rc;
-    if ((rc = set_lds(blind_rotate_fft2_kernel<GD, true>, BR_FFT2_LDS_BYTES))) return rc;
-#endif
     if ((rc = set_lds(blind_rotate_fft_lat_kernel<GD, false>, BrLatFft<GD>::LDS_BYTES))) return rc;
     return set_lds(blind_rotate_fft_lat_kernel<GD, true>, BrLatFft<GD>::LDS_BYTES);
 }
@@ -543,6 +531,7 @@ void destroy_stream_resources(iyk_hip_stream* st)
     if (st->d_rot) (void)hipFree(st->d_rot);
     if (st->d_abar) (void)hipFree(st->d_abar);
     if (st->d_scratch) (void)hipFree(st->d_scratch);
+    if (st->h_gate) (void)hipHostFree(st->h_gate);
     for (hipEvent_t e : st->stage_free)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : {st->xfer, st->xfer2})
@@ -608,7 +597,8 @@ int init_devices(std::vector<Device>& devs, const int* device_ids, int avail, co
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipDeviceSynchronize());
-        D.cost = default_level_cost(D.cus, use_fft);
+        D.cost = default_level_cost(D.cus, use_fft ? 2 : use_fp ? 1 : 0, p.n < 600);
+        __atomic_store_n(&D.max_passes, D.cost.max_passes, __ATOMIC_RELAXED);
     }
     return IYK_OK;
 }
@@ -733,24 +723,31 @@ int iyk_hip_rotation_round(int gpu_index)
     return BR_WAVES * G.devs[gpu_index].cus;
 }
 
+// Before iyk_hip_init: the 128-bit set on the default (FFT) path of a 256-CU part; afterwards: the ACTIVE path and parameter set
+// (the defaults used to be the 128-bit FFT figures whatever was running).
 int iyk_hip_level_cost_defaults(iyk_level_cost* out)
 {
     if (!out) return fail(IYK_ERR_INVALID, "null out");
-    *out = default_level_cost(256, true);
+    if (G.init.load()) *out = default_level_cost(256, G.use_fft ? 2 : G.use_fp ? 1 : 0, G.p.n < 600);
+    else *out = default_level_cost(256, 2, false);
     return IYK_OK;
 }
 
 int iyk_hip_level_cost_table(int gpu_index, iyk_level_cost* out)
 {
+    // (no fail() here before initialisation when called for a table a planner may legitimately want early: that is
+    //  iyk_hip_level_cost_defaults; this one needs a GPU)
     if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
     if (gpu_index < 0 || gpu_index >= (int)G.devs.size() || !out) return fail(IYK_ERR_INVALID, "gpu_index out of range / null out");
+    std::lock_guard<std::mutex> lock(G.mu);
     *out = G.devs[gpu_index].cost;
     return IYK_OK;
 }
 
 double iyk_hip_level_cost_ms(int gpu_index, int rotations)
 {
-    if (!G.init.load() || gpu_index < 0 || gpu_index >= (int)G.devs.size()) return level_cost_ms(default_level_cost(256, true), rotations);
+    if (!G.init.load() || gpu_index < 0 || gpu_index >= (int)G.devs.size()) return level_cost_ms(default_level_cost(256, 2, false), rotations);
+    std::lock_guard<std::mutex> lock(G.mu);
     return level_cost_ms(G.devs[gpu_index].cost, rotations);
 }
 
@@ -825,10 +822,14 @@ int iyk_hip_calibrate(int gpu_index)
     }
     c.max_passes = 0;
     while (c.max_passes < 8 && c.pass_ms[c.max_passes] < c.round_ms) ++c.max_passes;
+    // a single pass slower than a whole round is a measurement on a disturbed GPU, not a property of the kernels: one rotation
+    // never goes out as a full round
+    if (c.max_passes < 1) c.max_passes = 1;
     c.calibrated = 1;
-    {
+    {   // published under the lock the table's readers take; the dispatch reads its one field through the atomic
         std::lock_guard<std::mutex> lock(G.mu);
         D.cost = c;
+        __atomic_store_n(&D.max_passes, c.max_passes, __ATOMIC_RELAXED);
     }
     return done(IYK_OK);
     IYK_API_END
@@ -1003,11 +1004,23 @@ int iyk_hip_stream_destroy(iyk_hip_stream* st)
 
 int iyk_hip_stream_gpu(iyk_hip_stream* st) { return st ? st->gpu : fail(IYK_ERR_INVALID, "null stream"); }
 
+// the stream is idle: hand a finished iyk_hip_gate_host result from the pinned mirror to the caller's ciphertext
+static void deliver_gate_result(iyk_hip_stream* st)
+{
+    if (st->gate_out_user) {
+        std::memcpy(st->gate_out_user, st->h_gate, ((size_t)G.p.n + 1) * sizeof(u32));
+        st->gate_out_user = nullptr;
+    }
+}
+
 int iyk_hip_stream_query(iyk_hip_stream* st)
 {
     if (!st) return fail(IYK_ERR_INVALID, "null stream");
     hipError_t e = hipStreamQuery(st->s);
-    if (e == hipSuccess) return 1;
+    if (e == hipSuccess) {
+        deliver_gate_result(st);
+        return 1;
+    }
     if (e == hipErrorNotReady) return 0;
     return fail(IYK_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(e));
 }
@@ -1016,6 +1029,20 @@ int iyk_hip_stream_sync(iyk_hip_stream* st)
 {
     if (!st) return fail(IYK_ERR_INVALID, "null stream");
     HIP_TRY(hipStreamSynchronize(st->s));
+    deliver_gate_result(st);
+    return IYK_OK;
+}
+
+int iyk_hip_host_alloc(uint64_t bytes, void** out)
+{
+    if (!out || bytes == 0) return fail(IYK_ERR_INVALID, "bad argument");
+    HIP_TRY(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+    return IYK_OK;
+}
+
+int iyk_hip_host_free(void* p)
+{
+    if (p) HIP_TRY(hipHostFree(p));
     return IYK_OK;
 }
 
@@ -1344,17 +1371,26 @@ int iyk_hip_gate_host(iyk_hip_stream* st, int op, const uint32_t* in0, const uin
     if (rc) return rc;
     const size_t n1 = G.p.n + 1;
     if (!st->d_scratch) HIP_TRY(hipMalloc((void**)&st->d_scratch, 4 * n1 * sizeof(u32)));
+    if (!st->h_gate) HIP_TRY(hipHostMalloc((void**)&st->h_gate, 4 * n1 * sizeof(u32), hipHostMallocDefault));
+    if (st->gate_out_user) {   // the previous gate of this stream was never polled to completion: finish it first
+        HIP_TRY(hipStreamSynchronize(st->s));
+        deliver_gate_result(st);
+    }
     const uint32_t* ins[3] = {in0, in1, in2};
     int32_t idx[3] = {-1, -1, -1};
+    int last = 0;
     for (int k = 0; k < 3; ++k)
         if (ins[k]) {
-            HIP_TRY(hipMemcpyAsync(st->d_scratch + (k + 1) * n1, ins[k], n1 * sizeof(u32), hipMemcpyHostToDevice,
-                                   st->s));
+            std::memcpy(st->h_gate + (k + 1) * n1, ins[k], n1 * sizeof(u32));
             idx[k] = k + 1;
+            last = k + 1;
         }
+    if (last)   // ONE pinned transfer for all operands
+        HIP_TRY(hipMemcpyAsync(st->d_scratch + n1, st->h_gate + n1, (size_t)last * n1 * sizeof(u32), hipMemcpyHostToDevice, st->s));
     const int32_t o = 0, opv = op;
     if ((rc = iyk_hip_gate_batch(st, st->d_scratch, 4, 1, &opv, &idx[0], &idx[1], &idx[2], &o))) return rc;
-    HIP_TRY(hipMemcpyAsync(out, st->d_scratch, n1 * sizeof(u32), hipMemcpyDeviceToHost, st->s));
+    HIP_TRY(hipMemcpyAsync(st->h_gate, st->d_scratch, n1 * sizeof(u32), hipMemcpyDeviceToHost, st->s));
+    st->gate_out_user = out;
     return IYK_OK;
     IYK_API_END
 }

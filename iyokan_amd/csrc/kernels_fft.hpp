@@ -5,7 +5,6 @@
 //                                                       full rounds (14.1 ms per 2048 rotations at the 128-bit set, 15.5 sustained)
 //               blind_rotate_fft_lat_kernel<G, CHECK>   one rotation per workgroup of 8 wavefronts, transforms split over the two
 //                                                       waves of a SIMD in the halves of fft256.hpp: narrow frontiers (2.6 ms)
-//               (blind_rotate_fft2_kernel: two waves per rotation, 3 waves / SIMD — an experiment, only with -DIYK_WITH_FFT2)
 //
 // LDS map of blind_rotate_fft_kernel (bytes): T1 lane constants cplx [8][64] 8 K | accumulators [wave][2][1024] u32 64 K
 // (every polynomial 4 KB aligned) | exchange buffers [wave] 9 K each = 72 K  -> 144 KiB of the CU's 160, one 8-wave
@@ -24,24 +23,50 @@
 #ifndef IYK_FFT_BARRIER_EVERY
 #define IYK_FFT_BARRIER_EVERY 16
 #endif
-#ifndef IYK_FFT_RING
-#define IYK_FFT_RING 4
+#ifndef IYK_FFT_KH_AHEAD
+#define IYK_FFT_KH_AHEAD 4   // half blocks of the next row in flight across the transform
 #endif
-#ifndef IYK_FFT_AHEAD
-#define IYK_FFT_AHEAD 2
+#ifndef IYK_FFT_KH_DEPTH
+#define IYK_FFT_KH_DEPTH 5   // half blocks in flight during the MAC (4 .. 7 measure within 1 %; 8 spills: profiles/r05_fft_ab.txt)
 #endif
 #ifdef IYK_FFT_NO_SCHED_BARRIER
 #define IYK_FFT_SB
 #else
 #define IYK_FFT_SB __builtin_amdgcn_sched_barrier(0)
 #endif
-static_assert(8 % IYK_FFT_RING == 0 && IYK_FFT_AHEAD < IYK_FFT_RING, "the key ring must divide the 8 frequency blocks");
 
 namespace iyk {
 
+// Phase stamps for tools/ubench/fft_trace.hip only (-DIYK_FFT_TRACE=<step>): s_memtime at the phase boundaries of the FIRST row
+// (unpaired build) or pair (paired build) of that step.  A stamp first waits for every LDS operation in flight, so the interval
+// that ends at it includes the exchange round trip that would otherwise be charged to the next phase's first instruction.
+#ifdef IYK_FFT_TRACE
+// (stamps go straight to memory: twelve 64-bit values held in registers cost the kernel 24 VGPRs it does not have — the first
+// version of this trace ran four times slower than the kernel it was meant to observe)
+#define IYK_FFT_STAMP_AT(k, wait)                                                                              \
+    do { /* unconditional, every row of every step (the last one survives): a branch around it made the allocator spill */ \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        if (wait) __builtin_amdgcn_s_waitcnt(0xC07F);                                                          \
+        ((unsigned long long*)out_index)[(blockIdx.x * BR_WAVES + wave) * 12 + (k)] = __builtin_readcyclecounter(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    } while (0)
+#define IYK_FFT_STAMP(k) IYK_FFT_STAMP_AT(k, true)
+#define IYK_FFT_STAMP_NOWAIT(k) IYK_FFT_STAMP_AT(k, false)
+#else
+#define IYK_FFT_STAMP(k) ((void)0)
+#define IYK_FFT_STAMP_NOWAIT(k) ((void)0)
+#endif
+#ifdef IYK_FFT_TRACE
+#define IYK_FFT_OUT_INDEX(job) (job)   // the trace build borrows out_index for its stamps
+#else
+#define IYK_FFT_OUT_INDEX(job) (out_index ? out_index[job] : job)
+#endif
+
 static constexpr size_t BR_FFT_T1_BYTES = 8 * 64 * sizeof(fft::cplx);
 static constexpr size_t BR_FFT_T2_BYTES = 8 * 8 * sizeof(fft::cplx);
-static constexpr size_t BR_FFT_LDS_BYTES = BR_FFT_T1_BYTES + (size_t)BR_WAVES * 2 * NTT_N * sizeof(u32) + (size_t)BR_WAVES * fft::XCHG_BYTES + BR_FFT_T2_BYTES;
+static constexpr size_t BR_FFT_LF_BYTES = (4 * 64 + 4 * 8) * sizeof(fft::Lf);   // lf3 [4][64], lf2 [4][8]
+static constexpr size_t BR_FFT_LDS_BYTES =
+    BR_FFT_T1_BYTES + (size_t)BR_WAVES * 2 * NTT_N * sizeof(u32) + (size_t)BR_WAVES * fft::XCHG_BYTES + BR_FFT_T2_BYTES + BR_FFT_LF_BYTES;
 static_assert(BR_FFT_LDS_BYTES <= 160 * 1024, "FFT rotation kernel does not fit the CU's LDS");
 static_assert(BR_FFT_T1_BYTES % 4096 == 0, "diff16 needs every accumulator polynomial 4 KB aligned");
 
@@ -126,6 +151,95 @@ __device__ __forceinline__ void fft_forward(int lane, fft::cplx (&a)[8], const f
 {
     fft_forward_a(lane, a, u, t1_lane, xb);
     fft_forward_b(lane, a, t2, xb, [] {});
+}
+
+// Round 5: the same transform as three twisted DFT8 passes of Linzer-Feig butterflies (fft512.hpp: Lf, tdft8_*): no twiddle
+// layers, 216 instead of 256 arithmetic instructions, 8 instead of 15 table reads.  lf2 = LDS copy of Consts::lf2 ([which][k0]),
+// lf3 = of Consts::lf3 ([which][lane'']).  The level-1 / level-2 constants of a pass are requested BEFORE the exchange reads whose
+// data they meet (LDS returns in order: they are there when the data is), the level-3 pair behind them.
+__device__ __forceinline__ void fft_forward_lf_a(int lane, fft::cplx (&a)[8], const fft::LfU& u, fft::cplx* xb)
+{
+    fft::tdft8_levels12(a, fft::Lf{1.0, fft::RSQRT2}, fft::Lf{u.t2, u.c2}, [] {});
+    fft::tdft8_level3(a, fft::Lf{u.t1, u.c1}, fft::Lf{u.t1w, u.c1w});
+#pragma unroll
+    for (int r = 0; r < 8; ++r) xb[fft::x1_wbase(lane) + 72 * fft::lf_out(r)] = a[r];
+    lds_sync();
+}
+template <class Hook>
+__device__ __forceinline__ void fft_forward_lf_b(int lane, fft::cplx (&a)[8], const fft::Lf* lf2, const fft::Lf* lf3, fft::cplx* xb,
+                                                 Hook during_x2)
+{
+    {
+        const fft::Lf* t = lf2 + (lane >> 3);
+        const fft::Lf z4 = t[8 * fft::LF_Z4], z2 = t[8 * fft::LF_Z2];
+        fft::x1_get_b(lane, a, xb);
+        lds_sync();
+        fft::Lf z1, z1w;   // at most two pairs (8 VGPRs) alive at any time: the forward phase has no more (round 4's twiddles: two values)
+        fft::tdft8_levels12(a, z4, z2, [&] { z1 = t[8 * fft::LF_Z1]; lds_sync(); });
+        z1w = t[8 * fft::LF_Z1W];
+        lds_sync();
+        fft::tdft8_level3(a, z1, z1w);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) xb[fft::x2_wbase(lane) + 9 * fft::lf_out(r)] = a[r];
+    }
+    lds_sync();
+    {
+        const fft::Lf* t = lf3 + lane;
+        const fft::Lf z4 = t[64 * fft::LF_Z4], z2 = t[64 * fft::LF_Z2];
+        fft::x2_get_c(lane, a, xb);
+        during_x2();
+        lds_sync();
+        fft::Lf z1, z1w;
+        fft::tdft8_levels12(a, z4, z2, [&] { z1 = t[64 * fft::LF_Z1]; lds_sync(); });
+        z1w = t[64 * fft::LF_Z1W];
+        lds_sync();
+        fft::tdft8_level3(a, z1, z1w);
+        fft::lf_natural(a);
+    }
+}
+__device__ __forceinline__ void fft_forward_lf(int lane, fft::cplx (&a)[8], const fft::LfU& u, const fft::Lf* lf2, const fft::Lf* lf3,
+                                               fft::cplx* xb)
+{
+#ifdef IYK_FFT_TIMING_EARLYREAD
+    // TIMING ONLY (wrong results): every exchange's reads are issued BEFORE the pass that produces the data, so that their latency
+    // runs under that pass's arithmetic — the upper bound of what pairing two rows' transforms can hide (same LDS operations, 32
+    // more registers in flight)
+    fft::cplx b[8];
+    fft::x1_get_b(lane, b, xb);
+    fft::tdft8_levels12(a, fft::Lf{1.0, fft::RSQRT2}, fft::Lf{u.t2, u.c2}, [] {});
+    fft::tdft8_level3(a, fft::Lf{u.t1, u.c1}, fft::Lf{u.t1w, u.c1w});
+#pragma unroll
+    for (int r = 0; r < 8; ++r) xb[fft::x1_wbase(lane) + 72 * fft::lf_out(r)] = a[r];
+    lds_sync();
+    {
+        const fft::Lf* t = lf2 + (lane >> 3);
+        const fft::Lf z4 = t[8 * fft::LF_Z4], z2 = t[8 * fft::LF_Z2];
+        fft::x2_get_c(lane, a, xb);
+        lds_sync();
+        fft::Lf z1, z1w;
+        fft::tdft8_levels12(b, z4, z2, [&] { z1 = t[8 * fft::LF_Z1]; lds_sync(); });
+        z1w = t[8 * fft::LF_Z1W];
+        lds_sync();
+        fft::tdft8_level3(b, z1, z1w);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) xb[fft::x2_wbase(lane) + 9 * fft::lf_out(r)] = b[r];
+    }
+    lds_sync();
+    {
+        const fft::Lf* t = lf3 + lane;
+        const fft::Lf z4 = t[64 * fft::LF_Z4], z2 = t[64 * fft::LF_Z2];
+        lds_sync();
+        fft::Lf z1, z1w;
+        fft::tdft8_levels12(a, z4, z2, [&] { z1 = t[64 * fft::LF_Z1]; lds_sync(); });
+        z1w = t[64 * fft::LF_Z1W];
+        lds_sync();
+        fft::tdft8_level3(a, z1, z1w);
+        fft::lf_natural(a);
+    }
+#else
+    fft_forward_lf_a(lane, a, u, xb);
+    fft_forward_lf_b(lane, a, lf2, lf3, xb, [] {});
+#endif
 }
 
 // Two independent inverse transforms (the lo and hi halves of one output polynomial) through ONE exchange buffer, software-
@@ -334,9 +448,23 @@ __global__ __launch_bounds__(64) void bk_fft_kernel(const u32* __restrict__ bk, 
         const u32 kr = bk[poly * NTT_N + lane + 64 * m], ki = bk[poly * NTT_N + lane + 64 * m + 512];
         a[m] = {(double)(half ? fft::key_hi(kr) : fft::key_lo(kr)), (double)(half ? fft::key_hi(ki) : fft::key_lo(ki))};
     }
-    fft_forward(lane, a, C.u, &C.t1[0][lane], &C.t2t[0][lane & 7], xb);
+    fft_forward_lf(lane, a, C.lu, &C.lf2[0][0], &C.lf3[0][0], xb);   // constants straight from global memory: init only
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) bk_fft[q * fft::M + (size_t)k2 * 64 + lane] = {a[k2].re * (1.0 / 512.0), a[k2].im * (1.0 / 512.0)};
+}
+
+__device__ __forceinline__ int fft_lane_id(int lane0)
+{
+#ifdef IYK_FFT_LANE_R04
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));   // keep lane-dependent address math inside the iteration
+    return lane;
+#else
+    (void)lane0;
+    int lane;   // volatile: neither hoisted out of the row loop nor merged (hoisted, the lane's address math is live across the step and spills)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    return lane;
+#endif
 }
 
 template <class G, bool CHECK>
@@ -353,8 +481,12 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
     fft::cplx* s_xb = reinterpret_cast<fft::cplx*>(smem + BR_FFT_T1_BYTES + (size_t)BR_WAVES * 2 * NTT_N * sizeof(u32));
     fft::cplx* s_t2 = s_xb + (size_t)BR_WAVES * (fft::XCHG_BYTES / sizeof(fft::cplx));             // [b][a]
 
+    fft::Lf* s_lf3 = reinterpret_cast<fft::Lf*>(s_t2 + 64);   // [which][lane'']
+    fft::Lf* s_lf2 = s_lf3 + 4 * 64;                           // [which][k0]
     for (int e = threadIdx.x; e < 8 * 64; e += 64 * BR_WAVES) s_t1[e] = C.t1[e >> 6][e & 63];
     if (threadIdx.x < 64) s_t2[threadIdx.x] = C.t2t[threadIdx.x >> 3][threadIdx.x & 7];
+    if (threadIdx.x < 4 * 64) s_lf3[threadIdx.x] = C.lf3[threadIdx.x >> 6][threadIdx.x & 63];
+    if (threadIdx.x < 4 * 8) s_lf2[threadIdx.x] = C.lf2[threadIdx.x >> 3][threadIdx.x & 7];
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -375,30 +507,51 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
     // loads inside the transforms, and a scalar load forces lgkmcnt(0): every LDS operation in flight is waited for)
     fft::Twist U = C.u;
     asm volatile("" : "+s"(U.c1), "+s"(U.s1), "+s"(U.c2), "+s"(U.s2), "+s"(U.c3), "+s"(U.s3));
-    constexpr int KB_RING = IYK_FFT_RING, KB_AHEAD = IYK_FFT_AHEAD;
-    fft::cplx kb[KB_RING][4];
-    auto load_block = [&](fft::cplx (&dst)[4], u32 row_off, int q) {
+    fft::LfU LU = C.lu;   // forward pass 1 (round 5)
+    asm volatile("" : "+s"(LU.t2), "+s"(LU.c2), "+s"(LU.t1), "+s"(LU.c1), "+s"(LU.t1w), "+s"(LU.c1w));
+    // Key ring (round 5: HALF blocks).  A row's key words are 16 half blocks h = 2 q + (pc >> 1) of two 16-byte loads per lane
+    // (frequency block q, spectra pc = 2 (h & 1), + 1).  KH_AHEAD half blocks of a row are issued during the previous row's MAC and
+    // land during the transform; after the transform the depth is raised to KH_DEPTH, and every half block consumed issues the one
+    // KH_DEPTH ahead (the rows of all steps are contiguous: past a row's end these are the next row's first ones; past the last row
+    // the descriptor's bounds check returns zeros nobody uses).  Round 4 moved whole blocks (4 loads) with 4 blocks = 64 registers in
+    // flight at the top of the MAC; 6 half blocks = 48 registers leave room for the level-3 constants of the new forward
+    // transform, which otherwise cost 7-11 spilled words of u (ISA: scratch reloads with s_waitcnt vmcnt(0) at the top of every row).
+    constexpr int KH_AHEAD = IYK_FFT_KH_AHEAD, KH_DEPTH = IYK_FFT_KH_DEPTH, KH_RING = 8;
+    static_assert(KH_AHEAD <= KH_DEPTH && KH_DEPTH <= KH_RING, "key ring: ahead <= depth <= 8 half blocks");
+    fft::cplx kh[KH_RING][2];
+#if defined(IYK_FFT_TIMING_NOKEYS) || defined(IYK_FFT_TIMING_HALFKEYS)
 #pragma unroll
-        for (int pc = 0; pc < 4; ++pc) dst[pc] = keys.at(row_off, pc, q);
+    for (int h = 0; h < KH_RING; ++h) kh[h][0] = kh[h][1] = fft::cplx{1.0, 0.5};
+#endif
+    auto load_half = [&](fft::cplx (&dst)[2], u32 koff, u32 row_off, int h) {
+#if defined(IYK_FFT_TIMING_NOKEYS)      // TIMING ONLY: no key loads at all (the sums use whatever the registers hold)
+        (void)koff, (void)row_off, (void)h, (void)dst;
+#elif defined(IYK_FFT_TIMING_HALFKEYS)  // TIMING ONLY: every other half block is loaded, the rest reuse stale registers: half the L1 traffic
+        if (h & 1) return;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) dst[e] = keys.at_lane(koff, row_off, 2 * (h & 1) + e, h >> 1);
+#else
+#pragma unroll
+        for (int e = 0; e < 2; ++e) dst[e] = keys.at_lane(koff, row_off, 2 * (h & 1) + e, h >> 1);
+#endif
     };
 #pragma unroll
-    for (int q = 0; q < KB_AHEAD; ++q) load_block(kb[q], 0u, q);
-    auto mac_row = [&](auto first, fft::cplx (&S)[2][2][8], const fft::cplx (&a)[8], u32 row_off) {
-        constexpr bool FIRST = decltype(first)::value;
+    for (int h = 0; h < KH_AHEAD; ++h) load_half(kh[h], (u32)lane0 * 16u, 0u, h);
+    auto mac_row = [&](fft::cplx (&S)[2][2][8], const fft::cplx (&a)[8], u32 koff, u32 row_off) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int h = 0; h < 16; ++h) {
+            const int q = h >> 1;
 #ifndef IYK_FFT_FINE_WAITS
-            {   // one s_waitcnt for the block's four loads instead of one per load: a wait is an issue slot like any other
-                fft::cplx(&k)[4] = kb[q % KB_RING];
-                asm volatile("" : "+v"(k[0].re), "+v"(k[0].im), "+v"(k[1].re), "+v"(k[1].im), "+v"(k[2].re), "+v"(k[2].im),
-                             "+v"(k[3].re), "+v"(k[3].im));
+            {   // one s_waitcnt for the half block's two loads instead of one per load: a wait is an issue slot like any other
+                fft::cplx(&k)[2] = kh[h % KH_RING];
+                asm volatile("" : "+v"(k[0].re), "+v"(k[0].im), "+v"(k[1].re), "+v"(k[1].im));
             }
 #endif
 #pragma unroll
-            for (int pc = 0; pc < 4; ++pc) fft::cmac<FIRST>(S[pc >> 1][pc & 1][q], a[q], kb[q % KB_RING][pc]);
+            for (int e = 0; e < 2; ++e) fft::cmac<false>(S[h & 1][e][q], a[q], kh[h % KH_RING][e]);
             IYK_FFT_SB;
-            if (q + KB_RING < 8) load_block(kb[q % KB_RING], row_off, q + KB_RING);
-            else if (q + KB_RING - 8 < KB_AHEAD) load_block(kb[q % KB_RING], row_off + 4u * (u32)fft::M, q + KB_RING - 8);
+            if (h + KH_DEPTH < 16) load_half(kh[(h + KH_DEPTH) % KH_RING], koff, row_off, h + KH_DEPTH);
+            else if (h + KH_DEPTH - 16 < KH_AHEAD) load_half(kh[(h + KH_DEPTH) % KH_RING], koff, row_off + 4u * (u32)fft::M, h + KH_DEPTH - 16);
             IYK_FFT_SB;
         }
     };
@@ -423,27 +576,62 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
         for (int e = 0; e < 32; ++e) S[e >> 4][(e >> 3) & 1][e & 7] = {0.0, 0.0};
 #pragma unroll 1
         for (int r = 0; r < 2 * L; ++r) {
-            int lane = lane0;
-            asm volatile("" : "+v"(lane));   // keep lane-dependent address math inside the iteration
+            // the lane id is RECOMPUTED (two v_mbcnt) where it is needed: kept in a register across the step it was the one
+            // value the allocator spilled at 256 VGPRs, and its reload (scratch_load + s_waitcnt vmcnt(0)) waited for every key
+            // load in flight, three times per step (round 5; -DIYK_FFT_LANE_R04 = the round-4 form)
+            int lane = fft_lane_id(lane0);
             const int c = r >= L ? 1 : 0, lvl = r - c * L;
             if (lvl == 0) fft::diff16<G>(lane, ab, acc_lds + c * NTT_N, u);
             fft::cplx a[8];
             fft::digits8<G>(lvl, u, a);
+#ifdef IYK_FFT_FWD_R04
             fft_forward(lane, a, U, s_t1 + lane, s_t2 + (lane & 7), xb);
+#else
+#ifdef IYK_FFT_TRACE
+            IYK_FFT_STAMP(0);
+            fft_forward_lf_a(lane, a, LU, xb);            // P1 + exchange-1 stores
+            IYK_FFT_STAMP_NOWAIT(1);
+            fft::x1_get_b(lane, a, xb);
+            IYK_FFT_STAMP(2);                             // ... + the round trip of exchange 1
+            {
+                const fft::Lf* t = s_lf2 + (lane >> 3);
+                fft::tdft8_levels12(a, t[8 * fft::LF_Z4], t[8 * fft::LF_Z2], [] {});
+                fft::tdft8_level3(a, t[8 * fft::LF_Z1], t[8 * fft::LF_Z1W]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xb[fft::x2_wbase(lane) + 9 * fft::lf_out(e)] = a[e];
+                lds_sync();
+            }
+            IYK_FFT_STAMP_NOWAIT(3);                      // P2 + exchange-2 stores issued
+            fft::x2_get_c(lane, a, xb);
+            IYK_FFT_STAMP(4);                             // ... + the round trip of exchange 2
+            {
+                const fft::Lf* t = s_lf3 + lane;
+                fft::tdft8_levels12(a, t[64 * fft::LF_Z4], t[64 * fft::LF_Z2], [] {});
+                fft::tdft8_level3(a, t[64 * fft::LF_Z1], t[64 * fft::LF_Z1W]);
+                fft::lf_natural(a);
+            }
+            IYK_FFT_STAMP(5);                             // P3
+#else
+            fft_forward_lf(lane, a, LU, s_lf2, s_lf3, xb);
+#endif
+#endif
 #ifdef IYK_FFT_TIMING_L1KEYS
             const u32 row_off = 0u;
 #else
             const u32 row_off = (i * (u32)(2 * L) + (u32)r) * 4u * (u32)fft::M;
 #endif
+            const u32 koff = (u32)lane * 16u;   // in-loop: the key loads' + 1024 (q & 3) become immediate offsets (one address register)
 #pragma unroll
-            for (int q = KB_AHEAD; q < KB_RING; ++q) load_block(kb[q], row_off, q);
+            for (int h = KH_AHEAD; h < KH_DEPTH; ++h) load_half(kh[h], koff, row_off, h);
             __builtin_amdgcn_sched_barrier(0);
-            mac_row(std::false_type{}, S, a, row_off);
+            mac_row(S, a, koff, row_off);
+#ifdef IYK_FFT_TRACE
+            IYK_FFT_STAMP(6);                             // MAC
+#endif
         }
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
-            int lane = lane0;
-            asm volatile("" : "+v"(lane));
+            int lane = fft_lane_id(lane0);
             u32 lo[16];
             fft_inverse2(lane, S[cc][0], S[cc][1], U, s_t1 + lane, s_t2 + (lane & 7), xb);
             if (CHECK) {
@@ -455,6 +643,11 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
             fft::acc_update16(lane, S[cc][1], lo, acc_lds + cc * NTT_N);
         }
         lds_sync();
+#ifdef IYK_FFT_TRACE
+        {
+            IYK_FFT_STAMP(7);                                 // end of the step
+        }
+#endif
     }
 
     if (CHECK && max_err_bits) {   // non-negative doubles order like their bit patterns
@@ -465,199 +658,17 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
     if (live) {
         const int lane = lane0;
         if (trlwe_mode) {  // raw accumulator: TRLWE (a(X), b(X)), 2N words per job
-            u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (2 * NTT_N);
+            u32* out = tlwe1_out + (size_t)(IYK_FFT_OUT_INDEX(job)) * (2 * NTT_N);
             for (int j = lane; j < 2 * NTT_N; j += 64) out[j] = acc_lds[j];
         }
         else {             // sample extract at index 0: a'[0] = a[0], a'[j] = -a[N-j], b' = b[0]
-            u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (NTT_N + 1);
+            u32* out = tlwe1_out + (size_t)(IYK_FFT_OUT_INDEX(job)) * (NTT_N + 1);
             for (int j = lane; j < NTT_N; j += 64) out[j] = (j == 0) ? acc_lds[0] : 0u - acc_lds[NTT_N - j];
             if (lane == 0) out[NTT_N] = acc_lds[NTT_N];
         }
     }
 }
 
-#ifdef IYK_WITH_FFT2
-// ------------------------------------------------------------------------------------------------------------------------
-// NOT PART OF THE PRODUCT BUILD (compiled only with -DIYK_WITH_FFT2, tools/ab_fft_variants.sh): measured 10 % SLOWER than
-// blind_rotate_fft_kernel (profiles/r04_fft2_ab.txt: 537 vs 490 ms per 65 536 rotations with flags, 573 / 621 ms with one / two
-// workgroup barriers per level; bit-exact in every form).  Kept as the record of the experiment DESIGN.md section 9 describes.
-// The same rotation on TWO wavefronts, three waves per SIMD (round 4, second half).  blind_rotate_fft_kernel is pinned at two
-// waves per SIMD by its 128 VGPRs of sums — and two waves cap a SIMD at ~4.4 cycles per instruction while the 20 LDS exchange
-// round trips per step sit on each wave's critical path.  Here wave c in {0, 1} of a pair owns accumulator polynomial c of the
-// pair's rotation: it transforms the l digit polynomials of ITS polynomial, multiplies BOTH polynomials' spectra with the key
-// rows' column c (lo, hi: 64 VGPRs of sums), inverts its two sums and updates its own polynomial — no wave ever touches the
-// other's accumulator.  The partner's spectrum of a level comes through LDS: each wave leaves its spectrum in its exchange
-// buffer (free by then), a workgroup barrier, both multiply; a flag in LDS tells the owner when the partner has read the
-// spectrum and the buffer may be overwritten: l barriers per step (the waves of a workgroup run the same program in step).  12 waves = 6 rotations per CU:
-// LDS 6 x 8 K accumulators + 12 x 9 K exchange buffers + 1 K T2 = 157 K; T1 no longer fits and is read from global memory (8 KB,
-// L1-resident).  Instructions per rotation and step are those of the one-wave kernel (+ 2 x 24 spectrum stores / reads).
-static constexpr int BR2_ROT = 6, BR2_WAVES = 2 * BR2_ROT;
-static constexpr size_t BR_FFT2_LDS_BYTES = (size_t)BR2_ROT * 2 * NTT_N * sizeof(u32) + (size_t)BR2_WAVES * fft::XCHG_BYTES + BR_FFT_T2_BYTES + 128;
-static_assert(BR_FFT2_LDS_BYTES <= 160 * 1024, "paired FFT rotation kernel does not fit the CU's LDS");
-#ifndef IYK_FFT2_RING
-#define IYK_FFT2_RING 2
-#endif
-#ifndef IYK_FFT2_AHEAD
-#define IYK_FFT2_AHEAD 1
-#endif
-static_assert(8 % IYK_FFT2_RING == 0 && IYK_FFT2_AHEAD < IYK_FFT2_RING, "the key ring must divide the 8 frequency blocks");
-
-template <class G, bool CHECK>
-__global__ __launch_bounds__(64 * BR2_WAVES) __attribute__((amdgpu_waves_per_eu(3, 3))) void blind_rotate_fft2_kernel(
-    const u32* __restrict__ abar_all, int njobs, const fft::cplx* __restrict__ bk_fft, u32 bk_bytes,
-    const fft::Consts* __restrict__ Cp, u32* __restrict__ tlwe1_out, u32 n, u32 mu, u32 abar_stride, int trlwe_mode,
-    const int32_t* __restrict__ out_index, unsigned long long* __restrict__ max_err_bits)
-{
-    const fft::Consts& C = *Cp;
-    constexpr int L = G::L;
-    constexpr size_t XB = fft::XCHG_BYTES / sizeof(fft::cplx);
-    extern __shared__ __attribute__((aligned(4096))) unsigned char smem[];
-    u32* s_acc = reinterpret_cast<u32*>(smem);                                                        // [BR2_ROT][2][NTT_N]
-    fft::cplx* s_xb = reinterpret_cast<fft::cplx*>(smem + (size_t)BR2_ROT * 2 * NTT_N * sizeof(u32));   // [BR2_WAVES][XB]
-    fft::cplx* s_t2 = s_xb + (size_t)BR2_WAVES * XB;                                                  // [b][a]
-    u32* s_consumed = reinterpret_cast<u32*>(s_t2 + 64);                                              // [BR2_WAVES]: rounds of this wave's spectrum the partner has read
-    u32* s_ready = s_consumed + BR2_WAVES;                                                            // [BR2_WAVES]: rounds of this wave's spectrum that are complete in LDS
-    if (threadIdx.x < 64) s_t2[threadIdx.x] = C.t2t[threadIdx.x >> 3][threadIdx.x & 7];
-    if (threadIdx.x < 2 * BR2_WAVES) s_consumed[threadIdx.x] = 0u;
-
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane0 = threadIdx.x & 63;
-    const int rot = wave >> 1, c = wave & 1;          // the pair's rotation; this wave's polynomial (digits of acc_c, sums of column c)
-    int job = blockIdx.x * BR2_ROT + rot;
-    const bool live = job < njobs;
-    if (!live) job = njobs - 1;                       // idle pair of the last workgroup: recompute a real job, discard
-
-    u32* acc_c = s_acc + (size_t)(rot * 2 + c) * NTT_N;
-    fft::cplx* xb = s_xb + (size_t)wave * XB;
-    const fft::cplx* xb_oth = s_xb + (size_t)(wave ^ 1) * XB;
-    const u32* abar = abar_all + (size_t)job * abar_stride;
-    {
-        const u32 bbar = abar[n];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const u32 idx = ((u32)(lane0 + 64 * q) - bbar) & (2 * NTT_N - 1);
-            acc_c[lane0 + 64 * q] = c ? ((idx & NTT_N) ? 0u - mu : mu) : 0u;
-        }
-    }
-    const fft::Keys keys(bk_fft, bk_bytes, lane0);
-    double worst = 0.0;
-    fft::Twist U = C.u;
-    asm volatile("" : "+s"(U.c1), "+s"(U.s1), "+s"(U.c2), "+s"(U.s2), "+s"(U.c3), "+s"(U.s3));
-    const fft::cplx* t1g = &C.t1[0][0];               // global, L1-resident: [k0][lane]
-    typedef __attribute__((address_space(3))) u32* lds_u32p;
-    const u32 my_flag = (u32)(size_t)(lds_u32p)(s_consumed + wave), oth_flag = (u32)(size_t)(lds_u32p)(s_consumed + (wave ^ 1));
-    const u32 my_ready = (u32)(size_t)(lds_u32p)(s_ready + wave), oth_ready = (u32)(size_t)(lds_u32p)(s_ready + (wave ^ 1));
-    constexpr int KB_RING = IYK_FFT2_RING, KB_AHEAD = IYK_FFT2_AHEAD;
-    fft::cplx kb[KB_RING][4];                         // per frequency block: own row (lo, hi), partner's row (lo, hi), column c
-    // rows of round `rnd` = step * L + level (rounds of all steps are consecutive): own = digit polynomial (c, lvl), other = (1 - c, lvl)
-    auto load_block = [&](fft::cplx (&dst)[4], u32 rnd, int q) {
-        const u32 step = rnd / (u32)L, lvl = rnd - step * (u32)L;
-        const u32 own = ((step * 2u + (u32)c) * (u32)L + lvl) * 4u * (u32)fft::M, oth = ((step * 2u + (u32)(1 - c)) * (u32)L + lvl) * 4u * (u32)fft::M;
-        dst[0] = keys.at(own, 2 * c, q);
-        dst[1] = keys.at(own, 2 * c + 1, q);
-        dst[2] = keys.at(oth, 2 * c, q);
-        dst[3] = keys.at(oth, 2 * c + 1, q);
-    };
-#pragma unroll
-    for (int q = 0; q < KB_AHEAD; ++q) load_block(kb[q], 0u, q);
-    __syncthreads();
-
-    u32 ab_next = abar[0];
-    for (u32 i = 0; i < n; ++i) {
-        const u32 ab = ab_next;
-        ab_next = abar[i + 1 < n ? i + 1 : i];
-        fft::cplx S[2][8];   // [half][k2]: column c of the external product
-#pragma unroll
-        for (int e = 0; e < 16; ++e) S[e >> 3][e & 7] = {0.0, 0.0};
-        u32 u[16];
-        {
-            int lane = lane0;
-            asm volatile("" : "+v"(lane));
-            fft::diff16<G>(lane, ab, acc_c, u);
-        }
-#pragma unroll 1
-        for (int lvl = 0; lvl < L; ++lvl) {
-            int lane = lane0;
-            asm volatile("" : "+v"(lane));
-            fft::cplx a[8];
-            fft::digits8<G>(lvl, u, a);
-            const u32 rnd = i * (u32)L + (u32)lvl;
-            // the exchange buffer still holds the previous round's spectrum until the partner has read it (its flag says so);
-            // the partner finished that MAC about when this wave did, so the wait is a formality — but not a guarantee
-            // (relaxed LDS accesses + wave-scope compiler fences: LDS is coherent within the workgroup and a wave's DS operations
-            // execute in order; an acquire / release at workgroup scope would invalidate / write back the vector L1 — measured 5x)
-            spin_until_at_least(my_flag, rnd);
-            fft_forward(lane, a, U, t1g + lane, s_t2 + (lane & 7), xb);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) xb[q * 64 + lane] = a[q];          // this wave's spectrum, for the partner
-#pragma unroll
-            for (int q = KB_AHEAD; q < KB_RING; ++q) load_block(kb[q], rnd, q);
-#ifdef IYK_FFT2_BARRIER
-            wg_barrier_lds();                                              // both spectra of every pair are in LDS
-#else
-            // this wave's spectrum is complete (a wave's DS operations execute in order): raise its flag, wait for the partner's
-            asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" ::"v"(my_ready), "v"(rnd + 1u) : "memory");
-            if ((i & 15u) == 0u && lvl == 0) asm volatile("s_barrier" ::: "memory");   // keep the CU's waves on the same key rows (L1)
-            spin_until_at_least(oth_ready, rnd + 1u);
-#endif
-            fft::cplx d_oth = xb_oth[lane];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                fft::cplx d_next = d_oth;
-                if (q + 1 < 8) d_next = xb_oth[(q + 1) * 64 + lane];
-                fft::cplx(&k)[4] = kb[q % KB_RING];
-                fft::cmac<false>(S[0][q], a[q], k[0]);
-                fft::cmac<false>(S[1][q], a[q], k[1]);
-                fft::cmac<false>(S[0][q], d_oth, k[2]);
-                fft::cmac<false>(S[1][q], d_oth, k[3]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (q + KB_RING < 8) load_block(kb[q % KB_RING], rnd, q + KB_RING);
-                else if (q + KB_RING - 8 < KB_AHEAD) load_block(kb[q % KB_RING], rnd + 1u, q + KB_RING - 8);
-                __builtin_amdgcn_sched_barrier(0);
-                d_oth = d_next;
-            }
-            // every read of the partner's spectrum has returned (its values were used): tell the partner its buffer is free
-            asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" ::"v"(oth_flag), "v"(rnd + 1u) : "memory");
-        }
-        {
-            int lane = lane0;
-            asm volatile("" : "+v"(lane));
-            u32 lo[16];
-            spin_until_at_least(my_flag, (i + 1u) * (u32)L);
-            fft_inverse2(lane, S[0], S[1], U, t1g + lane, s_t2 + (lane & 7), xb);
-            if (CHECK) {
-                const double e0 = fft::round_err8(S[0]), e1 = fft::round_err8(S[1]);
-                worst = e0 > worst ? e0 : worst;
-                worst = e1 > worst ? e1 : worst;
-            }
-            fft::round16(S[0], lo);
-            fft::acc_update16(lane, S[1], lo, acc_c);
-        }
-        lds_sync();
-    }
-
-    if (CHECK && max_err_bits) {
-        unsigned long long b;
-        __builtin_memcpy(&b, &worst, 8);
-        atomicMax(max_err_bits, b);
-    }
-    if (live) {
-        const int lane = lane0;
-        if (trlwe_mode) {  // raw accumulator: TRLWE (a(X), b(X)), 2N words per job; each wave its polynomial
-            u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (2 * NTT_N) + (size_t)c * NTT_N;
-            for (int j = lane; j < NTT_N; j += 64) out[j] = acc_c[j];
-        }
-        else {             // sample extract at index 0: a'[0] = a[0], a'[j] = -a[N-j] (wave 0), b' = b[0] (wave 1)
-            u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (NTT_N + 1);
-            if (c == 0) {
-                for (int j = lane; j < NTT_N; j += 64) out[j] = (j == 0) ? acc_c[0] : 0u - acc_c[NTT_N - j];
-            }
-            else if (lane == 0) out[NTT_N] = acc_c[0];
-        }
-    }
-}
-
-#endif  // IYK_WITH_FFT2
 
 // ------------------------------------------------------------------------------------------------------------------------
 // Narrow frontiers on the FFT path: ONE ROTATION PER WORKGROUP of 8 wavefronts (one CU each), three workgroup barriers per

@@ -34,7 +34,7 @@ EXPORTS = [
     "iyk_hip_stream_gpu", "iyk_hip_arena_upload_slots", "iyk_hip_arena_download_slots", "iyk_hip_arena_copy",
     "iyk_hip_arena_sync_slots", "iyk_hip_trlwe_alloc", "iyk_hip_trlwe_free", "iyk_hip_trlwe_upload",
     "iyk_hip_trlwe_download", "iyk_hip_rotation_round", "iyk_hip_arena_sync_slots_multi", "iyk_hip_peer_access",
-    "iyk_hip_build_id",
+    "iyk_hip_build_id", "iyk_hip_host_alloc", "iyk_hip_host_free",
 ]
 
 

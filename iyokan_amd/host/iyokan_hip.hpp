@@ -466,15 +466,44 @@ using HIPNetwork = TaskNetwork<HIPWorkerInfo>;
 // kernel, a larger one in one more round) — the figures live in csrc/iyokan_hip.hip only, measured ones once
 // iyk_hip_calibrate() has run.  Never cached here: before iyk_hip_init the library answers with its compiled-in MI355X table,
 // afterwards with GPU 0's (round 3 cached the first answer for the whole process).
+// The table a planner prices with: fetched ONCE per planning call and passed down (the planner used to ask the library
+// several times per cut).  Multi-GPU: every GPU dispatches with its own calibrated threshold, so the common table is the
+// element-wise MAXIMUM over the GPUs (a cut is priced at what the slowest replica pays) with the smallest threshold.
 inline iyk_level_cost levelCostTable()
 {
     iyk_level_cost c{};
-    if (iyk_hip_level_cost_table(0, &c) != IYK_OK) (void)iyk_hip_level_cost_defaults(&c);
+    if (!iyk_hip_is_initialized()) {   // no fail() / last-error on a non-error path
+        (void)iyk_hip_level_cost_defaults(&c);
+        return c;
+    }
+    const int ngpu = iyk_hip_num_gpus();
+    for (int g = 0; g < ngpu; ++g) {
+        iyk_level_cost t{};
+        if (iyk_hip_level_cost_table(g, &t) != IYK_OK) continue;
+        if (g == 0) {
+            c = t;
+            continue;
+        }
+        c.round_ms = std::max(c.round_ms, t.round_ms);
+        for (int j = 0; j < 8; ++j) c.pass_ms[j] = std::max(c.pass_ms[j], t.pass_ms[j]);
+        c.max_passes = std::min(c.max_passes, t.max_passes);
+        c.calibrated = c.calibrated && t.calibrated;
+    }
     return c;
+}
+// iyk_hip_gate_batch's dispatch as a pure function of a table (csrc/iyokan_hip.hip: level_cost_ms)
+inline double levelCostMs(const iyk_level_cost& c, long rot)
+{
+    if (rot <= 0) return 0.0;
+    const long full = rot / c.round, rem = rot % c.round;
+    const double t = (double)c.round_ms * (double)full;
+    if (rem == 0) return t;
+    if (rem <= (long)c.max_passes * c.pass) return t + c.pass_ms[(rem + c.pass - 1) / c.pass - 1];
+    return t + c.round_ms;
 }
 inline long rotationRound() { return (long)levelCostTable().round; }
 inline long rotationPass() { return (long)levelCostTable().pass; }
-inline double levelCostMs(long rot) { return iyk_hip_level_cost_ms(0, (int)rot); }
+inline double levelCostMs(long rot) { return levelCostMs(levelCostTable(), rot); }
 
 // Static plan of a clock: the frontier (0, 1, ...) in which every task starts.  Same search as iyokan_amd/frontier.py
 // beam_levels: frontier by frontier, the ready gates sorted by their latest frontier (depth - 1 - upward rank: later would
@@ -509,12 +538,13 @@ class HIPWorker : public Worker<HIPWorkerInfo> {
             if (net.node(id).priority >= crit) must += r;
         }
         if (total == 0 || crit == 0) return;
+        const iyk_level_cost T = levelCostTable();   // once per frontier
         long cut = total;
-        double best = levelCostMs((total + G - 1) / G) / (double)total;
-        for (long q : {rotationRound() * G, rotationPass() * G}) {
+        double best = levelCostMs(T, (total + G - 1) / G) / (double)total;
+        for (long q : {(long)T.round * G, (long)T.pass * G}) {
             const long c = (total / q) * q;
             if (c < must || c <= 0 || c == total) continue;
-            const double v = levelCostMs((c + G - 1) / G) / (double)c;
+            const double v = levelCostMs(T, (c + G - 1) / G) / (double)c;
             if (v < best) best = v, cut = c;
         }
         if (cut == total) return;
@@ -649,7 +679,8 @@ inline std::vector<int> planLevels(const PlanGraph& pg, int G, int width, double
         std::vector<int> placed, ready;
         std::unordered_map<int, int> pending;
     };
-    const double rate = levelCostMs(rotationRound()) / (double)rotationRound();
+    const iyk_level_cost T = levelCostTable();   // once per plan
+    const double rate = levelCostMs(T, T.round) / (double)T.round;
     std::vector<std::shared_ptr<Partial>> beam{std::make_shared<Partial>()};
     for (int i = 0; i < n; ++i)
         if (indeg0[i] == 0) beam[0]->ready.push_back(i);
@@ -681,7 +712,7 @@ inline std::vector<int> planLevels(const PlanGraph& pg, int G, int width, double
             }
             std::vector<long> cuts{total};
             if (total && k + 1 < depth)
-                for (long q : {rotationRound() * G, rotationPass() * G})
+                for (long q : {(long)T.round * G, (long)T.pass * G})
                     for (long c : {(total / q) * q, (total / q) * q - q})
                         if (c >= must && c > 0 && std::find(cuts.begin(), cuts.end(), c) == cuts.end()) cuts.push_back(c);
             std::sort(cuts.begin(), cuts.end());  // with the stable sort below: the order frontier.plan_levels (Python) walks
@@ -706,7 +737,7 @@ inline std::vector<int> planLevels(const PlanGraph& pg, int G, int width, double
                         g->ready.push_back(id);
                     }
                 }
-                g->ms += levelCostMs((acc + G - 1) / G);
+                g->ms += levelCostMs(T, (acc + G - 1) / G);
                 g->done += acc;
                 grown.push_back(std::move(g));
             }

@@ -199,7 +199,9 @@ class TFHEPacket:
         """PlainPacket::encrypt (/root/reference/src/packet.hpp:225-262): every RAM / ROM image in BOTH forms — TLWE lvl0 rows
         (`ramInTLWE`, `romInTLWE`: what the MUX memories and this backend read) and TRLWE lvl1 (`ram`: one per bit, `rom`: N bits
         per ciphertext — what upstream's CMUX memories read), so that a request made here can drive either kind of run;
-        trlwe=False leaves the TRLWE maps empty (4 KB per RAM bit)."""
+        trlwe=False leaves the TRLWE maps empty (a TRLWE lvl1 is 2N words = 8 KB per RAM bit, and its phases cost an O(N^2) product
+        each: callers that only feed THIS backend — which reads the TLWE forms — should pass trlwe=False, as the C++ encryptPacket's
+        default does)."""
         from . import client
 
         t = cls(keys.params, plain.cycles)

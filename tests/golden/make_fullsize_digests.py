@@ -23,18 +23,27 @@ from iyokan_amd.params import OPS, params_128bit, params_80bit  # noqa: E402
 SETS = {   # name: (params, rng seed of bits / operand choice, number of input ciphertexts, encryption seed)
     "128": (params_128bit, 2, 4096, 2),
     "80": (params_80bit, 12, 2048, 6),
+    # round 5: SURVEY 8(d) config 2's own input shape — 2 x 65 536 FRESH encryptions, gate g =
+    # NAND(in[g], in[G + g]), key seed 1, data seed 2 — which is exactly what bench.py times on rank 0 (bits from
+    # default_rng(1000), encryptions with seed 2): `bench.py` compares the words of its TIMED step with these digests
+    "fresh_128": (params_128bit, 1000, 2 * 65536, 2),
+    "fresh_80": (params_80bit, 1000, 2 * 65536, 2),
 }
 G = 65536
 
 
 def workload(name):
-    """the exact inputs of the full-size GPU tests: (keys, bits, ia, ib, enc)"""
+    """the exact inputs of the full-size GPU tests / of bench.py: (keys, bits, ia, ib, enc)"""
     mk, rs, nin, es = SETS[name]
     keys = client.keygen(mk(), seed=1)
     rng = np.random.default_rng(rs)
     bits = rng.integers(0, 2, size=nin).astype(np.uint8)
-    ia = rng.integers(0, nin, size=G).astype(np.int32)
-    ib = rng.integers(0, nin, size=G).astype(np.int32)
+    if name.startswith("fresh"):
+        ia = np.arange(G, dtype=np.int32)
+        ib = ia + G
+    else:
+        ia = rng.integers(0, nin, size=G).astype(np.int32)
+        ib = rng.integers(0, nin, size=G).astype(np.int32)
     return keys, bits, ia, ib, client.encrypt_bits(keys, bits, seed=es)
 
 
@@ -54,12 +63,19 @@ def main():
         t0 = time.time()
         CH = 4096
         for lo in range(0, G, CH):
-            arena = np.zeros((nin + CH, p.n + 1), dtype=np.uint32)
-            arena[:nin] = enc
-            orc.gate_batch([OPS["NAND"]] * CH, ia[lo:lo + CH], ib[lo:lo + CH], [-1] * CH, list(range(nin, nin + CH)), arena,
+            if name.startswith("fresh"):     # the chunk's own operands only: [in0 of the chunk | in1 of the chunk | outputs]
+                arena = np.zeros((3 * CH, p.n + 1), dtype=np.uint32)
+                arena[:CH] = enc[ia[lo:lo + CH]]
+                arena[CH:2 * CH] = enc[ib[lo:lo + CH]]
+                a_idx, b_idx, first_out = np.arange(CH, dtype=np.int32), np.arange(CH, 2 * CH, dtype=np.int32), 2 * CH
+            else:
+                arena = np.zeros((nin + CH, p.n + 1), dtype=np.uint32)
+                arena[:nin] = enc
+                a_idx, b_idx, first_out = ia[lo:lo + CH], ib[lo:lo + CH], nin
+            orc.gate_batch([OPS["NAND"]] * CH, a_idx, b_idx, [-1] * CH, list(range(first_out, first_out + CH)), arena,
                            nthreads=os.cpu_count() or 1, mode=mode)
-            assert np.array_equal(client.decrypt_bits(keys, arena[nin:]), 1 - (bits[ia[lo:lo + CH]] & bits[ib[lo:lo + CH]]))
-            out[lo:lo + CH] = digests(arena[nin:])
+            assert np.array_equal(client.decrypt_bits(keys, arena[first_out:]), 1 - (bits[ia[lo:lo + CH]] & bits[ib[lo:lo + CH]]))
+            out[lo:lo + CH] = digests(arena[first_out:])
             print(name, lo + CH, f"{time.time() - t0:.0f}s", flush=True)
         orc.close()
         out.tofile(os.path.join(HERE, f"fullsize_nand_{name}.bin"))

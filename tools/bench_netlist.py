@@ -25,6 +25,45 @@ NETS = {
 }
 
 
+def broadcast_cost_table(table, dist, device):
+    """rank 0's iyk_level_cost (a dict of numbers + build id) to every rank, as one float64 tensor"""
+    import torch
+
+    keys = ["round", "pass", "max_passes", "calibrated", "round_ms"]
+    vec = [float(table[k]) for k in keys] + [float(v) for v in table["pass_ms"]]
+    t = torch.tensor(vec, dtype=torch.float64, device=device)
+    dist.broadcast(t, src=0)
+    vals = [float(v) for v in t.cpu()]
+    out = dict(table)
+    for k, v in zip(keys, vals):
+        out[k] = bool(round(v)) if k == "calibrated" else (int(round(v)) if k != "round_ms" else v)
+    out["pass_ms"] = vals[len(keys):]
+    return out
+
+
+def plan_fingerprint(plan):
+    """63 bits of sha256 over the plan's levels (node ids per level) and slot assignment"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for level in plan.levels:   # {"boot": node ids, "ew": node ids, "base": first slot, "B": gates per rank}
+        h.update(np.asarray(level["boot"], dtype=np.int64).tobytes() + b"|" + np.asarray(level["ew"], dtype=np.int64).tobytes())
+        h.update(np.asarray([level["base"], level["B"]], dtype=np.int64).tobytes())
+    h.update(np.asarray(plan.slot, dtype=np.int64).tobytes())
+    return int.from_bytes(h.digest()[:8], "little") >> 1
+
+
+def assert_same_plan(plan, dist, device):
+    import torch
+
+    mine = torch.tensor([plan_fingerprint(plan)], dtype=torch.int64, device=device)
+    lo, hi = mine.clone(), mine.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if int(lo.item()) != int(hi.item()):
+        raise SystemExit("bench_netlist: the ranks derived different level plans — refusing to run the level exchange")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--net", default="mux-ram", choices=sorted(NETS))
@@ -69,8 +108,18 @@ def main():
     if distributed:
         keys = bench.broadcast_keys(keys, dist, dev, rank)   # rank 0's key material, once, over RCCL
     hip.initialize(keys, device_ids=(local,))
-    level_cost = make_level_cost(hip.calibrate(0))       # THIS device's table, measured (0.15 s): rounds, passes, threshold
+    # The level plan (cuts, slot layout, per-level widths) is a function of the cost table, and every rank must derive the SAME
+    # plan: the in-place all_gather_into_tensor assumes identical offsets and sizes everywhere.  Each rank calibrates its own GPU
+    # (its dispatch threshold follows its own measurement), but the PLAN is made from rank 0's table, broadcast — noisy per-rank
+    # floats picking different cuts would hang RCCL or corrupt ciphertexts.  A hash of the plan is compared
+    # across the ranks before anything runs.
+    table = hip.calibrate(0)
+    if distributed:
+        table = broadcast_cost_table(table, dist, dev)
+    level_cost = make_level_cost(table)
     plan = FrontierPlan(nl, world, balance=args.plan == "balanced", cost=level_cost)
+    if distributed:
+        assert_same_plan(plan, dist, dev)
     be = HipBackend(plan.num_slots, p, dev)
     ex = FrontierExecutor(plan, be, rank, world, dist if distributed else None)   # one rank too: the level exchange runs on RCCL
     if distributed and world == 1:
