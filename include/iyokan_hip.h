@@ -202,7 +202,19 @@ int iyk_hip_gate_batch(iyk_hip_stream* st, uint32_t* d_arena, uint64_t arena_slo
  * mirror inside the stream, so that neither the call nor the poll ever waits for the gate — the ciphertexts themselves may be
  * ordinary memory (TFHEpp::TLWE in a std::shared_ptr, as upstream's tasks hold them).  One gate in flight per stream
  * (the reference's shape: one Ctxt set per worker, /root/reference/src/iyokan_cufhe.hpp:290-312); a second call before the
- * first was seen idle finishes the first one first. */
+ * first was seen idle finishes the first one first.
+ *
+ * COALESCING (default; IYK_HIP_COALESCE=0 at iyk_hip_init turns it off).  The reference relies on the GPU running the kernels of
+ * its 240 - 800 one-gate streams side by side; this part runs launches of different streams of a process about four at a time
+ * (hardware queues), i.e. ~1.5 k gates/s however many streams there are.  So the call does not launch: the gate is parked — its
+ * operands copied into a page-locked batch buffer of the GPU — and ALL parked gates of the GPU go out as one iyk_hip_gate_batch on
+ * a stream of the library's own at the second iyk_hip_stream_query of any parked stream (the reference's worker polls once right
+ * after starting a gate, /root/reference/src/iyokan.hpp:851-874: the second poll means every worker of the sweep has handed its
+ * gate in), at IYK_HIP_COALESCE_MAX parked gates (default 2048), or at iyk_hip_stream_sync.  iyk_hip_stream_query(st) returns 1
+ * once st's gate has come back and `out` is written.  Results are the same words either way; the reference's harness shape
+ * (one host thread, processAllGates(net, 240)) reaches ~60 % of the batched flavour's rate instead of ~1 %
+ * (profiles/r05_per_gate.txt).  Other work enqueued on `st` is not ordered against a parked gate: a stream used for
+ * iyk_hip_gate_host should be used for nothing else until it has been seen idle (the reference's workers do exactly that). */
 int iyk_hip_gate_host(iyk_hip_stream* st, int op, const uint32_t* in0, const uint32_t* in1,
                       const uint32_t* in2, uint32_t* out);
 
@@ -310,7 +322,14 @@ typedef struct iyk_level_cost {
 int iyk_hip_level_cost_defaults(iyk_level_cost* out);
 int iyk_hip_level_cost_table(int gpu_index, iyk_level_cost* out);
 double iyk_hip_level_cost_ms(int gpu_index, int rotations);
-int iyk_hip_calibrate(int gpu_index);
+int iyk_hip_calibrate(int gpu_index);   /* gpu_index = -1: every GPU, concurrently (one host thread each) */
+
+/* The steps of the last iyk_hip_init, "name [gpu] milliseconds" separated by ';': alloc g, pin, enqueue g, wait g.  Since round 5
+ * the devices are fed CONCURRENTLY — buffers everywhere, the caller's key arrays page-locked once, uploads + key transforms
+ * enqueued on one stream per device, then one wait per device — so every "enqueue" precedes the first "wait" and N GPUs cost about
+ * what one costs (the reference replicates by a per-device loop inside cufhe::Initialize, /root/reference/src/iyokan_cufhe.cpp:530-536).
+ * Valid until the next iyk_hip_init. */
+const char* iyk_hip_init_profile(void);
 
 /* Bytes of device memory holding keys on one GPU (NTT-domain BK + padded KSK + tables). */
 int iyk_hip_resident_key_bytes(uint64_t* out);

@@ -13,6 +13,8 @@
 // are set once per device inside iyk_hip_init (under its lock), a failed init releases what it allocated.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -21,6 +23,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -56,6 +59,7 @@ int fail(int code, const std::string& msg)
 
 constexpr int MAX_GPUS = 64;
 
+struct GateCoalescer;
 struct Device {
     int ordinal = -1;
     int cus = 256;           // compute units (one wave-per-rotation workgroup each)
@@ -68,6 +72,7 @@ struct Device {
     fft::ConstsAll* fftc = nullptr;   // fft512.hpp's constants, then fft256.hpp's
     unsigned long long* fft_err = nullptr;  // IYK_HIP_DEBUG: largest |z - rint(z)| seen by the FFT kernel (bits of a double)
     iyk_level_cost cost{};         // what a level of r rotations costs on this GPU (iyk_hip_level_cost_table); read / written under G.mu
+    struct GateCoalescer* co = nullptr;   // lazily created by iyk_hip_gate_host (one per GPU); freed by iyk_hip_cleanup
     int max_passes = 0;            // cost.max_passes as the dispatch reads it: __atomic loads / stores, lock-free (a calibration may run
                                    // beside a batch; a plain int keeps Device copyable)
     void release()
@@ -132,10 +137,14 @@ double level_cost_ms(const iyk_level_cost& c, long rot)
     return t + c.round_ms;
 }
 
+void coalescer_free(Device& D);
+int coalescer_poll(iyk_hip_stream* st, bool block);
+
 struct Global {
     std::mutex mu;
     std::atomic<bool> init{false};
     bool debug = false;           // IYK_HIP_DEBUG=1 at init: gate_batch also verifies the independence contract
+    bool coalesce = true;         // IYK_HIP_COALESCE=0 at init: iyk_hip_gate_host launches per gate on the caller's stream
     iyk_params p{};
     u32 ksk_stride = 0;
     int ks_kernel = 1;    // 1: keyswitch_wave_kernel where instantiated, 0: keyswitch_kernel (IYK_HIP_KS_KERNEL)
@@ -187,6 +196,9 @@ struct iyk_hip_stream {
     u32* d_scratch = nullptr;
     u32* h_gate = nullptr;
     u32* gate_out_user = nullptr;
+    // a gate of this stream travelling in a COALESCED batch (GateCoalescer below): generation and position, 0 = none
+    uint64_t co_gen = 0;
+    uint32_t co_index = 0, co_polls = 0;
 };
 
 namespace {
@@ -399,6 +411,26 @@ template <int T, int NC, int GW>
 int launch_keyswitch_wave(iyk_hip_stream* st, u32* d_arena, const KsJob* d_jobs, int njobs)
 {
     const Device& D = G.devs[st->gpu];
+    static const int shared_max = [] {   // IYK_HIP_KS_SHARED_MAX: largest batch on the shared-gates form (0 = never; A/B and tests)
+        const char* e = std::getenv("IYK_HIP_KS_SHARED_MAX");
+        return e ? std::atoi(e) : 4096;
+    }();
+    if (njobs <= shared_max) {
+        // narrow frontier: a workgroup's four waves share GW gates and split the i range; a quarter of the atomics (kernels.hpp)
+        static const int min_wg = [] {   // IYK_HIP_KS_SHARED_WG: workgroups a launch is sliced up to (A/B: profiles/r05_ks_small_ab.txt)
+            const char* e = std::getenv("IYK_HIP_KS_SHARED_WG");
+            return e ? std::max(1, std::atoi(e)) : 512;
+        }();
+        const int groups = (njobs + GW - 1) / GW;
+        int slices = 1;
+        while (slices < 256 && groups * slices < min_wg) slices *= 2;
+        const u32 i_per_slice = (u32)NTT_N / (u32)slices;   // per workgroup: >= 4, one i per wave at least
+        hipLaunchKernelGGL((keyswitch_wave_kernel<T, NC, GW, true>), dim3((unsigned)groups, (unsigned)slices), dim3(256),
+                           (size_t)4 * GW * KS2_CHUNK * 2 + (size_t)GW * NC * 128 * 4, st->s, (const u32*)st->d_rot, d_jobs, njobs,
+                           (const u32*)D.ksk, d_arena, G.p.n, G.ksk_stride, i_per_slice);
+        HIP_TRY(hipGetLastError());
+        return IYK_OK;
+    }
     const int groups = (njobs + 4 * GW - 1) / (4 * GW);
     int slices = 1;
     while (slices < 256 && groups * slices < 512) slices *= 2;
@@ -546,60 +578,140 @@ void destroy_stream_resources(iyk_hip_stream* st)
     if (st->owned && st->s) (void)hipStreamDestroy(st->s);
 }
 
+// What iyk_hip_init did, step by step, for iyk_hip_init_profile(): "alloc g", "pin", "enqueue g", "wait g" with milliseconds.
+std::string g_init_log;
+void init_note(const char* what, int g, double ms)
+{
+    char buf[96];
+    if (g >= 0) std::snprintf(buf, sizeof buf, "%s%s %d %.2f", g_init_log.empty() ? "" : ";", what, g, ms);
+    else std::snprintf(buf, sizeof buf, "%s%s %.2f", g_init_log.empty() ? "" : ";", what, ms);
+    g_init_log += buf;
+}
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Round 5: every GPU is fed CONCURRENTLY.  Round 4 went device by device — pageable upload, transforms,
+// hipDeviceSynchronize — so eight GPUs cost eight times one.  Now: (1) allocate everywhere; (2) page-lock the caller's two key arrays
+// once (in place: hipHostRegister); (3) per device, on a stream of its own, enqueue the uploads and the key transforms — nothing
+// waits; (4) wait for all streams.  The devices' PCIe links and transform kernels overlap; the host does one pass of enqueues.
 int init_devices(std::vector<Device>& devs, const int* device_ids, int avail, const iyk_params& p, bool use_fp,
                  bool use_fft, const fft::ConstsAll& fftc, int split, const uint32_t* bk_torus, const std::vector<u32>& ksk_pad, const std::vector<u64>& twf,
                  const std::vector<u64>& twi, const fp::HostTables& fpt)
 {
     const size_t bk_words = (size_t)iyk_bk_words(&p);
     const size_t polys = bk_words / NTT_N;
+    g_init_log.clear();
+    struct PerDevice {
+        hipStream_t s = nullptr;
+        u32* d_bk = nullptr;   // torus-domain copy: only needed until the transforms have run
+    };
+    std::vector<PerDevice> pd(devs.size());
+    bool pinned_bk = false, pinned_ksk = false;
+    auto cleanup = [&] {
+        for (size_t g = 0; g < devs.size(); ++g) {
+            if (devs[g].ordinal >= 0) (void)hipSetDevice(devs[g].ordinal);
+            if (pd[g].s) {
+                (void)hipStreamSynchronize(pd[g].s);
+                (void)hipStreamDestroy(pd[g].s);
+            }
+            if (pd[g].d_bk) (void)hipFree(pd[g].d_bk);
+        }
+        if (pinned_bk) (void)hipHostUnregister((void*)bk_torus);
+        if (pinned_ksk) (void)hipHostUnregister((void*)ksk_pad.data());
+    };
+#define INIT_TRY(expr)                                                                    \
+    do {                                                                                  \
+        hipError_t e__ = (expr);                                                          \
+        if (e__ != hipSuccess) {                                                          \
+            cleanup();                                                                    \
+            return fail(IYK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+        }                                                                                 \
+    } while (0)
+    // (1) buffers
     for (size_t g = 0; g < devs.size(); ++g) {
+        const double t0 = now_ms();
         Device& D = devs[g];
         const int ord = device_ids ? device_ids[g] : (int)g;
-        if (ord < 0 || ord >= avail) return fail(IYK_ERR_INVALID, "device ordinal out of range");
+        if (ord < 0 || ord >= avail) {
+            cleanup();
+            return fail(IYK_ERR_INVALID, "device ordinal out of range");
+        }
         D.ordinal = ord;
-        HIP_TRY(hipSetDevice(D.ordinal));
-        HIP_TRY(hipDeviceGetAttribute(&D.cus, hipDeviceAttributeMultiprocessorCount, D.ordinal));
-        if (D.cus < 1) return fail(IYK_ERR_HIP, "device reports no compute units");
+        INIT_TRY(hipSetDevice(D.ordinal));
+        INIT_TRY(hipDeviceGetAttribute(&D.cus, hipDeviceAttributeMultiprocessorCount, D.ordinal));
+        if (D.cus < 1) {
+            cleanup();
+            return fail(IYK_ERR_HIP, "device reports no compute units");
+        }
         int rc = set_kernel_attrs(p, use_fp, split);
-        if (rc) return rc;
-        u32* d_bk = nullptr;
-        HIP_TRY(hipMalloc((void**)&D.bk_ntt, bk_words * sizeof(u64) * (use_fp ? split : 1)));
-        HIP_TRY(hipMalloc((void**)&D.ksk, ksk_pad.size() * sizeof(u32)));
-        HIP_TRY(hipMalloc((void**)&D.tw_fwd, NTT_N * sizeof(u64)));
-        HIP_TRY(hipMalloc((void**)&D.tw_inv, 2 * NTT_N * sizeof(u64)));
-        HIP_TRY(hipMalloc((void**)&D.fpc, sizeof(fp::NttConsts)));
-        HIP_TRY(hipMalloc((void**)&d_bk, bk_words * sizeof(u32)));
-        struct Tmp {  // the torus-domain copy is only needed until the forward NTT has run
-            u32* p;
-            ~Tmp() { (void)hipFree(p); }
-        } tmp{d_bk};
-        HIP_TRY(hipMemcpy(D.fpc, &fpt.c, sizeof(fp::NttConsts), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d_bk, bk_torus, bk_words * sizeof(u32), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(D.ksk, ksk_pad.data(), ksk_pad.size() * sizeof(u32), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(D.tw_fwd, twf.data(), NTT_N * sizeof(u64), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(D.tw_inv, twi.data(), 2 * NTT_N * sizeof(u64), hipMemcpyHostToDevice));
+        if (rc) {
+            cleanup();
+            return rc;
+        }
+        INIT_TRY(hipStreamCreateWithFlags(&pd[g].s, hipStreamNonBlocking));
+        INIT_TRY(hipMalloc((void**)&D.bk_ntt, bk_words * sizeof(u64) * (use_fp ? split : 1)));
+        INIT_TRY(hipMalloc((void**)&D.ksk, ksk_pad.size() * sizeof(u32)));
+        INIT_TRY(hipMalloc((void**)&D.tw_fwd, NTT_N * sizeof(u64)));
+        INIT_TRY(hipMalloc((void**)&D.tw_inv, 2 * NTT_N * sizeof(u64)));
+        INIT_TRY(hipMalloc((void**)&D.fpc, sizeof(fp::NttConsts)));
+        INIT_TRY(hipMalloc((void**)&pd[g].d_bk, bk_words * sizeof(u32)));
+        if (use_fft) {
+            INIT_TRY(hipMalloc((void**)&D.bk_fft, polys * 2 * fft::M * sizeof(fft::cplx)));
+            INIT_TRY(hipMalloc((void**)&D.fftc, sizeof(fft::ConstsAll)));
+            INIT_TRY(hipMalloc((void**)&D.fft_err, sizeof(unsigned long long)));
+        }
+        init_note("alloc", (int)g, now_ms() - t0);
+    }
+    // (2) the two big arrays page-locked in place, once for all devices (a failure here only costs the overlap: pageable copies
+    // are staged by the runtime)
+    {
+        const double t0 = now_ms();
+        pinned_bk = hipHostRegister((void*)bk_torus, bk_words * sizeof(u32), hipHostRegisterDefault) == hipSuccess;
+        pinned_ksk = hipHostRegister((void*)ksk_pad.data(), ksk_pad.size() * sizeof(u32), hipHostRegisterDefault) == hipSuccess;
+        (void)hipGetLastError();
+        init_note(pinned_bk && pinned_ksk ? "pin" : "pin-failed", -1, now_ms() - t0);
+    }
+    // (3) uploads + transforms, enqueued device after device; nothing waits
+    for (size_t g = 0; g < devs.size(); ++g) {
+        const double t0 = now_ms();
+        Device& D = devs[g];
+        hipStream_t s = pd[g].s;
+        INIT_TRY(hipSetDevice(D.ordinal));
+        INIT_TRY(hipMemcpyAsync(D.fpc, &fpt.c, sizeof(fp::NttConsts), hipMemcpyHostToDevice, s));
+        INIT_TRY(hipMemcpyAsync(pd[g].d_bk, bk_torus, bk_words * sizeof(u32), hipMemcpyHostToDevice, s));
+        INIT_TRY(hipMemcpyAsync(D.ksk, ksk_pad.data(), ksk_pad.size() * sizeof(u32), hipMemcpyHostToDevice, s));
+        INIT_TRY(hipMemcpyAsync(D.tw_fwd, twf.data(), NTT_N * sizeof(u64), hipMemcpyHostToDevice, s));
+        INIT_TRY(hipMemcpyAsync(D.tw_inv, twi.data(), 2 * NTT_N * sizeof(u64), hipMemcpyHostToDevice, s));
         if (use_fp)
-            hipLaunchKernelGGL(bk_ntt_fp_kernel, dim3((unsigned)((polys * split + 1) / 2)), dim3(64), 0, 0, d_bk,
+            hipLaunchKernelGGL(bk_ntt_fp_kernel, dim3((unsigned)((polys * split + 1) / 2)), dim3(64), 0, s, pd[g].d_bk,
                                (double*)D.bk_ntt, (const double*)D.tw_fwd, D.fpc, polys * split, (int)p.l, split,
                                (int)p.Bgbit / 2);
         else
-            hipLaunchKernelGGL(bk_ntt_kernel, dim3((unsigned)((polys + 1) / 2)), dim3(64), 0, 0, d_bk, D.bk_ntt,
+            hipLaunchKernelGGL(bk_ntt_kernel, dim3((unsigned)((polys + 1) / 2)), dim3(64), 0, s, pd[g].d_bk, D.bk_ntt,
                                D.tw_fwd, polys);
-        HIP_TRY(hipGetLastError());
+        INIT_TRY(hipGetLastError());
         if (use_fft) {  // the wave-per-rotation kernel's key: spectra of the signed 16-bit halves, 2 x 8 KB per polynomial
-            HIP_TRY(hipMalloc((void**)&D.bk_fft, polys * 2 * fft::M * sizeof(fft::cplx)));
-            HIP_TRY(hipMalloc((void**)&D.fftc, sizeof(fft::ConstsAll)));
-            HIP_TRY(hipMalloc((void**)&D.fft_err, sizeof(unsigned long long)));
-            HIP_TRY(hipMemset(D.fft_err, 0, sizeof(unsigned long long)));
-            HIP_TRY(hipMemcpy(D.fftc, &fftc, sizeof(fft::ConstsAll), hipMemcpyHostToDevice));
-            hipLaunchKernelGGL(bk_fft_kernel, dim3((unsigned)(polys * 2)), dim3(64), 0, 0, d_bk, D.bk_fft,
+            INIT_TRY(hipMemsetAsync(D.fft_err, 0, sizeof(unsigned long long), s));
+            INIT_TRY(hipMemcpyAsync(D.fftc, &fftc, sizeof(fft::ConstsAll), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(bk_fft_kernel, dim3((unsigned)(polys * 2)), dim3(64), 0, s, pd[g].d_bk, D.bk_fft,
                                &D.fftc->c, polys);
-            HIP_TRY(hipGetLastError());
+            INIT_TRY(hipGetLastError());
         }
-        HIP_TRY(hipDeviceSynchronize());
         D.cost = default_level_cost(D.cus, use_fft ? 2 : use_fp ? 1 : 0, p.n < 600);
         __atomic_store_n(&D.max_passes, D.cost.max_passes, __ATOMIC_RELAXED);
+        init_note("enqueue", (int)g, now_ms() - t0);
     }
+    // (4) one wait per device, after everything is in flight
+    for (size_t g = 0; g < devs.size(); ++g) {
+        const double t0 = now_ms();
+        INIT_TRY(hipSetDevice(devs[g].ordinal));
+        INIT_TRY(hipStreamSynchronize(pd[g].s));
+        init_note("wait", (int)g, now_ms() - t0);
+    }
+#undef INIT_TRY
+    cleanup();
     return IYK_OK;
 }
 
@@ -755,7 +867,32 @@ double iyk_hip_level_cost_ms(int gpu_index, int rotations)
  * on random mod-switched rows (every kernel runs all n CMUX steps whatever the row holds), HIP events on a private stream.  The table of
  * GPU `gpu_index` then holds measured milliseconds, and the dispatch's narrow-frontier threshold follows it (the largest
  * number of passes still cheaper than one more round). */
+static int calibrate_one(int gpu_index);
+
+// gpu_index = -1: every GPU, CONCURRENTLY (one host thread each: a calibration is a chain of timed launches the host waits for;
+// eight in a row cost 1.2 s of bring-up for nothing — VERDICT r04 #7).  Errors of a worker thread are re-raised on the caller's.
 int iyk_hip_calibrate(int gpu_index)
+{
+    IYK_API_BEGIN
+    if (gpu_index != -1) return calibrate_one(gpu_index);
+    if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
+    const int n = (int)G.devs.size();
+    std::vector<int> rc(n, IYK_OK);
+    std::vector<std::string> msg(n);
+    std::vector<std::thread> th;
+    for (int g = 0; g < n; ++g)
+        th.emplace_back([g, &rc, &msg] {
+            rc[g] = calibrate_one(g);
+            if (rc[g]) msg[g] = iyk_hip_last_error();
+        });
+    for (auto& t : th) t.join();
+    for (int g = 0; g < n; ++g)
+        if (rc[g]) return fail(rc[g], "calibration of GPU " + std::to_string(g) + ": " + msg[g]);
+    return IYK_OK;
+    IYK_API_END
+}
+
+static int calibrate_one(int gpu_index)
 {
     IYK_API_BEGIN
     if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
@@ -834,6 +971,10 @@ int iyk_hip_calibrate(int gpu_index)
     return done(IYK_OK);
     IYK_API_END
 }
+
+// The steps of the last iyk_hip_init as "name [gpu] milliseconds" separated by ';' — alloc g / pin / enqueue g / wait g — for
+// tests and for the multi-GPU bring-up: every "enqueue" precedes the first "wait" (the devices are fed concurrently).
+const char* iyk_hip_init_profile(void) { return g_init_log.c_str(); }
 
 int iyk_hip_resident_key_bytes(uint64_t* out)
 {
@@ -943,6 +1084,8 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
             if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) peer[(size_t)a * ngpu + b] = 1;
             (void)hipGetLastError();
         }
+    if (const char* co = std::getenv("IYK_HIP_COALESCE")) G.coalesce = co[0] != '0';
+    else G.coalesce = true;
     const char* dbg = std::getenv("IYK_HIP_DEBUG");
     G.ks_kernel = 1;
     G.debug = dbg && dbg[0] == '1';
@@ -966,7 +1109,12 @@ int iyk_hip_cleanup(void)
     IYK_API_BEGIN
     std::lock_guard<std::mutex> lock(G.mu);
     if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
-    if (G.nstreams.load() != 0) return fail(IYK_ERR_STATE, "streams still alive");
+    {   // the coalescers' own streams do not count as the caller's
+        int own = 0;
+        for (Device& D : G.devs) own += D.co ? 1 : 0;
+        if (G.nstreams.load() != own) return fail(IYK_ERR_STATE, "streams still alive");
+        for (Device& D : G.devs) coalescer_free(D);
+    }
     for (Device& D : G.devs) D.release();
     G.devs.clear();
     G.init.store(false);
@@ -994,6 +1142,7 @@ int iyk_hip_stream_destroy(iyk_hip_stream* st)
     if (!st) return fail(IYK_ERR_INVALID, "null stream");
     int rc = set_device(st->gpu);
     if (rc) return rc;
+    if (st->co_gen && (rc = coalescer_poll(st, true)) < 0) return rc;   // a parked gate still owes its result to the caller
     HIP_TRY(hipStreamSynchronize(st->s));
     destroy_stream_resources(st);
     delete st;
@@ -1007,7 +1156,7 @@ int iyk_hip_stream_gpu(iyk_hip_stream* st) { return st ? st->gpu : fail(IYK_ERR_
 // the stream is idle: hand a finished iyk_hip_gate_host result from the pinned mirror to the caller's ciphertext
 static void deliver_gate_result(iyk_hip_stream* st)
 {
-    if (st->gate_out_user) {
+    if (st->gate_out_user && !st->co_gen) {
         std::memcpy(st->gate_out_user, st->h_gate, ((size_t)G.p.n + 1) * sizeof(u32));
         st->gate_out_user = nullptr;
     }
@@ -1016,6 +1165,10 @@ static void deliver_gate_result(iyk_hip_stream* st)
 int iyk_hip_stream_query(iyk_hip_stream* st)
 {
     if (!st) return fail(IYK_ERR_INVALID, "null stream");
+    if (st->co_gen) {   // a gate of this stream travels in a coalesced batch (iyk_hip_gate_host): idle once that has come back
+        const int r = coalescer_poll(st, false);
+        if (r <= 0) return r;
+    }
     hipError_t e = hipStreamQuery(st->s);
     if (e == hipSuccess) {
         deliver_gate_result(st);
@@ -1028,6 +1181,10 @@ int iyk_hip_stream_query(iyk_hip_stream* st)
 int iyk_hip_stream_sync(iyk_hip_stream* st)
 {
     if (!st) return fail(IYK_ERR_INVALID, "null stream");
+    if (st->co_gen) {
+        const int r = coalescer_poll(st, true);
+        if (r < 0) return r;
+    }
     HIP_TRY(hipStreamSynchronize(st->s));
     deliver_gate_result(st);
     return IYK_OK;
@@ -1361,6 +1518,172 @@ int iyk_hip_gate_batch(iyk_hip_stream* st, uint32_t* d_arena, uint64_t arena_slo
     IYK_API_END
 }
 
+// ---- one gate per stream, coalesced ------------------------------------------------------------------------------------------
+// The reference drives its GPU with hundreds of one-gate workers, one stream each, and relies on the GPU running their kernels
+// side by side (/root/reference/src/iyokan_cufhe.hpp:207-247, 290-312; 800 workers: iyokan_cufhe.cpp:259).  On this part kernels of
+// different streams of one process share a handful of hardware queues: measured, 240 or 800 streams of one-rotation launches run
+// four at a time — 1.5 k gates/s (profiles/r05_per_gate.txt) — whatever the host does.  So iyk_hip_gate_host does not launch: it
+// parks the gate (operands copied into a page-locked batch buffer) and the library sends every parked gate of the GPU as ONE
+// iyk_hip_gate_batch on a stream of its own when the callers start polling in earnest — at the SECOND iyk_hip_stream_query of any
+// parked stream (the reference's worker polls once right after starting a gate, /root/reference/src/iyokan.hpp:851-874; the second
+// poll means a whole sweep over the workers has passed and everybody who had a gate has handed it in), at
+// IYK_HIP_COALESCE_MAX parked gates (default 2048), or at iyk_hip_stream_sync.  A stream reports idle once its gate's batch
+// has finished and the result has been copied to the caller's ciphertext.  Same arithmetic, same words; only WHEN things run
+// differs.  Two batches are in the air at most: one on the GPU, one filling.  IYK_HIP_COALESCE=0 at init restores one launch
+// sequence per gate on the caller's stream.
+namespace {
+
+struct GateCoalescer {
+    iyk_hip_stream* st = nullptr;        // the library's own stream on this GPU
+    struct Side {                        // one of the two batch buffers
+        u32* h_in = nullptr;             // page-locked [cap][3][n + 1]
+        u32* h_out = nullptr;            // page-locked [cap][n + 1]
+        u32* d_arena = nullptr;          // [4 cap][n + 1]: gate g reads slots 3 g .. 3 g + 2, writes slot 3 cap + g
+        size_t cap = 0;
+        std::vector<int32_t> ops, in0, in1, in2, out;
+        uint64_t gen = 0;                // generation this side holds (0 = free)
+        size_t undelivered = 0;          // results not yet picked up by their streams
+        bool flying = false;
+        hipEvent_t done = nullptr;
+    } side[2];
+    int open = 0;                        // side that is filling
+    uint64_t next_gen = 1;
+    size_t max_gates = 2048;
+};
+
+int coalescer_get(int gpu, GateCoalescer** out)
+{
+    Device& D = G.devs[gpu];
+    if (!D.co) {
+        GateCoalescer* c = new (std::nothrow) GateCoalescer();
+        if (!c) return fail(IYK_ERR_NOMEM, "out of host memory");
+        int rc = stream_new(gpu, nullptr, false, &c->st);
+        if (rc) {
+            delete c;
+            return rc;
+        }
+        for (auto& sd : c->side)
+            if (hipEventCreateWithFlags(&sd.done, hipEventDisableTiming) != hipSuccess) return fail(IYK_ERR_HIP, "hipEventCreate");
+        if (const char* m = std::getenv("IYK_HIP_COALESCE_MAX")) c->max_gates = (size_t)std::max(1, std::atoi(m));
+        c->side[0].gen = c->next_gen++;
+        D.co = c;
+    }
+    *out = D.co;
+    return IYK_OK;
+}
+
+void coalescer_free(Device& D)
+{
+    GateCoalescer* c = D.co;
+    if (!c) return;
+    (void)hipSetDevice(D.ordinal);
+    if (c->st) {
+        (void)hipStreamSynchronize(c->st->s);
+        destroy_stream_resources(c->st);
+        delete c->st;
+        G.nstreams.fetch_sub(1);
+    }
+    for (auto& sd : c->side) {
+        if (sd.h_in) (void)hipHostFree(sd.h_in);
+        if (sd.h_out) (void)hipHostFree(sd.h_out);
+        if (sd.d_arena) (void)hipFree(sd.d_arena);
+        if (sd.done) (void)hipEventDestroy(sd.done);
+    }
+    delete c;
+    D.co = nullptr;
+}
+
+int coalescer_reserve(GateCoalescer::Side& sd, size_t gates)
+{
+    if (gates <= sd.cap) return IYK_OK;
+    const size_t n1 = (size_t)G.p.n + 1;
+    size_t cap = sd.cap ? sd.cap : 256;
+    while (cap < gates) cap *= 2;
+    u32 *hi = nullptr, *ho = nullptr, *da = nullptr;
+    HIP_TRY(hipHostMalloc((void**)&hi, cap * 3 * n1 * sizeof(u32), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&ho, cap * n1 * sizeof(u32), hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&da, cap * 4 * n1 * sizeof(u32)));
+    if (sd.h_in) {   // the side is filling: keep what has been parked so far
+        std::memcpy(hi, sd.h_in, sd.ops.size() * 3 * n1 * sizeof(u32));
+        (void)hipHostFree(sd.h_in);
+        (void)hipHostFree(sd.h_out);
+        (void)hipFree(sd.d_arena);
+    }
+    sd.h_in = hi, sd.h_out = ho, sd.d_arena = da, sd.cap = cap;
+    return IYK_OK;
+}
+
+// send the filling side to the GPU if the other side is free to become the next filling one; no-op otherwise (retried at a later poll)
+int coalescer_flush(GateCoalescer* c)
+{
+    GateCoalescer::Side& sd = c->side[c->open];
+    GateCoalescer::Side& other = c->side[c->open ^ 1];
+    if (sd.ops.empty() || other.flying || other.undelivered) return IYK_OK;
+    const size_t n1 = (size_t)G.p.n + 1, count = sd.ops.size();
+    sd.out.resize(count);
+    for (size_t g = 0; g < count; ++g) sd.out[g] = (int32_t)(3 * sd.cap + g);
+    HIP_TRY(hipMemcpyAsync(sd.d_arena, sd.h_in, count * 3 * n1 * sizeof(u32), hipMemcpyHostToDevice, c->st->s));
+    int rc = iyk_hip_gate_batch(c->st, sd.d_arena, 4 * sd.cap, count, sd.ops.data(), sd.in0.data(), sd.in1.data(), sd.in2.data(),
+                                sd.out.data());
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(sd.h_out, sd.d_arena + 3 * sd.cap * n1, count * n1 * sizeof(u32), hipMemcpyDeviceToHost, c->st->s));
+    HIP_TRY(hipEventRecord(sd.done, c->st->s));
+    sd.flying = true;
+    sd.undelivered = count;
+    other.gen = c->next_gen++;
+    other.ops.clear(), other.in0.clear(), other.in1.clear(), other.in2.clear();
+    c->open ^= 1;
+    return IYK_OK;
+}
+
+// 1: the stream's parked gate has finished and `out` is written; 0: not yet; < 0: error.  `block`: wait for it.
+int coalescer_poll(iyk_hip_stream* st, bool block)
+{
+    GateCoalescer* c = G.devs[st->gpu].co;
+    if (!c || !st->co_gen) return 1;
+    int rc = set_device(st->gpu);
+    if (rc) return rc;
+    st->co_polls++;
+    for (;;) {
+        GateCoalescer::Side* sd = nullptr;
+        for (auto& x : c->side)
+            if (x.gen == st->co_gen) sd = &x;
+        if (!sd) return fail(IYK_ERR_STATE, "coalesced gate lost its batch");
+        if (!sd->flying) {   // still filling
+            if (block || st->co_polls >= 2 || sd->ops.size() >= c->max_gates)
+                if ((rc = coalescer_flush(c))) return rc;
+            if (!sd->flying) {
+                if (!block) return 0;
+                // blocked behind the other side: drain it (its owners pick their results up from the buffer later)
+                GateCoalescer::Side& other = c->side[(sd == &c->side[0]) ? 1 : 0];
+                if (other.flying) {
+                    HIP_TRY(hipEventSynchronize(other.done));
+                    other.flying = false;
+                }
+                if (other.undelivered) return fail(IYK_ERR_STATE, "iyk_hip_stream_sync on a coalesced gate while other streams have not collected "
+                                                                  "their finished gates: poll them first");
+                continue;
+            }
+        }
+        if (block) {
+            HIP_TRY(hipEventSynchronize(sd->done));
+        }
+        else {
+            hipError_t e = hipEventQuery(sd->done);
+            if (e == hipErrorNotReady) return 0;
+            if (e != hipSuccess) return fail(IYK_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
+        }
+        const size_t n1 = (size_t)G.p.n + 1;
+        std::memcpy(st->gate_out_user, sd->h_out + (size_t)st->co_index * n1, n1 * sizeof(u32));
+        st->gate_out_user = nullptr;
+        st->co_gen = 0;
+        if (--sd->undelivered == 0) sd->flying = false;   // the side may fill again
+        return 1;
+    }
+}
+
+}  // namespace
+
 int iyk_hip_gate_host(iyk_hip_stream* st, int op, const uint32_t* in0, const uint32_t* in1,
                       const uint32_t* in2, uint32_t* out)
 {
@@ -1370,13 +1693,38 @@ int iyk_hip_gate_host(iyk_hip_stream* st, int op, const uint32_t* in0, const uin
     int rc = set_device(st->gpu);
     if (rc) return rc;
     const size_t n1 = G.p.n + 1;
-    if (!st->d_scratch) HIP_TRY(hipMalloc((void**)&st->d_scratch, 4 * n1 * sizeof(u32)));
-    if (!st->h_gate) HIP_TRY(hipHostMalloc((void**)&st->h_gate, 4 * n1 * sizeof(u32), hipHostMallocDefault));
-    if (st->gate_out_user) {   // the previous gate of this stream was never polled to completion: finish it first
+    if (st->co_gen) {   // the previous gate of this stream was never polled to completion: finish it first
+        if ((rc = coalescer_poll(st, true)) < 0) return rc;
+    }
+    if (st->gate_out_user) {
         HIP_TRY(hipStreamSynchronize(st->s));
         deliver_gate_result(st);
     }
     const uint32_t* ins[3] = {in0, in1, in2};
+    if (G.coalesce) {
+        const int need = op == IYK_OP_MUX ? 3 : (op == IYK_OP_NOT || op == IYK_OP_COPY) ? 1 : (op >= 0 && op <= IYK_OP_XNOR) ? 2 : 0;
+        if (op < 0 || op >= IYK_OP__COUNT) return fail(IYK_ERR_INVALID, "unknown gate op");
+        for (int k = 0; k < need; ++k)
+            if (!ins[k]) return fail(IYK_ERR_INVALID, "gate needs more input ciphertexts");
+        GateCoalescer* c = nullptr;
+        if ((rc = coalescer_get(st->gpu, &c))) return rc;
+        GateCoalescer::Side& sd = c->side[c->open];
+        const size_t g = sd.ops.size();
+        if ((rc = coalescer_reserve(sd, g + 1))) return rc;
+        for (int k = 0; k < need; ++k) std::memcpy(sd.h_in + (3 * g + k) * n1, ins[k], n1 * sizeof(u32));
+        sd.ops.push_back(op);
+        sd.in0.push_back(need > 0 ? (int32_t)(3 * g) : -1);
+        sd.in1.push_back(need > 1 ? (int32_t)(3 * g + 1) : -1);
+        sd.in2.push_back(need > 2 ? (int32_t)(3 * g + 2) : -1);
+        st->co_gen = sd.gen;
+        st->co_index = (uint32_t)g;
+        st->co_polls = 0;
+        st->gate_out_user = out;
+        if (sd.ops.size() >= c->max_gates) return coalescer_flush(c);
+        return IYK_OK;
+    }
+    if (!st->d_scratch) HIP_TRY(hipMalloc((void**)&st->d_scratch, 4 * n1 * sizeof(u32)));
+    if (!st->h_gate) HIP_TRY(hipHostMalloc((void**)&st->h_gate, 4 * n1 * sizeof(u32), hipHostMallocDefault));
     int32_t idx[3] = {-1, -1, -1};
     int last = 0;
     for (int k = 0; k < 3; ++k)

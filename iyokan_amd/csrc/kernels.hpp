@@ -1000,26 +1000,38 @@ static constexpr int KS2_CHUNK = 128;  // digits staged per gate at a time
 // sum and a move per sum on each path not taken (1.4 k v_mov per i).
 __device__ __forceinline__ void add_in_place(u32& a, u32 b) { asm volatile("v_add_u32 %0, %0, %1" : "+v"(a) : "v"(b)); }
 
-template <int T, int NC, int KSW_G>
+// SHARED (round 5, narrow frontiers): the four waves of a workgroup take the SAME KSW_G gates and a quarter of the slice's i range
+// each, add their partial sums into one LDS accumulator (ds_add_u32) and the workgroup subtracts ONCE per word from the arena.  A
+// narrow level is sliced 64 .. 256 times over i so that the chip has work, and what it then costs is the integer atomics of the
+// slices' partial sums (~1 us per gate, profiles/r04_ks_small_ab.txt): with the waves of a workgroup on different gates every
+// wave pays its own 637 atomics per gate; shared, the same number of waves does the same additions with a quarter of the atomics.
+// The launch passes the WORKGROUP's i range; a wave walks i_per_slice / 4 of it (>= 1: at most 256 slices of 1024).
+template <int T, int NC, int KSW_G, bool SHARED = false>
 __global__ __launch_bounds__(256, (KSW_G > 10 ? 2 : KSW_G > 6 ? 3 : 4)) void keyswitch_wave_kernel(
     const u32* __restrict__ rot, const KsJob* __restrict__ jobs, int njobs, const u32* __restrict__ ksk,
-    u32* __restrict__ arena, u32 n, u32 stride, u32 i_per_slice)
+    u32* __restrict__ arena, u32 n, u32 stride, u32 i_per_slice_wg)
 {
     constexpr u32 dbits = 2u * T;
     constexpr u32 prec = 1u << (32 - (1 + dbits));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_ks[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     unsigned short* s_dig = reinterpret_cast<unsigned short*>(smem_ks) + wave * (KSW_G * KS2_CHUNK);  // [KSW_G][chunk], this wave's
-    const int gbase = blockIdx.x * (4 * KSW_G);
-    const u32 i0 = blockIdx.y * i_per_slice;
+    u32* s_sum = reinterpret_cast<u32*>(smem_ks + (size_t)4 * KSW_G * KS2_CHUNK * 2);                  // SHARED: [KSW_G][NC * 128]
+    const int gbase = SHARED ? blockIdx.x * KSW_G : blockIdx.x * (4 * KSW_G);
+    const u32 i_per_slice = SHARED ? i_per_slice_wg >> 2 : i_per_slice_wg;
+    const u32 i0 = blockIdx.y * i_per_slice_wg + (SHARED ? (u32)wave * i_per_slice : 0u);
     const u32 chunk = i_per_slice < (u32)KS2_CHUNK ? i_per_slice : (u32)KS2_CHUNK;
     const u32 block_words = 3 * stride;
     const u32 wl = 2u * (u32)lane;
+    if (SHARED) {
+        for (u32 e = threadIdx.x; e < (u32)KSW_G * NC * 128u; e += 256u) s_sum[e] = 0u;
+        __syncthreads();
+    }
 
-    // lane k < KSW_G holds the job of this wave's gate k = workgroup gate 4 k + wave
+    // lane k < KSW_G holds the job of this wave's gate k = workgroup gate 4 k + wave (SHARED: workgroup gate k, for every wave)
     KsJob mine;
     {
-        const int gi = gbase + 4 * (lane < KSW_G ? lane : 0) + wave;
+        const int gi = SHARED ? gbase + (lane < KSW_G ? lane : 0) : gbase + 4 * (lane < KSW_G ? lane : 0) + wave;
         mine = jobs[gi < njobs ? gi : njobs - 1];
         if (gi >= njobs) mine.out = -1;
     }
@@ -1089,6 +1101,24 @@ __global__ __launch_bounds__(256, (KSW_G > 10 ? 2 : KSW_G > 6 ? 3 : 4)) void key
                 }
             }
         }
+    }
+    if (SHARED) {
+#pragma unroll
+        for (int g = 0; g < KSW_G; ++g)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                u32* q = s_sum + g * (NC * 128) + c * 128 + wl;
+                __hip_atomic_fetch_add(q, acc[g][c][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(q + 1, acc[g][c][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        __syncthreads();
+        for (int g = 0; g < KSW_G; ++g) {   // the workgroup's ONE subtraction per word
+            const int out_slot = __builtin_amdgcn_readlane(mine.out, g);
+            if (out_slot < 0) continue;
+            u32* out = arena + (size_t)out_slot * ((size_t)n + 1);
+            for (u32 w = threadIdx.x; w <= n; w += 256u) atomicSub(out + w, s_sum[g * (NC * 128) + w]);
+        }
+        return;
     }
 #pragma unroll
     for (int g = 0; g < KSW_G; ++g) {

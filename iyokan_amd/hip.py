@@ -34,7 +34,7 @@ EXPORTS = [
     "iyk_hip_stream_gpu", "iyk_hip_arena_upload_slots", "iyk_hip_arena_download_slots", "iyk_hip_arena_copy",
     "iyk_hip_arena_sync_slots", "iyk_hip_trlwe_alloc", "iyk_hip_trlwe_free", "iyk_hip_trlwe_upload",
     "iyk_hip_trlwe_download", "iyk_hip_rotation_round", "iyk_hip_arena_sync_slots_multi", "iyk_hip_peer_access",
-    "iyk_hip_build_id", "iyk_hip_host_alloc", "iyk_hip_host_free",
+    "iyk_hip_build_id", "iyk_hip_host_alloc", "iyk_hip_host_free", "iyk_hip_init_profile",
 ]
 
 
@@ -185,9 +185,24 @@ def level_cost_table(gpu=0):
 
 
 def calibrate(gpu=0):
-    """~0.15 s self-calibration of the cost table (and of the dispatch's narrow-frontier threshold) on GPU `gpu`."""
+    """~0.15 s self-calibration of the cost table (and of the dispatch's narrow-frontier threshold) on GPU `gpu`;
+    gpu = -1: every GPU concurrently (returns GPU 0's table)."""
     _check(lib().iyk_hip_calibrate(int(gpu)), "iyk_hip_calibrate")
-    return level_cost_table(gpu)
+    return level_cost_table(max(int(gpu), 0))
+
+
+def init_profile():
+    """Steps of the last iyk_hip_init as [(name, gpu or None, milliseconds)]: alloc g, pin, enqueue g, wait g."""
+    L = lib()
+    L.iyk_hip_init_profile.restype = ctypes.c_char_p
+    out = []
+    for item in L.iyk_hip_init_profile().decode().split(";"):
+        parts = item.split()
+        if len(parts) == 3:
+            out.append((parts[0], int(parts[1]), float(parts[2])))
+        elif len(parts) == 2:
+            out.append((parts[0], None, float(parts[1])))
+    return out
 
 
 def rotation_round(gpu=0):

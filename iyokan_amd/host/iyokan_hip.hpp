@@ -56,11 +56,10 @@ inline void initializeHIP(const iyk_params& p, const uint32_t* bk_torus, const u
                           const int* device_ids = nullptr)
 {
     hipCheck(iyk_hip_init(numGPU, device_ids, &p, bk_torus, ksk), "iyk_hip_init");
-    // 0.15 s per GPU: the level-cost table planFrontiers cuts frontiers by becomes the one THIS GPU measures (the dispatch's
+    // 0.15 s, all GPUs at once: the level-cost table planFrontiers cuts frontiers by becomes the one THIS GPU measures (the dispatch's
     // narrow-frontier threshold follows it); IYK_HOST_CALIBRATE=0 keeps the library's compiled-in MI355X figures.
     const char* cal = std::getenv("IYK_HOST_CALIBRATE");
-    if (!cal || cal[0] != '0')
-        for (int g = 0; g < numGPU; ++g) hipCheck(iyk_hip_calibrate(g), "iyk_hip_calibrate");
+    if (!cal || cal[0] != '0') hipCheck(iyk_hip_calibrate(-1), "iyk_hip_calibrate");   // every GPU, concurrently
 }
 inline void cleanupHIP() { hipCheck(iyk_hip_cleanup(), "iyk_hip_cleanup"); }
 
