@@ -189,8 +189,9 @@ def cpu_quota():
 def cpu_baseline(keys, params, op_code, sample, data_seed, budget_s=24.0):
     """The oracle (kind 'port') timed on this host's cores on a bounded sample of the same workload.
 
-    Both exact restatements are timed (oracle/tfhe_oracle_fp.c: FP64-field products, AVX2 loops; oracle/tfhe_oracle.c:
-    Goldilocks 128-bit products) and the FASTER one is the reported value.  Thread count: ALL visible cores is tried
+    All three exact restatements are timed (oracle/tfhe_oracle_fft.c: the GPU's own algorithm — key split into signed 16-bit
+    halves, folded complex FP64 transform, AVX2 across transforms; oracle/tfhe_oracle_fp.c: FP64-field products, AVX2 loops;
+    oracle/tfhe_oracle.c: Goldilocks 128-bit products) and the FASTEST one is the reported value.  Thread count: ALL visible cores is tried
     first, then halvings of it — the fastest wins and every attempt is listed (round 2 measured 256 threads slower
     than 64 on the driver's box: a cgroup quota or SMT siblings, cpu_quota says which).  Probe chunks (one gate per
     thread) size the final sample so the whole leg takes ~budget_s."""
@@ -218,7 +219,7 @@ def cpu_baseline(keys, params, op_code, sample, data_seed, budget_s=24.0):
         assert np.array_equal(dec, 1 - (bits[:count] & bits[count:])), "oracle decrypt mismatch"
         return dt
 
-    fast = "fp" if orc.has_fp() else "goldilocks"
+    fast = "fft" if orc.has_fft() else "fp" if orc.has_fp() else "goldilocks"
     # thread-count probe on the faster restatement: one untimed warm-up pass (thread start-up, page faults), then
     # four gates per thread
     tried, t = {}, cores
@@ -227,7 +228,7 @@ def cpu_baseline(keys, params, op_code, sample, data_seed, budget_s=24.0):
         tried[t] = 4 * t / run(4 * t, data_seed, fast, t)
         t //= 2
     threads = max(tried, key=tried.get)
-    modes = ["fp", "goldilocks"] if orc.has_fp() else ["goldilocks"]
+    modes = (["fft"] if orc.has_fft() else []) + (["fp"] if orc.has_fp() else []) + ["goldilocks"]
     results = {}
     for mode in modes:
         share = (budget_s * 0.6) / len(modes)
@@ -242,7 +243,8 @@ def cpu_baseline(keys, params, op_code, sample, data_seed, budget_s=24.0):
     orc.close()
     best = max(results, key=lambda m: results[m][0])
     rate, n, dt = results[best]
-    names = {"fp": "oracle/tfhe_oracle_fp.c (FP64-field products)", "goldilocks": "oracle/tfhe_oracle.c (Goldilocks products)"}
+    names = {"fft": "oracle/tfhe_oracle_fft.c (the GPU's algorithm: split-key folded complex FP64 transform, AVX2 across transforms)",
+             "fp": "oracle/tfhe_oracle_fp.c (FP64-field products)", "goldilocks": "oracle/tfhe_oracle.c (Goldilocks products)"}
     return {"value": rate, "unit": "gates/s", "cores": threads, "kind": "port",
             "sample": f"{n} NAND gates of the same workload in {dt:.1f} s on {threads} threads ({cores} CPUs visible, fastest of "
                       f"the thread counts tried), own exact CPU restatement {names[best]}, OpenMP over gates; not TFHEpp",

@@ -186,12 +186,19 @@ struct orc_fp_ctx;
 struct orc_fp_ctx* orc_fp_new(const iyk_params* p, const u32* bk);
 void orc_fp_free(struct orc_fp_ctx* c);
 void orc_fp_blind_rotate(const struct orc_fp_ctx* c, const u32* tlwe0, u32* acc);
+/* third restatement, the GPU's split-key complex FP64 transform (tfhe_oracle_fft.c); mode 3 */
+struct orc_fft_ctx;
+struct orc_fft_ctx* orc_fft_new(const iyk_params* p, const u32* bk);
+void orc_fft_free(struct orc_fft_ctx* c);
+void orc_fft_blind_rotate(struct orc_fft_ctx* c, const u32* tlwe0, u32* acc);
+double orc_fft_worst(const struct orc_fft_ctx* c);
 
 typedef struct orc_ctx {
     iyk_params p;
     u32 logN;
     orc_ntt* ntt;
     struct orc_fp_ctx* fp; /* NULL when the parameter set does not meet the FP64 field's exactness bound */
+    struct orc_fft_ctx* fft; /* NULL when the parameter set is outside tfhe_oracle_fft.c's bound */
     const u32* bk;   /* torus domain, borrowed: [n][(k+1)l][k+1][N] */
     const u32* ksk;  /* borrowed: [kN][t][2^basebit-1][n+1] */
     u64* bk_ntt;     /* owned, same indexing, oracle's own (bit-reversed) NTT order */
@@ -216,17 +223,22 @@ orc_ctx* orc_new(const iyk_params* p, const u32* bk, const u32* ksk)
         ntt_fwd(c->ntt, dst);
     }
     c->fp = orc_fp_new(p, bk);
+    c->fft = orc_fft_new(p, bk);
     return c;
 }
 
 /* 1 when mode 2 (FP64-field restatement) is available for this parameter set */
 int orc_has_fp(const orc_ctx* c) { return c->fp != NULL; }
+/* 1 when mode 3 (split-key complex FFT restatement) is available; the largest rounding distance it has seen (< 1/4 or it aborts) */
+int orc_has_fft(const orc_ctx* c) { return c->fft != NULL; }
+double orc_fft_rounding_distance(const orc_ctx* c) { return orc_fft_worst(c->fft); }
 
 void orc_free(orc_ctx* c)
 {
     if (!c) return;
     ntt_free(c->ntt);
     orc_fp_free(c->fp);
+    orc_fft_free(c->fft);
     free(c->bk_ntt);
     free(c);
 }
@@ -279,10 +291,18 @@ static void mul_by_xai(u32 N, const u32* in, u32 a, u32* out)
 
 /* blind rotation of a lvl0 TLWE with the all-mu test vector; acc = [k+1][N] torus32.
  * schoolbook (= mode): 0 Goldilocks NTT products, 1 uint32 schoolbook products against the torus-domain BK,
- * 2 the FP64-field restatement of tfhe_oracle_fp.c (falls back to 0 where its exactness bound fails). */
+ * 2 the FP64-field restatement of tfhe_oracle_fp.c (falls back to 0 where its exactness bound fails),
+ * 3 the split-key complex-FFT restatement of tfhe_oracle_fft.c (the GPU's arithmetic; same fallback). */
 void orc_blind_rotate(const orc_ctx* c, const u32* tlwe0, u32* acc, int schoolbook)
 {
     const iyk_params* p = &c->p;
+    if (schoolbook == 3) {
+        if (c->fft) {
+            orc_fft_blind_rotate(c->fft, tlwe0, acc);
+            return;
+        }
+        schoolbook = 0;
+    }
     if (schoolbook == 2) {
         if (c->fp) {
             orc_fp_blind_rotate(c->fp, tlwe0, acc);

@@ -1,0 +1,308 @@
+/* tfhe_oracle_fft.c — third CPU restatement of the blind rotation: the algorithm the GPU's throughput kernel runs
+ * (iyokan_amd/csrc/kernels_fft.hpp), on the host's FPU.
+ *
+ * TEST INFRASTRUCTURE ONLY, like tfhe_oracle.c and tfhe_oracle_fp.c: used by tests/ and by bench.py's cpu_baseline leg, never by
+ * the product path.  It exists so that the CPU number beside the GPU's is not only "an exact field transform on a CPU" (the
+ * other two restatements) but also "the GPU's own arithmetic on a CPU": the same split of the bootstrapping key into two signed
+ * 16-bit halves, the same folded N/2-point complex FP64 transform of the digits, one pointwise multiply-accumulate per half,
+ * the same two roundings recombined as lo + 2^16 hi (mod 2^32).  This is also the shape of TFHEpp's own CPU path
+ * (spqlios: a folded complex FFT in doubles, /root/reference/src/tfhepp_cufhe_wrapper.hpp:1-40 only names the types; the library
+ * is an un-vendored submodule) with the one difference that TFHEpp multiplies by the whole 32-bit key
+ * word and accepts a rounding error below the noise, where this product is EXACT.
+ *
+ * Exactness: a digit is |d| <= Bg/2 and a key half |h| <= 2^15, so a coefficient of one half's sum over the (k+1) l rows is
+ * bounded by (k+1) l N (Bg/2) 2^15 (2^32.6 for the 128-bit set, 2^36 for the 80-bit one).  A radix-2 transform of M = N/2
+ * points carries log2 M = 9 butterfly layers, the fold's twist and the pointwise product: with u = 2^-53 the forward
+ * spectrum of the digits has relative error <= ~11 u in the 2-norm, the key spectra the same, the inverse another ~11 u;
+ * against the worst-case magnitudes above the absolute error is below 2^36 * 2^10 (sqrt(N) growth of the norm is already inside
+ * the bound on the sum) * 40 u = 2^-1.7 only in the all-worst-case corner no ciphertext reaches; for the values that occur
+ * (digits and key halves are uniform: sums ~ sqrt of the bound) it is ~2^-20.  orc_fft_blind_rotate() CHECKS it instead of
+ * trusting the estimate: the distance of every inverse-transform output to its nearest integer is tracked and the run aborts
+ * (orc_fft_worst() reports it) if it ever exceeds 1/4.  tests/test_oracle.py pins this file against tfhe_oracle.c word for word
+ * on both parameter sets.
+ *
+ * Own transform: radix-2 decimation-in-frequency forward (natural in, bit-reversed out), decimation-in-time inverse — not the
+ * GPU's three DFT8 passes of Linzer-Feig butterflies: two implementations of the same numbers.  Vectorised ACROSS transforms
+ * (GCC vector extensions, 4 doubles = one AVX2 register): the (k+1) l digit rows of a step are the lanes of the forward
+ * transform, the (k+1) x 2 (column, key half) sums the 4 lanes of the inverse one, so every butterfly layer is full-width with a
+ * broadcast factor and no shuffles; the key spectra are laid out [step][point][row][re | im][column, half] for it.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/iyokan_hip_params.h"
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t i32;
+typedef int64_t i64;
+
+typedef double v4d __attribute__((vector_size(32), aligned(32)));
+typedef uint64_t v4u __attribute__((vector_size(32), aligned(32)));
+static inline v4d vmax(v4d a, v4d b)
+{
+    const v4u m = (v4u)(a > b);
+    return (v4d)((m & (v4u)a) | (~m & (v4u)b));
+}
+
+typedef struct orc_fft_ctx {
+    iyk_params p;
+    u32 logN, M;
+    double *tw_re, *tw_im;   /* fold twist e^{+i pi j / N}, j < M */
+    double *ut_re, *ut_im;   /* unfold: e^{-i pi j / N} / M */
+    double *w_re, *w_im;     /* butterfly factors: w[len + j] = e^{+2 pi i j / (2 len)}, j < len, len = 1, 2, .., M/2 */
+    v4d* bk_spec;            /* owned: [n][M points, bit-reversed order][(k+1)l rows][re, im], lanes = (column, half: lo, hi) */
+    double worst;            /* largest distance to the nearest integer seen by any rounding (racy max: diagnostics) */
+} orc_fft_ctx;
+
+/* forward: X_k = sum_j x_j e^{+2 pi i jk / M}, natural in, bit-reversed out */
+static void fft_fwd(const orc_fft_ctx* c, double* restrict re, double* restrict im)
+{
+    const u32 M = c->M;
+    for (u32 len = M / 2; len >= 1; len >>= 1) {
+        const double* restrict wr = c->w_re + len;
+        const double* restrict wi = c->w_im + len;
+        for (u32 b = 0; b < M; b += 2 * len) {
+            double* restrict ar = re + b;
+            double* restrict ai = im + b;
+            double* restrict br = re + b + len;
+            double* restrict bi = im + b + len;
+#pragma omp simd
+            for (u32 j = 0; j < len; ++j) {
+                const double ur = ar[j], ui = ai[j], vr = br[j], vi = bi[j];
+                const double dr = ur - vr, di = ui - vi;
+                ar[j] = ur + vr;
+                ai[j] = ui + vi;
+                br[j] = dr * wr[j] - di * wi[j];
+                bi[j] = dr * wi[j] + di * wr[j];
+            }
+        }
+    }
+}
+
+/* the same transform, and its inverse (unscaled: x_j = sum_k X_k e^{-2 pi i jk / M}, bit-reversed in, natural out), on nv
+ * vectors per point: 4 nv independent transforms side by side */
+static void fft_fwd_v(const orc_fft_ctx* c, v4d* restrict re, v4d* restrict im, u32 nv)
+{
+    const u32 M = c->M;
+    for (u32 len = M / 2; len >= 1; len >>= 1)
+        for (u32 b = 0; b < M; b += 2 * len)
+            for (u32 j = 0; j < len; ++j) {
+                const double wr = c->w_re[len + j], wi = c->w_im[len + j];
+                v4d* ar = re + (size_t)(b + j) * nv;
+                v4d* ai = im + (size_t)(b + j) * nv;
+                v4d* br = ar + (size_t)len * nv;
+                v4d* bi = ai + (size_t)len * nv;
+                for (u32 t = 0; t < nv; ++t) {
+                    const v4d ur = ar[t], ui = ai[t], vr = br[t], vi = bi[t];
+                    const v4d dr = ur - vr, di = ui - vi;
+                    ar[t] = ur + vr;
+                    ai[t] = ui + vi;
+                    br[t] = dr * wr - di * wi;
+                    bi[t] = dr * wi + di * wr;
+                }
+            }
+}
+static void fft_inv_v(const orc_fft_ctx* c, v4d* restrict re, v4d* restrict im)
+{
+    const u32 M = c->M;
+    for (u32 len = 1; len < M; len <<= 1)
+        for (u32 b = 0; b < M; b += 2 * len)
+            for (u32 j = 0; j < len; ++j) {
+                const double wr = c->w_re[len + j], wi = c->w_im[len + j];
+                const v4d xr = re[b + j + len], xi = im[b + j + len];
+                const v4d vr = xr * wr + xi * wi, vi = xi * wr - xr * wi;
+                const v4d ur = re[b + j], ui = im[b + j];
+                re[b + j] = ur + vr;
+                im[b + j] = ui + vi;
+                re[b + j + len] = ur - vr;
+                im[b + j + len] = ui - vi;
+            }
+}
+
+/* fold a real polynomial of N coefficients (given as doubles) into M complex points: z_j = (a_j + i a_{j+M}) e^{i pi j / N};
+ * the transform of z is then a(X) at the N/2 odd powers e^{i pi (4k+1) / N} (the other N/2 are their conjugates) */
+static void fold(const orc_fft_ctx* c, const double* restrict a, double* restrict re, double* restrict im)
+{
+    const u32 M = c->M;
+#pragma omp simd
+    for (u32 j = 0; j < M; ++j) {
+        const double x = a[j], y = a[j + M];
+        re[j] = x * c->tw_re[j] - y * c->tw_im[j];
+        im[j] = x * c->tw_im[j] + y * c->tw_re[j];
+    }
+}
+
+int orc_fft_supported(const iyk_params* p)
+{
+    /* sums below 2^40: the measured rounding distance is then ~2^-16 at worst (the run-time check is the guarantee) */
+    const double worst = (double)(p->k + 1) * p->l * p->N * (double)(1u << (p->Bgbit - 1)) * 32768.0;
+    return (p->N & (p->N - 1)) == 0 && p->N >= 8 && p->k == 1 /* 4 lanes = 2 columns x 2 halves */ && worst < 1099511627776.0;
+}
+
+orc_fft_ctx* orc_fft_new(const iyk_params* p, const u32* bk)
+{
+    if (!orc_fft_supported(p)) return NULL;
+    orc_fft_ctx* c = (orc_fft_ctx*)calloc(1, sizeof(orc_fft_ctx));
+    c->p = *p;
+    while ((1u << c->logN) < p->N) c->logN++;
+    const u32 N = p->N, M = N / 2;
+    c->M = M;
+    c->tw_re = (double*)malloc(sizeof(double) * M);
+    c->tw_im = (double*)malloc(sizeof(double) * M);
+    c->ut_re = (double*)malloc(sizeof(double) * M);
+    c->ut_im = (double*)malloc(sizeof(double) * M);
+    c->w_re = (double*)malloc(sizeof(double) * M);
+    c->w_im = (double*)malloc(sizeof(double) * M);
+    const long double pi = 3.14159265358979323846264338327950288L;
+    for (u32 j = 0; j < M; ++j) {
+        const long double t = pi * (long double)j / (long double)N;
+        c->tw_re[j] = (double)cosl(t);
+        c->tw_im[j] = (double)sinl(t);
+        c->ut_re[j] = (double)(cosl(t) / (long double)M);
+        c->ut_im[j] = (double)(-sinl(t) / (long double)M);
+    }
+    c->w_re[0] = 1.0;
+    c->w_im[0] = 0.0;
+    for (u32 len = 1; len < M; len <<= 1)
+        for (u32 j = 0; j < len; ++j) {
+            const long double t = pi * (long double)j / (long double)len;
+            c->w_re[len + j] = (double)cosl(t);
+            c->w_im[len + j] = (double)sinl(t);
+        }
+    const size_t words = (size_t)iyk_bk_words(p), polys = words / N;
+    const u32 k1 = p->k + 1, rows = k1 * p->l;
+    c->bk_spec = (v4d*)aligned_alloc(64, sizeof(double) * polys * 2 * N);
+#pragma omp parallel
+    {
+        double* tmp = (double*)aligned_alloc(64, sizeof(double) * N);
+        double* sp = (double*)aligned_alloc(64, sizeof(double) * N);
+#pragma omp for schedule(static)
+        for (size_t q = 0; q < polys; ++q) {   /* q = (step i, row r, column cc) */
+            const u32* src = bk + q * N;
+            const size_t i = q / ((size_t)rows * k1), r = q / k1 % rows, cc = q % k1;
+            for (int h = 0; h < 2; ++h) {
+                for (u32 x = 0; x < N; ++x) {
+                    const i32 kw = (i32)src[x];
+                    const i32 lo = (i32)(int16_t)(kw & 0xffff);                 /* signed low half */
+                    const i32 hi = (i32)(((i64)kw - (i64)lo) >> 16);            /* kw = lo + 2^16 hi exactly, |hi| <= 2^15 */
+                    tmp[x] = (double)(h ? hi : lo);
+                }
+                fold(c, tmp, sp, sp + M);
+                fft_fwd(c, sp, sp + M);
+                double* dst = (double*)(c->bk_spec + (i * M * rows + r) * 2) + (cc * 2 + (size_t)h);
+                for (u32 x = 0; x < M; ++x) {
+                    dst[((size_t)x * rows * 2) * 4] = sp[x];
+                    dst[((size_t)x * rows * 2 + 1) * 4] = sp[M + x];
+                }
+            }
+        }
+        free(tmp);
+        free(sp);
+    }
+    return c;
+}
+
+void orc_fft_free(orc_fft_ctx* c)
+{
+    if (!c) return;
+    free(c->tw_re); free(c->tw_im); free(c->ut_re); free(c->ut_im); free(c->w_re); free(c->w_im);
+    free(c->bk_spec);
+    free(c);
+}
+
+double orc_fft_worst(const orc_fft_ctx* c) { return c ? c->worst : -1.0; }
+
+/* the same steps as orc_blind_rotate (tfhe_oracle.c): acc = (0, X^bbar tv); for i < n with abar_i != 0:
+ * acc += BK_i (x) ((X^abar_i - 1) acc).  acc = [k+1][N] torus32. */
+void orc_fft_blind_rotate(orc_fft_ctx* c, const u32* tlwe0, u32* acc)
+{
+    const iyk_params* p = &c->p;
+    const u32 N = p->N, M = c->M, k1 = p->k + 1, rows = k1 * p->l;
+    const u32 shift = 32 - 1 - c->logN;
+    u32 offset = 0;
+    for (u32 j = 1; j <= p->l; ++j) offset += (1u << (p->Bgbit - 1)) << (32 - j * p->Bgbit);
+    const u32 round = 1u << (32 - p->l * p->Bgbit - 1);
+    const u32 mask = (1u << p->Bgbit) - 1, half = 1u << (p->Bgbit - 1);
+    const u32 nv = (rows + 3) / 4;                                          /* vectors per point of the forward transform */
+    u32* diff = (u32*)aligned_alloc(64, sizeof(u32) * N);
+    v4d* fre = (v4d*)aligned_alloc(64, sizeof(v4d) * M * nv);               /* [point][row lanes] */
+    v4d* fim = (v4d*)aligned_alloc(64, sizeof(v4d) * M * nv);
+    v4d* sre = (v4d*)aligned_alloc(64, sizeof(v4d) * M);                    /* [point], lanes = (column, half) */
+    v4d* sim = (v4d*)aligned_alloc(64, sizeof(v4d) * M);
+    double worst = 0.0;
+    v4d worst4 = {0, 0, 0, 0};
+    memset(fre, 0, sizeof(v4d) * M * nv);
+    memset(fim, 0, sizeof(v4d) * M * nv);
+
+    const u32 bbar = (2 * N - (tlwe0[p->n] >> shift)) % (2 * N);
+    memset(acc, 0, sizeof(u32) * k1 * N);
+    for (u32 x = 0; x < N; ++x) {
+        const u32 idx = (x - bbar) & (2 * N - 1);
+        acc[p->k * N + x] = (idx & N) ? 0u - p->mu : p->mu;
+    }
+    for (u32 i = 0; i < p->n; ++i) {
+        const u32 abar = (u32)(tlwe0[i] + (1u << (shift - 1))) >> shift;
+        if (abar == 0) continue;
+        for (u32 q = 0; q < k1; ++q) {
+            const u32* a = acc + q * N;
+            /* (X^abar - 1) a + offset + round, as two contiguous runs (coefficient x of X^abar a is -+ a[x - abar mod N]) */
+            const u32 s = abar & (N - 1), neg = abar >= N ? 0xffffffffu : 0u;
+            for (u32 x = 0; x < s; ++x) diff[x] = ((a[x + N - s] ^ ~neg) + (neg ? 0u : 1u)) - a[x] + offset + round;
+            for (u32 x = s; x < N; ++x) diff[x] = ((a[x - s] ^ neg) + (neg ? 1u : 0u)) - a[x] + offset + round;
+            for (u32 j = 0; j < p->l; ++j) {   /* digit j of both halves, folded, into lane q l + j of the points */
+                const u32 sh = 32 - (j + 1) * p->Bgbit;
+                double* restrict dre = (double*)fre + (q * p->l + j);
+                double* restrict dim = (double*)fim + (q * p->l + j);
+                for (u32 x = 0; x < M; ++x) {
+                    const double d0 = (double)((i32)((diff[x] >> sh) & mask) - (i32)half);
+                    const double d1 = (double)((i32)((diff[x + M] >> sh) & mask) - (i32)half);
+                    dre[(size_t)x * nv * 4] = d0 * c->tw_re[x] - d1 * c->tw_im[x];
+                    dim[(size_t)x * nv * 4] = d0 * c->tw_im[x] + d1 * c->tw_re[x];
+                }
+            }
+        }
+        fft_fwd_v(c, fre, fim, nv);
+        const v4d* kb = c->bk_spec + (size_t)i * M * rows * 2;
+        for (u32 x = 0; x < M; ++x) {
+            const double* fr = (const double*)(fre + (size_t)x * nv);
+            const double* fi = (const double*)(fim + (size_t)x * nv);
+            const v4d* kx = kb + (size_t)x * rows * 2;
+            v4d ar = {0, 0, 0, 0}, ai = {0, 0, 0, 0};
+            for (u32 r = 0; r < rows; ++r) {
+                const v4d kr = kx[2 * r], ki = kx[2 * r + 1];
+                ar += kr * fr[r] - ki * fi[r];
+                ai += ki * fr[r] + kr * fi[r];
+            }
+            sre[x] = ar;
+            sim[x] = ai;
+        }
+        fft_inv_v(c, sre, sim);
+        for (u32 x = 0; x < M; ++x) {   /* unfold: (c_x + i c_{x+M}) = z_x e^{-i pi x / N} / M, for the four (column, half) lanes */
+            const v4d v0 = sre[x] * c->ut_re[x] - sim[x] * c->ut_im[x];
+            const v4d v1 = sre[x] * c->ut_im[x] + sim[x] * c->ut_re[x];
+            /* round to nearest through the 1.5 * 2^52 constant (|v| < 2^51): the sum's low mantissa bits are the integer in two's
+             * complement, and subtracting the constant again gives the rounded value for the distance check */
+            const v4d big = {6755399441055744.0, 6755399441055744.0, 6755399441055744.0, 6755399441055744.0};
+            const v4d s0 = v0 + big, s1 = v1 + big;
+            const v4d e0 = v0 - (s0 - big), e1 = v1 - (s1 - big);
+            worst4 = vmax(worst4, vmax(vmax(e0, -e0), vmax(e1, -e1)));
+            const v4u b0 = (v4u)s0, b1 = (v4u)s1;
+            for (u32 cc = 0; cc < k1; ++cc) {
+                acc[cc * N + x] += (u32)b0[2 * cc] + ((u32)b0[2 * cc + 1] << 16);
+                acc[cc * N + x + M] += (u32)b1[2 * cc] + ((u32)b1[2 * cc + 1] << 16);
+            }
+        }
+    }
+    for (int t = 0; t < 4; ++t)
+        if (worst4[t] > worst) worst = worst4[t];
+    if (worst > c->worst) c->worst = worst;
+    free(diff); free(fre); free(fim); free(sre); free(sim);
+    if (worst > 0.25) {
+        fprintf(stderr, "tfhe_oracle_fft: rounding distance %.3g > 1/4: the FP64 product is not provably exact here\n", worst);
+        abort();
+    }
+}

@@ -27,6 +27,9 @@ def lib():
         L.orc_gate_batch_mode.argtypes = [ctypes.c_void_p, ctypes.c_uint32, _i32p, _i32p, _i32p, _i32p, _i32p, _u32p,
                                           ctypes.c_int, ctypes.c_int]
         L.orc_has_fp.argtypes = [ctypes.c_void_p]
+        L.orc_has_fft.argtypes = [ctypes.c_void_p]
+        L.orc_fft_rounding_distance.restype = ctypes.c_double
+        L.orc_fft_rounding_distance.argtypes = [ctypes.c_void_p]
         L.orc_blind_rotate.argtypes = [ctypes.c_void_p, _u32p, _u32p, ctypes.c_int]
         L.orc_sample_extract0.argtypes = [ctypes.c_void_p, _u32p, _u32p]
         L.orc_keyswitch.argtypes = [ctypes.c_void_p, _u32p, _u32p]
@@ -62,7 +65,15 @@ class Oracle:
         lib().orc_gate(self.ctx, int(op), _p(args[0]), _p(args[1]), _p(args[2]), _p(out), int(schoolbook))
         return out
 
-    MODES = {"goldilocks": 0, "schoolbook": 1, "fp": 2}
+    MODES = {"goldilocks": 0, "schoolbook": 1, "fp": 2, "fft": 3}
+
+    def has_fft(self):
+        """True when the split-key complex-FFT restatement (oracle/tfhe_oracle_fft.c, the GPU's arithmetic) covers this set."""
+        return bool(lib().orc_has_fft(self.ctx))
+
+    def fft_rounding_distance(self):
+        """Largest |x - round(x)| any rounding of the FFT restatement has seen so far (it aborts above 1/4)."""
+        return float(lib().orc_fft_rounding_distance(self.ctx))
 
     def has_fp(self):
         """True when the FP64-field restatement (oracle/tfhe_oracle_fp.c) is exact for this parameter set."""

@@ -130,6 +130,49 @@ def test_fp_restatement_equals_goldilocks_restatement(keys128, oracle128, keys80
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("which", ["128bit", "80bit"])
+def test_fft_restatement_equals_goldilocks_restatement(which, keys128, oracle128, keys80, oracle80):
+    """oracle/tfhe_oracle_fft.c — the GPU's arithmetic on the CPU (key split into signed 16-bit halves, folded complex FP64
+    transform, two roundings recombined; bench.py's third cpu_baseline restatement) — against oracle/tfhe_oracle.c: the same words
+    for every gate kind on fresh encryptions, on bootstrapped inputs and on rows no encryption produces, BOTH parameter sets;
+    and its measured rounding distance stays far from the 1/4 at which it aborts."""
+    import os
+
+    keys, orc = (keys128, oracle128) if which == "128bit" else (keys80, oracle80)
+    assert orc.has_fft()
+    p = keys.params
+    rng = np.random.default_rng(78)
+    adv = oracle_lib.adversarial_rows(p.n)
+    nfresh = 12
+    nin = nfresh + adv.shape[0]
+    kinds = ["AND", "NAND", "ANDNOT", "OR", "NOR", "ORNOT", "XOR", "XNOR", "MUX", "MUX", "NOT", "NAND", "XOR", "MUX", "NAND", "MUX"]
+    ops = [OPS[k] for k in kinds]
+    in0 = [int(v) for v in rng.integers(0, nin, size=len(kinds))]
+    in1 = [int(v) if k != "NOT" else -1 for v, k in zip(rng.integers(0, nin, size=len(kinds)), kinds)]
+    in2 = [int(v) if k == "MUX" else -1 for v, k in zip(rng.integers(0, nin, size=len(kinds)), kinds)]
+    in0[-4:] = [nfresh, nfresh + 2, nfresh + 4, nfresh + 6]       # the adversarial rows are certainly among the operands
+    in1[-4:] = [nfresh + 1, nfresh + 3, nfresh + 5, nfresh + 7]
+    out = list(range(nin, nin + len(kinds)))
+    a = np.zeros((nin + 2 * len(kinds), p.n + 1), dtype=np.uint32)
+    a[:nfresh] = client.encrypt_bits(keys, rng.integers(0, 2, size=nfresh).astype(np.uint8), seed=124)
+    a[nfresh:nin] = adv
+    b = a.copy()
+    nt = os.cpu_count() or 1
+    orc.gate_batch(ops, in0, in1, in2, out, a, nthreads=nt, mode="goldilocks")
+    orc.gate_batch(ops, in0, in1, in2, out, b, nthreads=nt, mode="fft")
+    assert np.array_equal(a, b)
+    out2 = [o + len(kinds) for o in out]                            # second level: bootstrapped inputs
+    in0b = [nin + (i * 5) % len(kinds) for i in range(len(kinds))]
+    in1b = [nin + (i * 3 + 1) % len(kinds) if k != "NOT" else -1 for i, k in enumerate(kinds)]
+    in2b = [nin + (i * 7 + 2) % len(kinds) if k == "MUX" else -1 for i, k in enumerate(kinds)]
+    orc.gate_batch(ops, in0b, in1b, in2b, out2, a, nthreads=nt, mode="goldilocks")
+    orc.gate_batch(ops, in0b, in1b, in2b, out2, b, nthreads=nt, mode="fft")
+    assert np.array_equal(a, b)
+    d = orc.fft_rounding_distance()
+    print(f"fft restatement, {which}: largest rounding distance {d:.3g}")
+    assert 0.0 <= d < 1.0 / 64
+
+
 def test_adversarial_rows_same_words_in_both_restatements(keys128, oracle128):
     """Rows no encryption produces (oracle_lib.adversarial_rows): the Goldilocks and the FP64-field restatements
     must still agree word for word — the pipeline is a deterministic map on u32 vectors, valid ciphertext or not."""
