@@ -735,9 +735,21 @@ __global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_ker
     fft::cplx* s_h = s_t2 + 64;                                                              // Consts256: inv[2][11][64], fwd[2][11][64]
     static_assert(BR_FFT_T1_BYTES % 8192 == 0, "diff16_doubled needs 8 KB aligned accumulators");
 
+#ifndef IYK_LATFFT_FWD_LF
     if (NFULL)
         for (int e = threadIdx.x; e < 8 * 64; e += M::THREADS) s_t1[e] = C.t1[e >> 6][e & 63];
     if (NFULL && threadIdx.x < 64) s_t2[threadIdx.x] = C.t2t[threadIdx.x >> 3][threadIdx.x & 7];
+#else
+    // A/B only (-DIYK_LATFFT_FWD_LF): the whole rows' forward transform as in the throughput kernel (three twisted DFT8 passes of
+    // Linzer-Feig butterflies, 40 instructions fewer), its constants in place of the T1 table.  Not faster here — 2.565 against
+    // 2.578 ms at 16 rotations, 2.585 against 2.557 at 64, 2.75 against 2.69 at 256 (profiles/r05_latfft_ab.txt): this kernel
+    // waits on exchanges and barriers, not on its instruction count
+    fft::Lf* s_lf3 = reinterpret_cast<fft::Lf*>(s_t1);   // [which][lane'']
+    fft::Lf* s_lf2 = s_lf3 + 4 * 64;                      // [which][k0]
+    (void)s_t2;
+    if (NFULL && threadIdx.x < 4 * 64) s_lf3[threadIdx.x] = C.lf3[threadIdx.x >> 6][threadIdx.x & 63];
+    if (NFULL && threadIdx.x < 4 * 8) s_lf2[threadIdx.x] = C.lf2[threadIdx.x >> 3][threadIdx.x & 7];
+#endif
     {
         const fft::cplx* src = &Cp->h.inv[0][0][0];
         for (int e = threadIdx.x; e < (int)(sizeof(fft::Consts256) / sizeof(fft::cplx)); e += M::THREADS) s_h[e] = src[e];
@@ -771,6 +783,10 @@ __global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_ker
     asm volatile("" : "+v"(in_pos));
     fft::Twist U = C.u;
     asm volatile("" : "+s"(U.c1), "+s"(U.s1), "+s"(U.c2), "+s"(U.s2), "+s"(U.c3), "+s"(U.s3));
+#ifdef IYK_LATFFT_FWD_LF
+    fft::LfU LU = C.lu;
+    asm volatile("" : "+s"(LU.t2), "+s"(LU.c2), "+s"(LU.t1), "+s"(LU.c1), "+s"(LU.t1w), "+s"(LU.c1w));
+#endif
     const fft::Keys keys(bk_fft, bk_bytes, lane0);
     fft::cplx kb[XF][4];                             // this wave's key values of one step: frequency block q = wave
     // One row of a step's key values (4 x 1 KiB per wave).  The eight waves of the CU share ONE texture path (16 cycles per
@@ -815,9 +831,15 @@ __global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_ker
             fft::diff16_doubled<G>(lane, ab, acc2 + cF * 2 * NTT_N, u);
             fft::digits8<G>(lvl, u, a);
             IYK_FTRACE(1);
+#ifndef IYK_LATFFT_FWD_LF
             fft_forward_a(lane, a, U, s_t1 + lane, xbf);
             load_row(i, XF - 1);
             fft_forward_b(lane, a, s_t2 + (lane & 7), xbf, [] {});
+#else
+            fft_forward_lf_a(lane, a, LU, xbf);
+            load_row(i, XF - 1);
+            fft_forward_lf_b(lane, a, s_lf2, s_lf3, xbf, [] {});
+#endif
 #pragma unroll
             for (int q = 0; q < 8; ++q) xbf[q * 64 + lane] = a[q];
             IYK_FTRACE(2);

@@ -10,6 +10,11 @@ PARAMS=80bit bash tools/profile_round.sh ${T}_80bit > gpurun_out/${T}_80bit_prof
 for net in cahp-ruby cahp-system mux-ram; do timeout 600 python tools/bench_netlist.py --net $net --plan asap 2>/dev/null | tail -1; done > gpurun_out/${T}_bench_netlist.txt
 for net in cahp-ruby cahp-system mux-ram; do timeout 600 python tools/bench_netlist.py --net $net 2>/dev/null | tail -1; done > gpurun_out/${T}_bench_netlist_balanced.txt
 cat gpurun_out/${T}_bench_netlist.txt | cut -c1-200
+# what the narrow levels of a real netlist cost, kernel by kernel (one clock of the CAHP core = 41 levels)
+rm -rf /tmp/prof_nl && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_nl -o nl -- python tools/bench_netlist.py --net cahp-ruby --clocks 2 > /tmp/nl.log 2>&1
+python tools/rocprof_summary.py $(find /tmp/prof_nl -name "*.db" | head -1) > gpurun_out/${T}_netlist_kernel_trace.txt 2>&1
+# inputs of tools/scale_model.py (calibrated cost tables of both parameter sets, key-switch and fixed per-level costs)
+timeout 600 python tools/scale_model.py --measure gpurun_out/${T}_model_inputs.json 2>&1 | tail -1 | cut -c1-300
 python -c "
 import json
 for t in ('${T}','${T}_80bit'):

@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Model-predicted 1 / 2 / 4 / 8-GPU table for BASELINE.json's configs #2 - #5, from a CALIBRATED level-cost table
+("so the driver's first real SCALE record has something to be checked against").
+
+No GPU needed: the inputs are numbers a 1-GPU box measured (tools/gpu_round.sh writes them to gpurun_out/<tag>_model_inputs.json
+with --measure, see below) and the netlists under tests/golden/.  Everything the table assumes is written into the output.
+
+  flat configs (#2: 65 536 NANDs, 128-bit set; #5: the same on the 80-bit set), bench.py --gpus N, "strong" line:
+      a rank gets G / N gates:  t(N) = rot(G / N) + ks_per_gate * G / N + host_ms      value(N) = G / t(N)
+      rot(r) = the library's dispatch priced by the calibrated table (iyokan_amd/frontier.make_level_cost: full rounds of the
+      wave-per-rotation kernel + passes of the workgroup-per-rotation one); no data-path collective.
+      "weak" leg (G gates on every rank): value = N * G / t(1).
+  netlists (#3: mux-ram-8-16-16, #4: the CAHP system), tools/bench_netlist.py --gpus N, seconds per clock:
+      plan = FrontierPlan(netlist, N, cost) — the plan the executor would run;  per level
+      t = rot(rotations of the busiest rank) + ks_small(gates of that rank) + level_fixed_ms + (N > 1) * exchange(level bytes)
+      exchange = exch_lat_us + bytes / exch_GBps: ONE in-place all_gather of the level's output ciphertexts over RCCL / xGMI.
+      exch_* are ASSUMPTIONS (no multi-GPU box has run this yet): 40 us, 45 GB/s (a third of one xGMI link's ~153 GB/s).
+
+  python tools/scale_model.py --inputs gpurun_out/r05_model_inputs.json --out profiles/r05_scale_model.json
+  python tools/scale_model.py --measure gpurun_out/r05_model_inputs.json      (on a GPU box: calibrates both parameter sets)
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+G_FLAT = 65536
+WORLDS = (1, 2, 4, 8)
+
+
+def measure(path):
+    """On a GPU box: the calibrated cost table, the key switch's per-gate cost on wide and on narrow batches, and the fixed cost
+    of a level (events, staging copy, launch gaps) for both parameter sets."""
+    import numpy as np
+    import torch
+
+    from iyokan_amd import client, hip
+    from iyokan_amd.params import OPS, params_80bit, params_128bit
+
+    out = {}
+    for name, mk in (("128bit", params_128bit), ("80bit", params_80bit)):
+        p = mk()
+        keys = client.keygen(p, seed=1)
+        hip.initialize(keys, device_ids=(0,))
+        table = hip.calibrate(0)
+        dev = torch.device("cuda", 0)
+        rec = {"cost_table": table, "ks_ms": {}, "step_ms": {}, "rot_ms": {}}
+        import time
+
+        for g in (16, 64, 256, 1024, 4096, 65536):
+            t = torch.zeros((3 * g, p.n + 1), dtype=torch.int32, device=dev)
+            bits = np.random.default_rng(7).integers(0, 2, size=2 * g).astype(np.uint8)
+            t[: 2 * g] = torch.from_numpy(client.encrypt_bits(keys, bits, seed=3).view(np.int32)).to(dev)
+            arena = hip.Arena.from_torch(t, 0)
+            st = hip.Stream(0)
+            idx = np.arange(g, dtype=np.int32)
+            args = (np.full(g, OPS["NAND"], dtype=np.int32), idx, idx + g, np.full(g, -1, dtype=np.int32), idx + 2 * g)
+            best = None
+            for rep in range(5):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                st.gate_batch(arena, *args)
+                st.sync()
+                dt = (time.perf_counter() - t0) * 1e3
+                br, ks = st.last_batch_timing()
+                if rep and (best is None or dt < best[0]):
+                    best = (dt, br, ks)
+            rec["step_ms"][str(g)], rec["rot_ms"][str(g)], rec["ks_ms"][str(g)] = best
+            st.destroy()
+        hip.cleanup()
+        out[name] = rec
+    out["device"] = torch.cuda.get_device_name(0)
+    out["build_id"] = hip.build_id()
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps({k: v if not isinstance(v, dict) else "..." for k, v in out.items()}))
+
+
+def interp(points, x):
+    """Piecewise-linear through measured (size -> ms) points; linear in the size beyond the last one."""
+    xs = sorted(int(k) for k in points)
+    ys = [points[str(k)] for k in xs]
+    if x <= xs[0]:
+        return ys[0]
+    for (x0, y0), (x1, y1) in zip(zip(xs, ys), zip(xs[1:], ys[1:])):
+        if x <= x1:
+            return y0 + (y1 - y0) * (x - x0) / (x1 - x0)
+    return ys[-1] * x / xs[-1]
+
+
+def model(inputs, exch_lat_us, exch_gbps):
+    from iyokan_amd import netlist as N
+    from iyokan_amd.frontier import BINARY, FrontierPlan, level_rotations, make_level_cost
+    from iyokan_amd.params import params_128bit
+    from netlist_util import gold
+
+    import bench_netlist
+
+    res = {"assumptions": {
+        "exchange_latency_us": exch_lat_us, "exchange_GBps": exch_gbps,
+        "exchange": "one in-place all_gather of a level's output ciphertexts per level at N > 1 (RCCL over xGMI); ASSUMED figures, "
+                    "no multi-GPU run exists yet",
+        "flat": "t(N) = rot(G/N) + ks(G/N) + host, rot from the calibrated table, ks and host from the 1-GPU measurements in `inputs`",
+        "netlist": "per level: rot(busiest rank) + ks(its gates) + level_fixed + exchange; plan = FrontierPlan(netlist, N, calibrated cost)",
+    }, "inputs": inputs, "configs": {}}
+
+    for cfg, name in (("2_flat_nand_128bit", "128bit"), ("5_flat_nand_80bit", "80bit")):
+        rec = inputs[name]
+        cost = make_level_cost(rec["cost_table"])
+        host1 = rec["step_ms"][str(G_FLAT)] - rec["rot_ms"][str(G_FLAT)] - rec["ks_ms"][str(G_FLAT)]
+        rows = {}
+        for w in WORLDS:
+            g = G_FLAT // w
+            t = cost(g) + interp(rec["ks_ms"], g) + max(host1, 0.0)
+            t1 = cost(G_FLAT) + interp(rec["ks_ms"], G_FLAT) + max(host1, 0.0)
+            rows[str(w)] = {"strong_gates_per_s": G_FLAT / t * 1e3, "strong_ms_per_step": t,
+                            "weak_gates_per_s": w * G_FLAT / t1 * 1e3, "rot_ms": cost(g), "ks_ms": interp(rec["ks_ms"], g)}
+        res["configs"][cfg] = {"metric": "gates/s, 65 536 NAND gates per step", "measured_1gpu_ms_per_step": rec["step_ms"][str(G_FLAT)],
+                               "by_gpus": rows}
+
+    rec = inputs["128bit"]
+    cost = make_level_cost(rec["cost_table"])
+    p = params_128bit()
+    ct_bytes = (p.n + 1) * 4
+    # fixed cost of a level = what a narrow step costs beyond its two kernels (staging copy, events, launch gaps)
+    fixed = min(rec["step_ms"][k] - rec["rot_ms"][k] - rec["ks_ms"][k] for k in ("16", "64", "256"))
+    for cfg, net in (("3_mux_ram_8_16_16", "mux-ram"), ("4_cahp_system", "cahp-system")):
+        fname, kind, _pkt = bench_netlist.NETS[net]
+        if kind == "blueprint":
+            from iyokan_amd.system import load_blueprint
+
+            nl = load_blueprint(gold(fname)).nl
+        else:
+            nl = (N.load_iyokanl1_json if kind == "l1" else N.load_yosys_json)(gold(fname))
+        rows = {}
+        for w in WORLDS:
+            plan = FrontierPlan(nl, w, balance=True, cost=cost)
+            levels = [L["boot"] for L in plan.levels]
+            rots = level_rotations(nl, levels, w)
+            t_rot = t_ks = t_fix = t_ex = 0.0
+            for lv, r in zip(levels, rots):
+                gates = sum(1 for i in lv if nl.kinds[i] == "MUX" or nl.kinds[i] in BINARY)
+                mine = -(-gates // w)
+                if r:
+                    t_rot += cost(r)
+                    t_ks += interp(rec["ks_ms"], mine)
+                    t_fix += max(fixed, 0.0)
+                if w > 1 and gates:
+                    t_ex += exch_lat_us / 1e3 + gates * ct_bytes / (exch_gbps * 1e9) * 1e3
+            total = t_rot + t_ks + t_fix + t_ex
+            rows[str(w)] = {"s_per_clock": total / 1e3, "rot_ms": t_rot, "ks_ms": t_ks, "level_fixed_ms": t_fix, "exchange_ms": t_ex,
+                            "levels": len(levels), "rotations_per_clock": nl.rotations()}
+        res["configs"][cfg] = {"metric": "seconds per clock (tools/bench_netlist.py)", "level_fixed_ms_each": fixed, "by_gpus": rows}
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--measure", default=None, help="GPU box: write the model's inputs to this file")
+    ap.add_argument("--inputs", default=os.path.join(ROOT, "gpurun_out", "r05_model_inputs.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_scale_model.json"))
+    ap.add_argument("--exch-lat-us", type=float, default=40.0)
+    ap.add_argument("--exch-gbps", type=float, default=45.0)
+    args = ap.parse_args()
+    if args.measure:
+        measure(args.measure)
+        return
+    with open(args.inputs) as f:
+        inputs = json.load(f)
+    res = model(inputs, args.exch_lat_us, args.exch_gbps)
+    with open(args.out, "w") as f:
+        json.dump(res, f, indent=1)
+    for cfg, rec in res["configs"].items():
+        print(cfg, {w: round(r.get("strong_gates_per_s") or r["s_per_clock"], 4) for w, r in rec["by_gpus"].items()})
+
+
+if __name__ == "__main__":
+    main()
