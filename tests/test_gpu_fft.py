@@ -30,7 +30,7 @@ def _run_batch(hip, host, ops, in0, in1, in2, out):
 def test_fft_kernel_all_kinds_and_adversarial_rows(which, kernel, request, monkeypatch):
     """All gate kinds on fresh encryptions + the rows no encryption produces, 700 gates (partial workgroups, idle waves),
     with IYK_HIP_DEBUG=1: the kernel's own record of max |z - rint(z)| must stay below 2^-10 — a trip-wire far inside what DESIGN.md §2b
-    PROVES for any key and digits (< 2^-9.0 / 2^-5.6 at the 128- / 80-bit set, against the ½ that rint needs); real keys give ~2^-20."""
+    PROVES for any key and digits (< 2^-8.5 / 2^-5.1 at the 128- / 80-bit set, against the ½ that rint needs); real keys give ~2^-20."""
     import oracle_lib
     from iyokan_amd import hip
 

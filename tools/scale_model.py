@@ -6,9 +6,10 @@ No GPU needed: the inputs are numbers a 1-GPU box measured (tools/gpu_round.sh w
 with --measure, see below) and the netlists under tests/golden/.  Everything the table assumes is written into the output.
 
   flat configs (#2: 65 536 NANDs, 128-bit set; #5: the same on the 80-bit set), bench.py --gpus N, "strong" line:
-      a rank gets G / N gates:  t(N) = rot(G / N) + ks_per_gate * G / N + host_ms      value(N) = G / t(N)
-      rot(r) = the library's dispatch priced by the calibrated table (iyokan_amd/frontier.make_level_cost: full rounds of the
-      wave-per-rotation kernel + passes of the workgroup-per-rotation one); no data-path collective.
+      a rank gets G / N gates:  t(N) = rot(G / N) + ks(G / N) + host_ms      value(N) = G / t(N)
+      rot, ks = interpolated between the launches measured on one GPU at 4 096 and 65 536 gates (the calibrated table's
+      round_ms x rounds is listed beside it: one round alone is 3-9 % slower than a round inside a long launch);
+      no data-path collective.
       "weak" leg (G gates on every rank): value = N * G / t(1).
   netlists (#3: mux-ram-8-16-16, #4: the CAHP system), tools/bench_netlist.py --gpus N, seconds per clock:
       plan = FrontierPlan(netlist, N, cost) — the plan the executor would run;  per level
@@ -106,7 +107,7 @@ def model(inputs, exch_lat_us, exch_gbps):
         "exchange_latency_us": exch_lat_us, "exchange_GBps": exch_gbps,
         "exchange": "one in-place all_gather of a level's output ciphertexts per level at N > 1 (RCCL over xGMI); ASSUMED figures, "
                     "no multi-GPU run exists yet",
-        "flat": "t(N) = rot(G/N) + ks(G/N) + host, rot from the calibrated table, ks and host from the 1-GPU measurements in `inputs`",
+        "flat": "t(N) = rot(G/N) + ks(G/N) + host, all three from the 1-GPU measurements in `inputs` (linear interpolation between measured batch sizes)",
         "netlist": "per level: rot(busiest rank) + ks(its gates) + level_fixed + exchange; plan = FrontierPlan(netlist, N, calibrated cost)",
     }, "inputs": inputs, "configs": {}}
 
@@ -117,10 +118,13 @@ def model(inputs, exch_lat_us, exch_gbps):
         rows = {}
         for w in WORLDS:
             g = G_FLAT // w
-            t = cost(g) + interp(rec["ks_ms"], g) + max(host1, 0.0)
-            t1 = cost(G_FLAT) + interp(rec["ks_ms"], G_FLAT) + max(host1, 0.0)
+            # the rotation time of a multi-round launch is interpolated between MEASURED launches (a launch of many rounds runs its
+            # rounds ~3-9 % faster than round_ms, which is one round alone with its ramp and tail); the table's figure is listed beside it
+            t = interp(rec["rot_ms"], g) + interp(rec["ks_ms"], g) + max(host1, 0.0)
+            t1 = rec["rot_ms"][str(G_FLAT)] + rec["ks_ms"][str(G_FLAT)] + max(host1, 0.0)
             rows[str(w)] = {"strong_gates_per_s": G_FLAT / t * 1e3, "strong_ms_per_step": t,
-                            "weak_gates_per_s": w * G_FLAT / t1 * 1e3, "rot_ms": cost(g), "ks_ms": interp(rec["ks_ms"], g)}
+                            "weak_gates_per_s": w * G_FLAT / t1 * 1e3, "rot_ms": interp(rec["rot_ms"], g), "rot_ms_by_cost_table": cost(g),
+                            "ks_ms": interp(rec["ks_ms"], g)}
         res["configs"][cfg] = {"metric": "gates/s, 65 536 NAND gates per step", "measured_1gpu_ms_per_step": rec["step_ms"][str(G_FLAT)],
                                "by_gpus": rows}
 
