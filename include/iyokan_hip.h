@@ -214,7 +214,11 @@ int iyk_hip_gate_batch(iyk_hip_stream* st, uint32_t* d_arena, uint64_t arena_slo
  * once st's gate has come back and `out` is written.  Results are the same words either way; the reference's harness shape
  * (one host thread, processAllGates(net, 240)) reaches ~60 % of the batched flavour's rate instead of ~1 %
  * (profiles/r05_per_gate.txt).  Other work enqueued on `st` is not ordered against a parked gate: a stream used for
- * iyk_hip_gate_host should be used for nothing else until it has been seen idle (the reference's workers do exactly that). */
+ * iyk_hip_gate_host should be used for nothing else until it has been seen idle (the reference's workers do exactly that).
+ * `out` belongs to the library from the call until the stream is seen idle and may be written EARLIER than that poll (when
+ * another stream's iyk_hip_stream_sync has to drain the batch that holds this gate).  Threads: a stream is used by one host
+ * thread at a time; different streams — of the same GPU too — may be driven from different threads (the parked gates of a GPU
+ * are shared state behind one lock).  Destroying a stream with a parked gate completes the gate first. */
 int iyk_hip_gate_host(iyk_hip_stream* st, int op, const uint32_t* in0, const uint32_t* in1,
                       const uint32_t* in2, uint32_t* out);
 
@@ -273,7 +277,7 @@ int iyk_hip_ntt_path(void);
 
 /* Round 4: return value 2 = the default since — both rotation kernels (a wave per rotation for full rounds, a workgroup per
  * rotation for narrow frontiers) multiply through a 512-point COMPLEX FP64 FFT with every key word split into two signed
- * 16-bit halves (csrc/fft512.hpp): every inverse-transform output is provably within 2^-9.0 (128-bit set) / 2^-5.6 (80-bit
+ * 16-bit halves (csrc/fft512.hpp): every inverse-transform output is provably within 2^-8.5 (128-bit set) / 2^-5.1 (80-bit
  * set) of the exact integer sum for ANY key and digits, so rint() makes the product the exact schoolbook
  * one — the same ciphertext words as paths 1 and 0 — at two thirds of the instructions per CMUX step.  The field form of the
  * key stays resident beside the spectra (iyk_hip_resident_key_bytes) so that the field kernels can be forced per batch as a

@@ -5,7 +5,7 @@
 // needs 10 stages; a complex butterfly spends 8 on 2 COMPLEX points, the folded transform has 9 stages, and the radix-8
 // passes below make most twiddles trivial (+-1, +-i, (1 +- i)/sqrt 2): ~290 instead of ~1000 instructions per lane and
 // transform.  Exactness no longer comes from a field but from magnitudes: the key words are split into two SIGNED 16-bit
-// halves k = lo + 2^16 hi, both transformed once at init, and every rounded FFT product sum is provably within 2^-5.6 (80-bit set; 2^-9.0 at the 128-bit set) of an integer
+// halves k = lo + 2^16 hi, both transformed once at init, and every rounded FFT product sum is provably within 2^-5.1 (80-bit set; 2^-8.5 at the 128-bit set) of an integer
 // (proof and margins: DESIGN.md §2b; worst-case test: tests/test_gpu_fft.py), so rint() returns the exact integer sums
 // R_lo, R_hi and R = R_lo + 2^16 R_hi mod 2^32 is the schoolbook result — the same words as the Z_p and Goldilocks paths.
 //

@@ -139,6 +139,7 @@ double level_cost_ms(const iyk_level_cost& c, long rot)
 
 void coalescer_free(Device& D);
 int coalescer_poll(iyk_hip_stream* st, bool block);
+inline uint64_t co_gen_of(const iyk_hip_stream* st);
 
 struct Global {
     std::mutex mu;
@@ -411,16 +412,13 @@ template <int T, int NC, int GW>
 int launch_keyswitch_wave(iyk_hip_stream* st, u32* d_arena, const KsJob* d_jobs, int njobs)
 {
     const Device& D = G.devs[st->gpu];
-    static const int shared_max = [] {   // IYK_HIP_KS_SHARED_MAX: largest batch on the shared-gates form (0 = never; A/B and tests)
-        const char* e = std::getenv("IYK_HIP_KS_SHARED_MAX");
-        return e ? std::atoi(e) : 4096;
-    }();
+    // IYK_HIP_KS_SHARED_MAX: largest batch on the shared-gates form (0 = never); read per batch like IYK_HIP_KS_KERNEL (A/B, tests)
+    const char* smax = std::getenv("IYK_HIP_KS_SHARED_MAX");
+    const int shared_max = smax ? std::atoi(smax) : 4096;
     if (njobs <= shared_max) {
         // narrow frontier: a workgroup's four waves share GW gates and split the i range; a quarter of the atomics (kernels.hpp)
-        static const int min_wg = [] {   // IYK_HIP_KS_SHARED_WG: workgroups a launch is sliced up to (A/B: profiles/r05_ks_small_ab.txt)
-            const char* e = std::getenv("IYK_HIP_KS_SHARED_WG");
-            return e ? std::max(1, std::atoi(e)) : 512;
-        }();
+        const char* swg = std::getenv("IYK_HIP_KS_SHARED_WG");   // workgroups a launch is sliced up to (A/B: profiles/r05_ks_small_ab.txt)
+        const int min_wg = swg ? std::max(1, std::atoi(swg)) : 512;
         const int groups = (njobs + GW - 1) / GW;
         int slices = 1;
         while (slices < 256 && groups * slices < min_wg) slices *= 2;
@@ -1142,7 +1140,7 @@ int iyk_hip_stream_destroy(iyk_hip_stream* st)
     if (!st) return fail(IYK_ERR_INVALID, "null stream");
     int rc = set_device(st->gpu);
     if (rc) return rc;
-    if (st->co_gen && (rc = coalescer_poll(st, true)) < 0) return rc;   // a parked gate still owes its result to the caller
+    if (co_gen_of(st) && (rc = coalescer_poll(st, true)) < 0) return rc;   // a parked gate still owes its result to the caller
     HIP_TRY(hipStreamSynchronize(st->s));
     destroy_stream_resources(st);
     delete st;
@@ -1156,7 +1154,7 @@ int iyk_hip_stream_gpu(iyk_hip_stream* st) { return st ? st->gpu : fail(IYK_ERR_
 // the stream is idle: hand a finished iyk_hip_gate_host result from the pinned mirror to the caller's ciphertext
 static void deliver_gate_result(iyk_hip_stream* st)
 {
-    if (st->gate_out_user && !st->co_gen) {
+    if (st->gate_out_user && !co_gen_of(st)) {
         std::memcpy(st->gate_out_user, st->h_gate, ((size_t)G.p.n + 1) * sizeof(u32));
         st->gate_out_user = nullptr;
     }
@@ -1165,7 +1163,7 @@ static void deliver_gate_result(iyk_hip_stream* st)
 int iyk_hip_stream_query(iyk_hip_stream* st)
 {
     if (!st) return fail(IYK_ERR_INVALID, "null stream");
-    if (st->co_gen) {   // a gate of this stream travels in a coalesced batch (iyk_hip_gate_host): idle once that has come back
+    if (co_gen_of(st)) {   // a gate of this stream travels in a coalesced batch (iyk_hip_gate_host): idle once that has come back
         const int r = coalescer_poll(st, false);
         if (r <= 0) return r;
     }
@@ -1181,7 +1179,7 @@ int iyk_hip_stream_query(iyk_hip_stream* st)
 int iyk_hip_stream_sync(iyk_hip_stream* st)
 {
     if (!st) return fail(IYK_ERR_INVALID, "null stream");
-    if (st->co_gen) {
+    if (co_gen_of(st)) {
         const int r = coalescer_poll(st, true);
         if (r < 0) return r;
     }
@@ -1541,6 +1539,7 @@ struct GateCoalescer {
         u32* d_arena = nullptr;          // [4 cap][n + 1]: gate g reads slots 3 g .. 3 g + 2, writes slot 3 cap + g
         size_t cap = 0;
         std::vector<int32_t> ops, in0, in1, in2, out;
+        std::vector<iyk_hip_stream*> owner;   // stream whose gate sits at this index; nullptr once its result has been handed over
         uint64_t gen = 0;                // generation this side holds (0 = free)
         size_t undelivered = 0;          // results not yet picked up by their streams
         bool flying = false;
@@ -1550,6 +1549,10 @@ struct GateCoalescer {
     uint64_t next_gen = 1;
     size_t max_gates = 2048;
 };
+// One lock for all coalescers: parking, flushing and result hand-over touch state shared by every stream of a GPU, and the callers'
+// streams may live on different host threads (a stream itself is used by one thread at a time, like a hipStream_t's owner).
+std::mutex g_co_mu;
+inline uint64_t co_gen_of(const iyk_hip_stream* st) { return __atomic_load_n(&st->co_gen, __ATOMIC_ACQUIRE); }
 
 int coalescer_get(int gpu, GateCoalescer** out)
 {
@@ -1562,11 +1565,14 @@ int coalescer_get(int gpu, GateCoalescer** out)
             delete c;
             return rc;
         }
+        D.co = c;   // from here on coalescer_free() releases whatever exists
         for (auto& sd : c->side)
-            if (hipEventCreateWithFlags(&sd.done, hipEventDisableTiming) != hipSuccess) return fail(IYK_ERR_HIP, "hipEventCreate");
+            if (hipEventCreateWithFlags(&sd.done, hipEventDisableTiming) != hipSuccess) {
+                coalescer_free(D);
+                return fail(IYK_ERR_HIP, "hipEventCreate");
+            }
         if (const char* m = std::getenv("IYK_HIP_COALESCE_MAX")) c->max_gates = (size_t)std::max(1, std::atoi(m));
         c->side[0].gen = c->next_gen++;
-        D.co = c;
     }
     *out = D.co;
     return IYK_OK;
@@ -1631,14 +1637,32 @@ int coalescer_flush(GateCoalescer* c)
     sd.flying = true;
     sd.undelivered = count;
     other.gen = c->next_gen++;
-    other.ops.clear(), other.in0.clear(), other.in1.clear(), other.in2.clear();
+    other.ops.clear(), other.in0.clear(), other.in1.clear(), other.in2.clear(), other.owner.clear();
     c->open ^= 1;
     return IYK_OK;
+}
+
+// a finished side's results to the ciphertexts of every stream that has not collected its own yet (the streams then find
+// themselves idle at their next poll); the side is free to fill again
+void coalescer_deliver_all(GateCoalescer::Side& sd)
+{
+    const size_t n1 = (size_t)G.p.n + 1;
+    for (size_t g = 0; g < sd.owner.size(); ++g) {
+        iyk_hip_stream* o = sd.owner[g];
+        if (!o || o->co_gen != sd.gen) continue;
+        std::memcpy(o->gate_out_user, sd.h_out + g * n1, n1 * sizeof(u32));
+        o->gate_out_user = nullptr;
+        sd.owner[g] = nullptr;
+        __atomic_store_n(&o->co_gen, (uint64_t)0, __ATOMIC_RELEASE);
+    }
+    sd.undelivered = 0;
+    sd.flying = false;
 }
 
 // 1: the stream's parked gate has finished and `out` is written; 0: not yet; < 0: error.  `block`: wait for it.
 int coalescer_poll(iyk_hip_stream* st, bool block)
 {
+    std::lock_guard<std::mutex> lock(g_co_mu);
     GateCoalescer* c = G.devs[st->gpu].co;
     if (!c || !st->co_gen) return 1;
     int rc = set_device(st->gpu);
@@ -1654,14 +1678,11 @@ int coalescer_poll(iyk_hip_stream* st, bool block)
                 if ((rc = coalescer_flush(c))) return rc;
             if (!sd->flying) {
                 if (!block) return 0;
-                // blocked behind the other side: drain it (its owners pick their results up from the buffer later)
+                // blocked behind the other side: wait for it and hand its results to their owners right away (a ciphertext written
+                // before its stream is polled is within the contract: `out` belongs to the library until the stream is seen idle)
                 GateCoalescer::Side& other = c->side[(sd == &c->side[0]) ? 1 : 0];
-                if (other.flying) {
-                    HIP_TRY(hipEventSynchronize(other.done));
-                    other.flying = false;
-                }
-                if (other.undelivered) return fail(IYK_ERR_STATE, "iyk_hip_stream_sync on a coalesced gate while other streams have not collected "
-                                                                  "their finished gates: poll them first");
+                if (other.flying) HIP_TRY(hipEventSynchronize(other.done));
+                coalescer_deliver_all(other);
                 continue;
             }
         }
@@ -1676,7 +1697,8 @@ int coalescer_poll(iyk_hip_stream* st, bool block)
         const size_t n1 = (size_t)G.p.n + 1;
         std::memcpy(st->gate_out_user, sd->h_out + (size_t)st->co_index * n1, n1 * sizeof(u32));
         st->gate_out_user = nullptr;
-        st->co_gen = 0;
+        sd->owner[st->co_index] = nullptr;
+        __atomic_store_n(&st->co_gen, (uint64_t)0, __ATOMIC_RELEASE);
         if (--sd->undelivered == 0) sd->flying = false;   // the side may fill again
         return 1;
     }
@@ -1693,7 +1715,7 @@ int iyk_hip_gate_host(iyk_hip_stream* st, int op, const uint32_t* in0, const uin
     int rc = set_device(st->gpu);
     if (rc) return rc;
     const size_t n1 = G.p.n + 1;
-    if (st->co_gen) {   // the previous gate of this stream was never polled to completion: finish it first
+    if (co_gen_of(st)) {   // the previous gate of this stream was never polled to completion: finish it first
         if ((rc = coalescer_poll(st, true)) < 0) return rc;
     }
     if (st->gate_out_user) {
@@ -1706,6 +1728,7 @@ int iyk_hip_gate_host(iyk_hip_stream* st, int op, const uint32_t* in0, const uin
         if (op < 0 || op >= IYK_OP__COUNT) return fail(IYK_ERR_INVALID, "unknown gate op");
         for (int k = 0; k < need; ++k)
             if (!ins[k]) return fail(IYK_ERR_INVALID, "gate needs more input ciphertexts");
+        std::lock_guard<std::mutex> lock(g_co_mu);
         GateCoalescer* c = nullptr;
         if ((rc = coalescer_get(st->gpu, &c))) return rc;
         GateCoalescer::Side& sd = c->side[c->open];
@@ -1716,10 +1739,11 @@ int iyk_hip_gate_host(iyk_hip_stream* st, int op, const uint32_t* in0, const uin
         sd.in0.push_back(need > 0 ? (int32_t)(3 * g) : -1);
         sd.in1.push_back(need > 1 ? (int32_t)(3 * g + 1) : -1);
         sd.in2.push_back(need > 2 ? (int32_t)(3 * g + 2) : -1);
-        st->co_gen = sd.gen;
+        sd.owner.push_back(st);
         st->co_index = (uint32_t)g;
         st->co_polls = 0;
         st->gate_out_user = out;
+        __atomic_store_n(&st->co_gen, sd.gen, __ATOMIC_RELEASE);
         if (sd.ops.size() >= c->max_gates) return coalescer_flush(c);
         return IYK_OK;
     }

@@ -162,6 +162,116 @@ def test_host_pointer_gate_and_stream_query(gpu128, keys128, oracle128):
     st2.destroy()
 
 
+def _gate_host_async(hip, st, op, a, b, out):
+    """iyk_hip_gate_host without the wrapper's sync: the gate is parked (coalescing) or enqueued; `out` is written at idle."""
+    import ctypes
+
+    u32p = ctypes.POINTER(ctypes.c_uint32)
+    ptr = lambda x: x.ctypes.data_as(u32p) if x is not None else None
+    rc = hip.lib().iyk_hip_gate_host(st.h, OPS[op], ptr(a), ptr(b), None, ptr(out))
+    assert rc == 0, hip.lib().iyk_hip_last_error().decode()
+
+
+def test_coalesced_gates_survive_every_collection_order(gpu128, keys128, oracle128):
+    """iyk_hip_gate_host parks gates and sends them as one batch (include/iyokan_hip.h): whatever the callers do next must
+    hand every stream its own result.  Orders exercised: a stream SYNCHRONISED while the previous batch's results are still
+    uncollected by their streams (they are then delivered eagerly), a stream DESTROYED with its gate still parked, a stream
+    re-used for a second gate before it was ever polled, and collection in reverse order."""
+    hip, _ = gpu128
+    p = keys128.params
+    rng = np.random.default_rng(31)
+    cts = client.encrypt_bits(keys128, rng.integers(0, 2, size=16).astype(np.uint8), seed=131)
+    want = lambda op, i, j: oracle128.gate(OPS[op], cts[i], cts[j])
+    sts = [hip.Stream(0) for _ in range(6)]
+    outs = [np.zeros(p.n + 1, dtype=np.uint32) for _ in range(8)]
+    # first batch: streams 0 .. 2 park; two polls of stream 0 flush it; nobody collects
+    for k in range(3):
+        _gate_host_async(hip, sts[k], "NAND", cts[k], cts[k + 1], outs[k])
+    assert sts[0].query() is False
+    sts[0].query()
+    # second batch parks behind it: stream 3 and 4; stream 4 is synchronised while 0 .. 2 have not collected
+    _gate_host_async(hip, sts[3], "XOR", cts[3], cts[4], outs[3])
+    _gate_host_async(hip, sts[4], "OR", cts[4], cts[5], outs[4])
+    sts[4].sync()
+    assert np.array_equal(outs[4], want("OR", 4, 5))
+    for k in (2, 1, 0):   # reverse order; results were delivered when stream 4 drained the first batch
+        assert sts[k].query() is True
+        assert np.array_equal(outs[k], want("NAND", k, k + 1))
+    sts[3].sync()
+    assert np.array_equal(outs[3], want("XOR", 3, 4))
+    # a stream destroyed with its gate parked still writes its result; a stream given a second gate before any poll finishes the first
+    _gate_host_async(hip, sts[5], "AND", cts[5], cts[6], outs[5])
+    _gate_host_async(hip, sts[0], "NOR", cts[6], cts[7], outs[6])
+    _gate_host_async(hip, sts[0], "XNOR", cts[7], cts[8], outs[7])     # finishes NOR first
+    assert np.array_equal(outs[6], want("NOR", 6, 7))
+    sts[5].destroy()
+    assert np.array_equal(outs[5], want("AND", 5, 6))
+    sts[0].sync()
+    assert np.array_equal(outs[7], want("XNOR", 7, 8))
+    for s in sts[:5]:
+        s.destroy()
+
+
+def test_coalesced_gates_from_two_host_threads(gpu128, keys128, oracle128):
+    """Two host threads, 40 one-gate streams each, polling round-robin as upstream's workers do: the coalescer is shared by all
+    streams of a GPU and takes one lock; every result equals the oracle's."""
+    import threading
+
+    hip, _ = gpu128
+    p = keys128.params
+    rng = np.random.default_rng(32)
+    nct = 24
+    cts = client.encrypt_bits(keys128, rng.integers(0, 2, size=nct).astype(np.uint8), seed=132)
+    per_thread, gates_each = 40, 120
+    jobs = [[(["NAND", "XOR", "ANDNOT", "OR"][int(rng.integers(0, 4))], int(rng.integers(0, nct)), int(rng.integers(0, nct)))
+             for _ in range(gates_each)] for _ in range(2)]
+    results = [[None] * gates_each for _ in range(2)]
+    errors = []
+
+    def worker(t):
+        try:
+            sts = [hip.Stream(0) for _ in range(per_thread)]
+            bufs = [np.zeros(p.n + 1, dtype=np.uint32) for _ in range(per_thread)]
+            busy = [-1] * per_thread
+            nxt = done = 0
+            while done < gates_each:
+                for w in range(per_thread):
+                    if busy[w] < 0 and nxt < gates_each:
+                        op, i, j = jobs[t][nxt]
+                        _gate_host_async(hip, sts[w], op, cts[i], cts[j], bufs[w])
+                        busy[w] = nxt
+                        nxt += 1
+                    if busy[w] >= 0 and sts[w].query():
+                        results[t][busy[w]] = bufs[w].copy()
+                        busy[w] = -1
+                        done += 1
+            for s in sts:
+                s.destroy()
+        except Exception as e:   # noqa: BLE001 - reported below
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=300)
+    assert not errors, errors
+    for t in range(2):
+        for g in (0, 1, gates_each // 2, gates_each - 1):
+            op, i, j = jobs[t][g]
+            assert np.array_equal(results[t][g], oracle128.gate(OPS[op], cts[i], cts[j])), (t, g)
+    # all of them against a batch on the GPU (word for word; the oracle checked the sample above)
+    st = hip.Stream(0)
+    for t in range(2):
+        host = np.zeros((nct + gates_each, p.n + 1), dtype=np.uint32)
+        host[:nct] = cts
+        ops = [OPS[o] for o, _, _ in jobs[t]]
+        got = _run(hip, st, host, ops, [i for _, i, _ in jobs[t]], [j for _, _, j in jobs[t]], [-1] * gates_each,
+                   list(range(nct, nct + gates_each)))
+        assert np.array_equal(got[nct:], np.stack(results[t]))
+    st.destroy()
+
+
 def test_ragged_and_empty_batches(gpu128, keys128, oracle128):
     hip, st = gpu128
     p = keys128.params
@@ -325,6 +435,32 @@ def test_key_switch_kernels_agree(gpu128, keys128, oracle128, ng, monkeypatch):
     ref = host.copy()
     oracle128.gate_batch(ops[sample], in0[sample], in1[sample], in2[sample], out[sample], ref, nthreads=os.cpu_count() or 1)
     assert np.array_equal(results["1"][out[sample]], ref[out[sample]])
+
+
+@pytest.mark.parametrize("ng", [1, 15, 16, 17, 100, 1000, 4096, 4097])
+def test_key_switch_narrow_frontier_form_agrees(gpu128, keys128, ng, monkeypatch):
+    """Round 5: batches of up to 4 096 gates take keyswitch_wave_kernel's SHARED form (a workgroup's four waves on the same 16
+    gates, partial sums reduced in LDS before the atomics); IYK_HIP_KS_SHARED_MAX=0 forces round 4's form.  Integer additions
+    commute: the same words, at batch sizes around a workgroup's 16 gates and either side of the threshold (4 097 runs the wide
+    form in both settings: the control)."""
+    hip, st = gpu128
+    p = keys128.params
+    rng = np.random.default_rng(300 + ng)
+    nin = 32
+    bits = rng.integers(0, 2, size=nin).astype(np.uint8)
+    ops = rng.choice([OPS["NAND"], OPS["XOR"], OPS["MUX"], OPS["ORNOT"]], size=ng).astype(np.int32)
+    in0, in1, in2 = (rng.integers(0, nin, size=ng).astype(np.int32) for _ in range(3))
+    in2 = np.where(ops == OPS["MUX"], in2, -1).astype(np.int32)
+    out = np.arange(nin, nin + ng, dtype=np.int32)
+    host = np.zeros((nin + ng, p.n + 1), dtype=np.uint32)
+    host[:nin] = client.encrypt_bits(keys128, bits, seed=79)
+    shared = _run(hip, st, host, ops, in0, in1, in2, out)
+    monkeypatch.setenv("IYK_HIP_KS_SHARED_MAX", "0")
+    wide = _run(hip, st, host, ops, in0, in1, in2, out)
+    monkeypatch.setenv("IYK_HIP_KS_SHARED_MAX", "4096")
+    monkeypatch.setenv("IYK_HIP_KS_SHARED_WG", "64")           # another slicing of the i range: still the same sums
+    sliced = _run(hip, st, host, ops, in0, in1, in2, out)
+    assert np.array_equal(shared, wide) and np.array_equal(shared, sliced)
 
 
 def test_adversarial_rows_bit_exact_on_every_kernel(gpu128, keys128, oracle128, monkeypatch):
