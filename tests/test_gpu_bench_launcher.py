@@ -61,5 +61,8 @@ def test_scale_all_writes_lines_and_stops_at_the_first_refusal(tmp_path):
     r = subprocess.run(["bash", "tools/scale_all.sh", str(out)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     lines = [json.loads(x) for x in out.read_text().splitlines()]
     assert r.returncode == 3, (r.returncode, r.stderr[-1000:])
-    assert len(lines) == 2 and lines[0]["n_gpus"] == n and lines[0]["config"]["decrypt_check"] is True
-    assert lines[1]["refused"] == f"bench 128bit x{n + 1}" and lines[1]["status"] == 3
+    # line 0: the distinct-device tests (run where >= 2 GPUs are visible, a "skipped" record otherwise)
+    assert "distinct_device_tests" in lines[0] and (n >= 2 or lines[0]["distinct_device_tests"].startswith("skipped"))
+    assert n < 2 or lines[0]["status"] == 0, lines[0]
+    assert len(lines) == 3 and lines[1]["n_gpus"] == n and lines[1]["config"]["decrypt_check"] is True
+    assert lines[2]["refused"] == f"bench 128bit x{n + 1}" and lines[2]["status"] == 3

@@ -3,6 +3,7 @@
 #   bash tools/scale_all.sh [outfile]          # default gpurun_out/scale_all.jsonl
 #   - bench.py --gpus {1,2,4,8}: 65 536 flat NANDs, 128-bit set, then the 80-bit set (configs #2 / #5; strong line + weak leg)
 #   - tools/bench_netlist.py --gpus {1,8}: config #3 (mux-ram-8-16-16) and config #4 (CAHP system), 10 clocks each
+#   - before anything else, on a box with >= 2 GPUs: the distinct-device replica-exchange and multi-GPU init tests (one JSON line)
 # One JSON line per run, in that order.  bench.py / bench_netlist.py refuse (status 3, no JSON) to report an N-GPU number
 # from fewer than N devices; this script then stops with status 3 after writing what it has — a partial table is labelled
 # by its last line {"refused": ...}, never silently padded.  The reference takes its GPU count the same way
@@ -26,6 +27,16 @@ run() {   # run <label> <cmd...>
   echo "$line" >> "$out"
   echo "$label: $(echo "$line" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d.get('value') or d.get('s_per_clock'))")"
 }
+# FIRST, where the box has more than one GPU: the in-process replica exchange between DISTINCT devices (hipMemcpyPeerAsync over
+# xGMI, iyk_hip_arena_sync_slots_multi) and the concurrent multi-GPU init — the two paths a 1-GPU box can only run aliased
+ndev=$(python -c "import torch; print(torch.cuda.device_count())" 2>/dev/null || echo 0)
+if [ "${ndev:-0}" -ge 2 ]; then
+  timeout 900 python -m pytest tests/test_gpu_zz_debug.py -q -m gpu -k "fan_out or multi_gpu_init" > /tmp/scale_all.peer 2>&1; rc=$?
+  echo "{\"distinct_device_tests\": \"$(tail -1 /tmp/scale_all.peer | tr -d '"\\' | cut -c1-120)\", \"status\": $rc, \"devices\": $ndev}" >> "$out"
+  echo "distinct-device tests: $(tail -1 /tmp/scale_all.peer)"
+else
+  echo "{\"distinct_device_tests\": \"skipped: $ndev device(s) visible\"}" >> "$out"
+fi
 for params in 128bit 80bit; do
   for n in $GPUS; do
     run "bench $params x$n" python bench.py --gpus $n --params $params --steps ${STEPS:-4} --warmup 1 --cpu-sample 0
