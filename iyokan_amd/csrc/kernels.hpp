@@ -10,7 +10,9 @@
 //               blind_rotate_kernel<L,BGBIT>          one wavefront per rotation, Goldilocks integers (IYK_HIP_NTT=goldilocks)
 //               sample_extract_kernel                 TRLWE -> TLWE lvl1 (CMUX-memory helper entry point only)
 //               keyswitch_init_kernel + keyswitch_wave_kernel<T,NC,16>   lvl1 -> lvl0 identity key switch, 16 gates and whole rows
-//                                                     per wavefront (keyswitch_kernel<T>: round 1's 16 gates per workgroup, A/B + fallback)
+//                                                     per wavefront (keyswitch_kernel<T>: round 1's 16 gates per workgroup, A/B + fallback);
+//                                                     <.., SHARED = true> for batches <= 4096 gates: a workgroup's four waves on the
+//                                                     SAME 16 gates, a quarter of the i range each, LDS reduction before the atomics
 //               gather_slots_kernel / scatter_slots_kernel   bulk slot I/O
 //               elementwise_kernel                    NOT / COPY / CONSTONE / CONSTZERO on arena slots
 //
