@@ -64,11 +64,11 @@ def _case(tmp_path, params, count, seed):
     return files, arena[3 * count:], params
 
 
-def _run(files, params, tmp_path, mode):
+def _run(files, params, tmp_path, mode, env=None):
     bits = 128 if params.n == 636 else 80
     out = str(tmp_path / ("out_" + "_".join(mode).replace("-", "") + ".bin"))
     r = subprocess.run([_harness(bits), str(params.n), files["bk"], files["ksk"], files["ops"], files["operands"], out] + mode,
-                       capture_output=True, text=True, timeout=600)
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stderr[-2000:]
     stats = json.loads(r.stdout.strip().splitlines()[-1])
     got = np.fromfile(out, dtype=np.uint32).reshape(-1, params.n + 1)
@@ -92,3 +92,22 @@ def test_per_gate_workers_equal_oracle(tmp_path, workers):
     assert np.array_equal(got, want)
     assert stats["gates"] == 1000
     print(f"upstream flavour, per gate, {workers} workers:", json.dumps(stats))
+
+
+@pytest.mark.parametrize("env, label", [({"IYK_HIP_COALESCE_MAX": "7"}, "flush every 7 parked gates"),
+                                        ({"IYK_HIP_COALESCE": "0"}, "one launch sequence per gate on the worker's stream")],
+                         ids=["max7", "off"])
+def test_per_gate_workers_other_coalescing_settings(tmp_path, env, label):
+    """The same one-gate workers with the coalescer forced to flush by COUNT (7 gates: dozens of small batches, both buffer sides in
+    use all the time) and with coalescing OFF (the reference's literal launch pattern): the same words as the oracle either way."""
+    files, want, params = _case(tmp_path, params_128bit(), count=150, seed=13)
+    got, stats = _run(files, params, tmp_path, ["--per-gate", "48"], env=env)
+    assert np.array_equal(got, want)
+    print(f"upstream flavour, per gate, 48 workers, {label}:", json.dumps(stats))
+
+
+def test_per_gate_workers_80bit(tmp_path):
+    files, want, params = _case(tmp_path, params_80bit(), count=400, seed=14)
+    got, stats = _run(files, params, tmp_path, ["--per-gate", "240"])
+    assert np.array_equal(got, want)
+    print("upstream flavour, per gate, 240 workers, 80-bit set:", json.dumps(stats))
