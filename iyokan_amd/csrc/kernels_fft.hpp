@@ -21,7 +21,25 @@
 // A/B knobs of tools/ab_fft_variants.sh (defaults = the shipped kernel).  IYK_FFT_TIMING_* variants compute WRONG results on
 // purpose (they remove one cost to measure it) and never ship.
 #ifndef IYK_FFT_BARRIER_EVERY
-#define IYK_FFT_BARRIER_EVERY 16
+#define IYK_FFT_BARRIER_EVERY 4   // round 5: 4 with the phase priorities below (16 before; 1 .. 8 within 0.5 %, 32 / 64 slower)
+#endif
+// Phase priorities of the throughput kernel (round 5; s_setprio, 14 instructions per CMUX step).  The two waves of a SIMD run the same
+// code, fall into step (the barrier aligns them) and then want the LDS, the texture path and the VALU at the same moments.  With a
+// DIFFERENT arbitration priority in every phase — digits and pass 1 of a forward transform 1, its passes 2 and 3 (the exchanges) 3,
+// the first half of a row's MAC 0, the second half 1, the inverse transforms 2 — whichever wave is in the plain FMA stream of a MAC
+// yields to its partner's exchange traffic, and the pair settles out of phase: +4.1 .. 4.7 % gates/s at the 128-bit set, +3.9 .. 4.4 %
+// at the 80-bit set on four boxes; +5.5 .. 5.9 % / +5.1 .. 5.6 % together with the barrier every 4 steps (the waves of a CU drift
+// further apart now, and the barrier is what keeps their key rows in the L1).  Any assignment with three or more distinct levels
+// gains 2 .. 3 %, two levels 1.2 %, a split inside the MAC the rest; the ORDER of the levels matters less than that they differ
+// (profiles/r05_prio_ab.txt).  -DIYK_FFT_PRIO_OFF = no priorities (with -DIYK_FFT_BARRIER_EVERY=16: round 5's kernel before this).
+#ifndef IYK_FFT_PRIO_OFF
+#ifndef IYK_FFT_PRIO_FWD
+#define IYK_FFT_PRIO_FWD 1
+#define IYK_FFT_PRIO_FWD2 3
+#define IYK_FFT_PRIO_MAC 0
+#define IYK_FFT_PRIO_MAC2 1
+#define IYK_FFT_PRIO_INV 2
+#endif
 #endif
 #ifndef IYK_FFT_KH_AHEAD
 #define IYK_FFT_KH_AHEAD 4   // half blocks of the next row in flight across the transform
@@ -549,6 +567,20 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
 #endif
 #pragma unroll
             for (int e = 0; e < 2; ++e) fft::cmac<false>(S[h & 1][e][q], a[q], kh[h % KH_RING][e]);
+#ifdef IYK_FFT_PRIO_MAC2
+            if (h == 7) __builtin_amdgcn_s_setprio(IYK_FFT_PRIO_MAC2);
+#endif
+#ifdef IYK_FFT_PRIO_MACPAT   // A/B: priority of half block h + 1 where it differs from h's
+            {
+                constexpr int pat[16] = IYK_FFT_PRIO_MACPAT;
+                if (h < 15 && pat[h + 1] != pat[h]) {   // h is an unrolled loop's counter: the builtin wants a literal
+                    if (pat[h + 1] == 0) __builtin_amdgcn_s_setprio(0);
+                    else if (pat[h + 1] == 1) __builtin_amdgcn_s_setprio(1);
+                    else if (pat[h + 1] == 2) __builtin_amdgcn_s_setprio(2);
+                    else __builtin_amdgcn_s_setprio(3);
+                }
+            }
+#endif
             IYK_FFT_SB;
             if (h + KH_DEPTH < 16) load_half(kh[(h + KH_DEPTH) % KH_RING], koff, row_off, h + KH_DEPTH);
             else if (h + KH_DEPTH - 16 < KH_AHEAD) load_half(kh[(h + KH_DEPTH) % KH_RING], koff, row_off + 4u * (u32)fft::M, h + KH_DEPTH - 16);
@@ -612,7 +644,23 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
             }
             IYK_FFT_STAMP(5);                             // P3
 #else
+#ifdef IYK_FFT_PRIO_FWD
+            __builtin_amdgcn_s_setprio(IYK_FFT_PRIO_FWD);
+#endif
+#ifdef IYK_FFT_PRIO_FWD2
+            fft_forward_lf_a(lane, a, LU, xb);
+            __builtin_amdgcn_s_setprio(IYK_FFT_PRIO_FWD2);
+#ifdef IYK_FFT_PRIO_FWD3
+            fft_forward_lf_b(lane, a, s_lf2, s_lf3, xb, [] { __builtin_amdgcn_s_setprio(IYK_FFT_PRIO_FWD3); });
+#else
+            fft_forward_lf_b(lane, a, s_lf2, s_lf3, xb, [] {});
+#endif
+#else
             fft_forward_lf(lane, a, LU, s_lf2, s_lf3, xb);
+#endif
+#ifdef IYK_FFT_PRIO_MAC
+            __builtin_amdgcn_s_setprio(IYK_FFT_PRIO_MAC);
+#endif
 #endif
 #endif
 #ifdef IYK_FFT_TIMING_L1KEYS
@@ -629,10 +677,16 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
             IYK_FFT_STAMP(6);                             // MAC
 #endif
         }
+#ifdef IYK_FFT_PRIO_INV
+        __builtin_amdgcn_s_setprio(IYK_FFT_PRIO_INV);
+#endif
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
             int lane = fft_lane_id(lane0);
             u32 lo[16];
+#ifdef IYK_FFT_PRIO_INVB
+            if (cc == 1) __builtin_amdgcn_s_setprio(IYK_FFT_PRIO_INVB);
+#endif
             fft_inverse2(lane, S[cc][0], S[cc][1], U, s_t1 + lane, s_t2 + (lane & 7), xb);
             if (CHECK) {
                 const double e0 = fft::round_err8(S[cc][0]), e1 = fft::round_err8(S[cc][1]);
