@@ -757,6 +757,10 @@ struct BrLatFft {
     __host__ __device__ static constexpr int half_buf(int row, int par) { return NFULL ? 2 * (row - NFULL) + par : row + 4 * par; }
 };
 
+#if !defined(IYK_LATFFT_PRIO_OFF) && !defined(IYK_LATFFT_PRIO_SEGF)
+#define IYK_LATFFT_PRIO_SEGF 131    // digits: levels before the first exchange / between the exchanges / after the second
+#define IYK_LATFFT_PRIO_SEGI 1031   // (a leading 1 keeps a leading zero from making the literal octal)
+#endif
 // Phase stamps for tools/ubench/latfft_trace.hip only (compiled with -DIYK_LATFFT_TRACE=<step>): s_memtime at the phase
 // boundaries of ONE step, written per wave to the buffer passed in place of out_index.  Not part of the product build.
 #ifdef IYK_LATFFT_TRACE
@@ -879,6 +883,15 @@ __global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_ker
         IYK_FTRACE(0);
         // ---- forward
         if (full) {   // row = wave -> spectrum in the wave's buffer, [k2][lane'']
+#ifndef IYK_LATFFT_PRIO_OFF   // round 5, arbitration priorities (s_setprio; profiles/r05_latfft_ab.txt).  (1) The whole-row wave of a SIMD
+            // — the longer job of the forward phase — runs at level 1 throughout, above the START of its half-row partner (w + 4):
+            // 2.579 -> 2.515 ms at 16 rotations.  (2) A half transform changes level with its segments: forward halves 1 / 3 / 1
+            // (before the first exchange / between the exchanges / after the second), inverse halves 0 / 3 / 1 — the two waves of a
+            // SIMD leave a barrier together, and unequal levels along the code pull them apart (the throughput kernel's finding):
+            // 2.515 -> 2.461 ms at 16, 2.51 -> 2.47 at 64, 80-bit set 1.93 -> 1.85 at 256; nothing at 256 rotations of the 128-bit
+            // set.  Segmenting the whole-row waves as well: slower (2.49).  Round 4 had tried half-row waves up: +3 % time.
+            __builtin_amdgcn_s_setprio(1);
+#endif
             u32 u[16];
             fft::cplx a[8];
             load_row(i, XF - 2);
@@ -907,14 +920,25 @@ __global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_ker
             fft::diff8_doubled<G>(lane, fp, ab, acc2 + cF * 2 * NTT_N, u);
             fft::digits4<G>(lvl, u, x);
             IYK_FTRACE(1);
+#ifdef IYK_LATFFT_PRIO_SEGF   // A/B: a different priority in every segment of a half transform (a, b, c = the three levels)
+            __builtin_amdgcn_s_setprio(IYK_LATFFT_PRIO_SEGF / 100 % 10);
+            auto k1 = [&] { load_row(i, XF - 1); __builtin_amdgcn_s_setprio(IYK_LATFFT_PRIO_SEGF / 10 % 10); };
+            auto k2 = [] { __builtin_amdgcn_s_setprio(IYK_LATFFT_PRIO_SEGF % 10); };
+#else
             auto k1 = [&] { load_row(i, XF - 1); };
             auto k2 = [] {};
+#endif
             if (fp) hfft_forward<1>(HA, x, U, t, k1, k2);
             else hfft_forward<0>(HA, x, U, t, k1, k2);
 #pragma unroll
             for (int q = 0; q < 4; ++q) xbf[q * 64 + in_pos] = x[q];
             IYK_FTRACE(2);
         }
+#if defined(IYK_LATFFT_PRIO_SEGF)
+        __builtin_amdgcn_s_setprio(0);
+#elif !defined(IYK_LATFFT_PRIO_OFF)
+        if (NFULL) __builtin_amdgcn_s_setprio(0);
+#endif
         wg_barrier_lds();
         IYK_FTRACE(3);
         // ---- MAC: frequency block q = wave of all four sums
@@ -952,9 +976,16 @@ __global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_ker
             for (int q = 0; q < 8; ++q) c[q] = s_sum[si * fft::M + q * 64 + in_pos];
 #pragma unroll
             for (int k = 0; k < 11; ++k) t[k] = tinv[k];
+#ifdef IYK_LATFFT_PRIO_SEGI
+            __builtin_amdgcn_s_setprio(IYK_LATFFT_PRIO_SEGI / 100 % 10);
+            auto k1 = [&] { load_row(i + 1, 0); __builtin_amdgcn_s_setprio(IYK_LATFFT_PRIO_SEGI / 10 % 10); };
+            auto k2 = [&] { load_row(i + 1, 1); __builtin_amdgcn_s_setprio(IYK_LATFFT_PRIO_SEGI % 10); };
+            auto k3 = [&] { if (XF > 4) load_row(i + 1, 2); };
+#else
             auto k1 = [&] { load_row(i + 1, 0); };
             auto k2 = [&] { load_row(i + 1, 1); };
             auto k3 = [&] { if (XF > 4) load_row(i + 1, 2); };
+#endif
             if (ip) hfft_inverse<1>(HA, c, y, U, t, k1, k2, k3);
             else hfft_inverse<0>(HA, c, y, U, t, k1, k2, k3);
             if (CHECK) {
@@ -966,6 +997,9 @@ __global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_ker
             if (XF > 4) load_row(i + 1, 3);
             IYK_FTRACE(7);
         }
+#ifdef IYK_LATFFT_PRIO_SEGI
+        __builtin_amdgcn_s_setprio(0);
+#endif
         wg_barrier_lds();
         IYK_FTRACE(8);
     }
