@@ -114,11 +114,12 @@ iyk_level_cost default_level_cost(int cus, int path, bool set80)
     c.round = BR_WAVES * cus;
     c.pass = cus;
     c.calibrated = 0;
-    // full rounds, sustained (profiles/r04_bench_final.json, r04_80bit_bench_final.json, r03_bench*.json)
-    c.round_ms = path == 2 ? (set80 ? 9.6f : 15.5f) : path == 1 ? (set80 ? 20.0f : 19.7f) : (set80 ? 52.0f : 86.0f);
-    // workgroup-per-rotation kernels: the FFT one with its half transforms (profiles/r04_sweep_kernels.txt), the field one
-    const float pass_fft[8] = {2.60f, 5.13f, 7.66f, 10.19f, 12.74f, 15.30f, 17.85f, 20.40f};
-    const float pass_fft80[8] = {1.80f, 3.60f, 5.40f, 7.20f, 9.00f, 10.80f, 12.60f, 14.40f};
+    // one full round as iyk_hip_calibrate measures it (profiles/r05_model_inputs.json; inside a long launch a round is ~4 % shorter),
+    // field paths: r03_bench*.json
+    c.round_ms = path == 2 ? (set80 ? 9.4f : 14.5f) : path == 1 ? (set80 ? 20.0f : 19.7f) : (set80 ? 52.0f : 86.0f);
+    // workgroup-per-rotation kernels, one pass = one rotation per CU: the FFT one (profiles/r05_model_inputs.json), the field one
+    const float pass_fft[8] = {2.62f, 5.11f, 7.57f, 10.09f, 12.52f, 15.00f, 17.62f, 20.05f};
+    const float pass_fft80[8] = {1.86f, 3.66f, 5.31f, 6.88f, 8.42f, 10.08f, 11.76f, 13.44f};
     const float pass_fp[8] = {3.33f, 6.96f, 10.23f, 13.52f, 16.79f, 20.1f, 23.4f, 26.7f};
     for (int j = 0; j < 8; ++j) c.pass_ms[j] = path == 2 ? (set80 ? pass_fft80[j] : pass_fft[j]) : pass_fp[j];
     c.max_passes = 0;
