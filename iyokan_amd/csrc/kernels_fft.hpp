@@ -26,11 +26,12 @@
 // Phase priorities of the throughput kernel (round 5; s_setprio, 14 instructions per CMUX step).  The two waves of a SIMD run the same
 // code, fall into step (the barrier aligns them) and then want the LDS, the texture path and the VALU at the same moments.  With a
 // DIFFERENT arbitration priority in every phase — digits and pass 1 of a forward transform 1, its passes 2 and 3 (the exchanges) 3,
-// the first half of a row's MAC 0, the second half 1, the inverse transforms 2 — whichever wave is in the plain FMA stream of a MAC
-// yields to its partner's exchange traffic, and the pair settles out of phase: +4.1 .. 4.7 % gates/s at the 128-bit set, +3.9 .. 4.4 %
-// at the 80-bit set on four boxes; +5.5 .. 5.9 % / +5.1 .. 5.6 % together with the barrier every 4 steps (the waves of a CU drift
-// further apart now, and the barrier is what keeps their key rows in the L1).  Any assignment with three or more distinct levels
-// gains 2 .. 3 %, two levels 1.2 %, a split inside the MAC the rest; the ORDER of the levels matters less than that they differ
+// the first half of a row's MAC 0, the second half 1, the three passes of a pair of inverse transforms 1 / 0 / 3 — whichever wave is
+// in the plain FMA stream of a MAC yields to its partner's exchange traffic, and the pair settles out of phase: +4.1 .. 4.7 % gates/s
+// at the 128-bit set, +3.9 .. 4.4 % at the 80-bit set on four boxes with the inverse at one level (2); +5.5 .. 5.9 % / +5.1 .. 5.6 %
+// together with the barrier every 4 steps (the waves of a CU drift further apart now, and the barrier is what keeps their key rows in
+// the L1); the inverse's own three levels another +1.5 % / +1.1 %.  Any assignment with three or more distinct levels gains 2 .. 3 %,
+// two levels 1.2 %, a split inside the MAC the rest; the ORDER of the levels matters less than that they differ
 // (profiles/r05_prio_ab.txt).  -DIYK_FFT_PRIO_OFF = no priorities (with -DIYK_FFT_BARRIER_EVERY=16: round 5's kernel before this).
 #ifndef IYK_FFT_PRIO_OFF
 #ifndef IYK_FFT_PRIO_FWD
@@ -38,7 +39,7 @@
 #define IYK_FFT_PRIO_FWD2 3
 #define IYK_FFT_PRIO_MAC 0
 #define IYK_FFT_PRIO_MAC2 1
-#define IYK_FFT_PRIO_INV 2
+#define IYK_FFT_PRIO_INVSEG 103   // a pair of inverse transforms: pass 1 / pass 2 / pass 3
 #endif
 #endif
 #ifndef IYK_FFT_KH_AHEAD
@@ -298,8 +299,14 @@ __device__ __forceinline__ void fft_inverse2(int lane, fft::cplx (&a)[8], fft::c
     };
     p1(a);
     p1(b);
+#ifdef IYK_FFT_PRIO_INVSEG
+    __builtin_amdgcn_s_setprio(IYK_FFT_PRIO_INVSEG / 10 % 10);
+#endif
     p2(a);
     p2(b);
+#ifdef IYK_FFT_PRIO_INVSEG
+    __builtin_amdgcn_s_setprio(IYK_FFT_PRIO_INVSEG % 10);
+#endif
     p3(a);
     p3(b);
 }
@@ -686,6 +693,9 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
             u32 lo[16];
 #ifdef IYK_FFT_PRIO_INVB
             if (cc == 1) __builtin_amdgcn_s_setprio(IYK_FFT_PRIO_INVB);
+#endif
+#ifdef IYK_FFT_PRIO_INVSEG
+            __builtin_amdgcn_s_setprio(IYK_FFT_PRIO_INVSEG / 100 % 10);
 #endif
             fft_inverse2(lane, S[cc][0], S[cc][1], U, s_t1 + lane, s_t2 + (lane & 7), xb);
             if (CHECK) {
