@@ -25,17 +25,18 @@
 #endif
 // Phase priorities of the throughput kernel (round 5; s_setprio, 14 instructions per CMUX step).  The two waves of a SIMD run the same
 // code, fall into step (the barrier aligns them) and then want the LDS, the texture path and the VALU at the same moments.  With a
-// DIFFERENT arbitration priority in every phase — digits and pass 1 of a forward transform 1, its passes 2 and 3 (the exchanges) 3,
+// DIFFERENT arbitration priority in every phase — digits and pass 1 of a forward transform 2, its passes 2 and 3 (the exchanges) 3,
 // the first half of a row's MAC 0, the second half 1, the three passes of a pair of inverse transforms 1 / 0 / 3 — whichever wave is
 // in the plain FMA stream of a MAC yields to its partner's exchange traffic, and the pair settles out of phase: +4.1 .. 4.7 % gates/s
 // at the 128-bit set, +3.9 .. 4.4 % at the 80-bit set on four boxes with the inverse at one level (2); +5.5 .. 5.9 % / +5.1 .. 5.6 %
 // together with the barrier every 4 steps (the waves of a CU drift further apart now, and the barrier is what keeps their key rows in
-// the L1); the inverse's own three levels another +1.5 % / +1.1 %.  Any assignment with three or more distinct levels gains 2 .. 3 %,
+// the L1); the inverse's own three levels another +1.5 % / +1.1 %, and pass 1 of the forward transform at 2 instead of 1 after that +1.7 %
+// (a coordinate search: every neighbour of the shipped assignment measured lower).  Any assignment with three or more distinct levels gains 2 .. 3 %,
 // two levels 1.2 %, a split inside the MAC the rest; the ORDER of the levels matters less than that they differ
 // (profiles/r05_prio_ab.txt).  -DIYK_FFT_PRIO_OFF = no priorities (with -DIYK_FFT_BARRIER_EVERY=16: round 5's kernel before this).
 #ifndef IYK_FFT_PRIO_OFF
 #ifndef IYK_FFT_PRIO_FWD
-#define IYK_FFT_PRIO_FWD 1
+#define IYK_FFT_PRIO_FWD 2
 #define IYK_FFT_PRIO_FWD2 3
 #define IYK_FFT_PRIO_MAC 0
 #define IYK_FFT_PRIO_MAC2 1

@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
-out=gpurun_out/r05u_fft_ab.txt; : > $out
+out=gpurun_out/r05x_fft_ab.txt; : > $out
 cp iyokan_amd/lib/libiyokan_hip.so /tmp/keep.so
 for rep in 1 2 3; do for v in $VARIANTS; do
   cp iyokan_amd/lib/variant_$v.so iyokan_amd/lib/libiyokan_hip.so
@@ -10,7 +10,7 @@ cp /tmp/keep.so iyokan_amd/lib/libiyokan_hip.so
 python - <<'P'
 import collections
 r=collections.defaultdict(list)
-for l in open('/root/repo/gpurun_out/r05u_fft_ab.txt'):
+for l in open('/root/repo/gpurun_out/r05x_fft_ab.txt'):
     f=l.split()
     k=(f[0],'80' if f[1]=='80bit' else '128'); r[k].append(int(f[-3]))
 for k in sorted(r, key=lambda k:(k[1],k[0])): print(k, r[k], round(sum(r[k])/len(r[k])))
