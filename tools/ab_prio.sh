@@ -1,3 +1,7 @@
+#!/bin/bash
+# Same-box A/B of throughput-kernel variants at BOTH parameter sets, three repetitions each, with a per-variant summary
+# (profiles/r05_prio_ab.txt was made with it).  Build the variants first:  bash tools/ab_fft_variants.sh build "name:-DFLAG ..." ...
+# then on the GPU box:  VARIANTS="base a b" bash tools/ab_prio.sh   ->  gpurun_out/r05x_fft_ab.txt (edit the tag below per batch)
 export TMPDIR=/tmp
 out=gpurun_out/r05x_fft_ab.txt; : > $out
 cp iyokan_amd/lib/libiyokan_hip.so /tmp/keep.so
