@@ -1,9 +1,9 @@
 #!/bin/bash
 # Same-box A/B of throughput-kernel variants at BOTH parameter sets, three repetitions each, with a per-variant summary
 # (profiles/r05_prio_ab.txt was made with it).  Build the variants first:  bash tools/ab_fft_variants.sh build "name:-DFLAG ..." ...
-# then on the GPU box:  VARIANTS="base a b" bash tools/ab_prio.sh   ->  gpurun_out/r05y_fft_ab.txt (edit the tag below per batch)
+# then on the GPU box:  VARIANTS="base a b" bash tools/ab_prio.sh   ->  gpurun_out/r05z_fft_ab.txt (edit the tag below per batch)
 export TMPDIR=/tmp
-out=gpurun_out/r05y_fft_ab.txt; : > $out
+out=gpurun_out/r05z_fft_ab.txt; : > $out
 cp iyokan_amd/lib/libiyokan_hip.so /tmp/keep.so
 for rep in 1 2 3; do for v in $VARIANTS; do
   cp iyokan_amd/lib/variant_$v.so iyokan_amd/lib/libiyokan_hip.so
@@ -14,7 +14,7 @@ cp /tmp/keep.so iyokan_amd/lib/libiyokan_hip.so
 python - <<'P'
 import collections
 r=collections.defaultdict(list)
-for l in open('/root/repo/gpurun_out/r05y_fft_ab.txt'):
+for l in open('/root/repo/gpurun_out/r05z_fft_ab.txt'):
     f=l.split()
     k=(f[0],'80' if f[1]=='80bit' else '128'); r[k].append(int(f[-3]))
 for k in sorted(r, key=lambda k:(k[1],k[0])): print(k, r[k], round(sum(r[k])/len(r[k])))
