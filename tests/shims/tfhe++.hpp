@@ -94,6 +94,11 @@ struct SecretKey {
     template <class Archive> void serialize(Archive&) {}
 };
 struct EvalKey {
+    // storage for the two keys the gate-bootstrapping path uses, under the member names TFHEpp's EvalKey gives them; empty
+    // unless something fills them (tests/upstream_exec/tfhepp_runtime.cpp does, when upstream's engine is EXECUTED around the
+    // plugin; the compile-only use never touches them)
+    std::shared_ptr<BootstrappingKey<lvl01param>> bklvl01;
+    std::shared_ptr<KeySwitchingKey<lvl10param>> iksklvl10;
     EvalKey();
     EvalKey(const SecretKey&);
     template <class P> void emplacebk(const SecretKey&);

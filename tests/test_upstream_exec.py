@@ -1,0 +1,90 @@
+"""The upstream-flavour plugin EXECUTED under upstream Iyokan's real engine (tests/upstream_exec/README.md).
+
+Upstream's header-only engine (`/root/reference/src/iyokan.hpp`), its own `iyokan*.cpp` and its own templated `test0.cpp` tests are
+compiled where they lie, against working stand-ins for the third-party pieces the engine calls, and linked with
+`integration/upstream/iyokan_hip.{hpp,cpp}` and a CPU mock of the C ABI (`tests/mock/`).  Then upstream's tests run with
+`HIPNetworkBuilder` through BOTH worker flavours under AddressSanitizer + UBSan.
+
+Build container only (needs `/root/reference`); objects and binaries go to a temporary directory.
+"""
+import json
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+EXEC = os.path.join(ROOT, "tests", "upstream_exec")
+
+pytestmark = pytest.mark.skipif(
+    not os.path.exists(os.path.join(REF, "src", "iyokan.hpp")) or shutil.which("g++") is None
+    or not os.path.exists(os.path.join(ROOT, "oracle", "libiyk_oracle.so"))
+    or not os.path.exists(os.path.join(ROOT, "iyokan_amd", "lib", "libiyokan_client.so")),
+    reason="needs the reference checkout, g++, and the built oracle + client libraries (build container only)",
+)
+
+
+def _build(out, san):
+    r = subprocess.run(["make", "-j8", "-C", EXEC, f"OUT={out}", f"SAN={san}"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-6000:]
+    return os.path.join(out, "test0_hip_exec")
+
+
+def _run(exe, extra_env=None, timeout=1500):
+    env = dict(os.environ, IYK_EXEC_SEED="20260929", ASAN_OPTIONS="detect_leaks=1:abort_on_error=0",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    env.pop("IYOKAN_HIP_PER_GATE", None)
+    env.update(extra_env or {})
+    # upstream's tests open "test/iyokanl1-json/..." relative to the checkout; nothing is written there
+    return subprocess.run([exe], cwd=REF, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.fixture(scope="module")
+def exec_binary(tmp_path_factory):
+    return _build(str(tmp_path_factory.mktemp("upstream_exec")), "-fsanitize=address,undefined -fno-sanitize-recover=undefined")
+
+
+def _check_report(r):
+    assert r.returncode == 0, (r.stdout + r.stderr)[-6000:]
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr and "ThreadSanitizer" not in r.stderr, \
+        r.stderr[-6000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    sec = {s["name"]: s for s in rep["sections"]}
+    # nothing outlived iyk_hip_cleanup
+    assert (rep["live_streams"], rep["live_arenas"], rep["live_trlwes"], rep["live_pinned"]) == (0, 0, 0, 0)
+    # the batching worker sent frontiers (several gates per batch at least once), never single host gates ...
+    for name in ("upstream_tests_batch_worker", "fresh_gates_batch_worker", "fresh_counter_batch_worker", "runner_batch_worker"):
+        assert sec[name]["gate_batches"] > 0 and sec[name]["gate_host_calls"] == 0, sec[name]
+        assert sec[name]["gates_in_batches"] > sec[name]["gate_batches"], sec[name]
+    assert rep["max_batch"] >= 9   # the eight binary gates + MUX of one frontier went out together
+    # ... the reference-shaped workers one gate per stream, and the SAME number of gates either way
+    for batch, per_gate in (("upstream_tests_batch_worker", "upstream_tests_per_gate_workers"),
+                            ("fresh_gates_batch_worker", "fresh_gates_per_gate_workers"),
+                            ("fresh_counter_batch_worker", "fresh_counter_per_gate_workers"),
+                            ("runner_batch_worker", "runner_per_gate_workers")):
+        assert sec[per_gate]["gate_batches"] == 0, sec[per_gate]
+        assert sec[per_gate]["gate_host_calls"] == sec[batch]["gates_in_batches"], (sec[per_gate], sec[batch])
+    # the "GPU" really was asynchronous: streams were polled busy before they were seen idle
+    assert all(sec[n]["queries_busy"] > 0 for n in sec if n != "upstream_tfhepp_plugin_selfcheck")
+    return rep
+
+
+def test_upstreams_tests_pass_with_the_hip_plugin_under_upstreams_engine(exec_binary):
+    """testNOT / testMUX / testBinopGates / six JSON circuits / testSequentialCircuit / 4-bit counter / PrioritySetVisitor / bridges
+    with HIPNetworkBuilder, through HIPBatchWorker and through 240 HIPWorkers; then fresh encryptions; then both runners."""
+    _check_report(_run(exec_binary))
+
+
+def test_the_harness_notices_a_wrong_gate(exec_binary):
+    """Negative control: with the mock computing AND for NAND the very same binary must die in one of upstream's assertions."""
+    r = _run(exec_binary, {"IYK_MOCK_SABOTAGE": "1"})
+    assert r.returncode != 0
+    assert "Assertion" in r.stderr, r.stderr[-3000:]
+
+
+@pytest.mark.skipif(os.environ.get("IYK_EXEC_TSAN") != "1", reason="set IYK_EXEC_TSAN=1 for the ThreadSanitizer build (+2 min)")
+def test_thread_sanitizer_is_clean(tmp_path):
+    exe = _build(str(tmp_path), "-fsanitize=thread")
+    _check_report(_run(exe, {"TSAN_OPTIONS": "halt_on_error=1"}))

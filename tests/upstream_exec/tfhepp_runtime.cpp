@@ -1,0 +1,310 @@
+// tfhepp_runtime.cpp — definitions behind the declarations of tests/shims/tfhe++.hpp and tests/shims/toml.hpp, so that upstream
+// Iyokan's engine (/root/reference/src/iyokan.hpp, header-only) can be LINKED and RUN around the upstream-flavour plugin in the
+// build container (tests/test_upstream_exec.py; README.md beside this file).
+//
+// TEST INFRASTRUCTURE, and NOT a build of TFHEpp: no line of TFHEpp is here or anywhere in this container.  Every function is
+// a delegation to code of this repository —
+//     key generation, bit encryption / decryption, trivial ciphertexts   iyokan_amd/lib/libiyokan_client.so (the product's client library)
+//     the Hom* gates of upstream's CPU worker (TaskTFHEppGate*)            oracle/libiyk_oracle.so (the CPU restatement)
+// — or a loud abort for what the executed tests never reach (circuit bootstrapping, the CMUX memories' FFT-domain helpers, TOML).
+// Nothing measured, nothing a parity claim rests on: the point is to put upstream's real Task / DepNode / ReadyQueue / Worker /
+// NetworkRunner code under the plugin's task and worker classes and watch it terminate with the right bits.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <random>
+
+#include <tfhe++.hpp>
+#include <toml.hpp>
+
+#include <iyokan_hip_params.h>
+
+extern "C" {
+// iyokan_amd/csrc/client.cpp
+int iyk_client_keygen(const iyk_params* p, uint64_t seed, int deterministic, uint32_t* s0, uint32_t* s1, uint32_t* bk,
+                      uint32_t* ksk);
+int iyk_client_encrypt_bits(const iyk_params* p, const uint32_t* s0, uint64_t seed, int deterministic, const uint8_t* bits,
+                            uint64_t count, uint32_t* out);
+int iyk_client_decrypt_bits(const iyk_params* p, const uint32_t* s0, const uint32_t* ct, uint64_t count, uint8_t* bits);
+int iyk_client_trivial(const iyk_params* p, int bit, uint32_t* out);
+// oracle/tfhe_oracle.c
+struct orc_ctx;
+orc_ctx* orc_new(const iyk_params* p, const uint32_t* bk, const uint32_t* ksk);
+void orc_free(orc_ctx* c);
+void orc_gate(const orc_ctx* c, int op, const uint32_t* in0, const uint32_t* in1, const uint32_t* in2, uint32_t* out, int mode);
+
+// the MUX-RAM netlists upstream embeds with objcopy (/root/reference/src/CMakeLists.txt); the executed tests build no RAM
+char _binary_mux_ram_8_8_8_min_json_start[1] = {0}, _binary_mux_ram_8_8_8_min_json_end[1] = {0};
+char _binary_mux_ram_8_16_16_min_json_start[1] = {0}, _binary_mux_ram_8_16_16_min_json_end[1] = {0};
+char _binary_mux_ram_9_16_16_min_json_start[1] = {0}, _binary_mux_ram_9_16_16_min_json_end[1] = {0};
+}
+
+namespace {
+
+using namespace TFHEpp;
+
+[[noreturn]] void notModelled(const char* what)
+{
+    std::fprintf(stderr, "tests/upstream_exec: %s is not modelled (the executed tests must not reach it)\n", what);
+    std::abort();
+}
+
+iyk_params params()
+{
+    iyk_params p{};
+    p.n = lvl0param::n;
+    p.N = lvl1param::n;
+    p.k = lvl1param::k;
+    p.l = lvl1param::l;
+    p.Bgbit = lvl1param::Bgbit;
+    p.t = lvl10param::t;
+    p.basebit = lvl10param::basebit;
+    p.mu = lvl1param::μ;
+    p.alpha0 = lvl0param::α;
+    p.alpha1 = lvl1param::α;
+    return p;
+}
+
+// one key generation yields the secrets AND the evaluation keys (iyk_client_keygen); SecretKey() runs it and the emplace*
+// calls pick their part up by the secret's value
+struct Generated {
+    std::shared_ptr<BootstrappingKey<lvl01param>> bk = std::make_shared<BootstrappingKey<lvl01param>>();
+    std::shared_ptr<KeySwitchingKey<lvl10param>> ksk = std::make_shared<KeySwitchingKey<lvl10param>>();
+};
+std::mutex g_mu;
+std::map<Key<lvl0param>, Generated> g_generated;
+struct Oracles {
+    std::map<const void*, orc_ctx*> byKey;  // by bk storage address
+    ~Oracles()
+    {
+        for (auto&& [key, ctx] : byKey)
+            orc_free(ctx);
+    }
+} g_oracles;
+
+const Generated& generatedFor(const SecretKey& sk)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_generated.find(sk.key.lvl0);
+    if (it == g_generated.end())
+        notModelled("an EvalKey for a SecretKey that SecretKey() did not generate");
+    return it->second;
+}
+
+const orc_ctx* oracleFor(const EvalKey& ek)
+{
+    if (!ek.bklvl01 || !ek.iksklvl10)
+        notModelled("a Hom* gate with an EvalKey lacking bk<lvl01> / iksk<lvl10>");
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto& slot = g_oracles.byKey[ek.bklvl01.get()];
+    if (!slot) {
+        static const iyk_params p = params();
+        slot = orc_new(&p, reinterpret_cast<const uint32_t*>(ek.bklvl01->data()),
+                       reinterpret_cast<const uint32_t*>(ek.iksklvl10->data()));
+    }
+    return slot;
+}
+
+enum { OP_AND, OP_NAND, OP_ANDNOT, OP_OR, OP_NOR, OP_ORNOT, OP_XOR, OP_XNOR, OP_MUX };  // include/iyokan_hip.h, iyk_gate_op
+
+uint64_t freshSeed()
+{
+    static std::mutex mu;
+    static uint64_t next = [] {
+        if (const char* v = std::getenv("IYK_EXEC_SEED"))
+            return static_cast<uint64_t>(std::strtoull(v, nullptr, 0));
+        return static_cast<uint64_t>(std::random_device{}()) << 20;
+    }();
+    std::lock_guard<std::mutex> lk(mu);
+    return next++;
+}
+
+}  // namespace
+
+namespace TFHEpp {
+
+SecretKey::SecretKey()
+{
+    const iyk_params p = params();
+    Generated g;
+    key.lvl2.fill(0);
+    iyk_client_keygen(&p, freshSeed(), 1, key.lvl0.data(), key.lvl1.data(), reinterpret_cast<uint32_t*>(g.bk->data()),
+                      reinterpret_cast<uint32_t*>(g.ksk->data()));
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_generated.emplace(key.lvl0, std::move(g));
+}
+
+template <> const Key<lvl0param>& lweKey::get<lvl0param>() const { return lvl0; }
+template <> const Key<lvl1param>& lweKey::get<lvl1param>() const { return lvl1; }
+template <> const Key<lvl2param>& lweKey::get<lvl2param>() const { return lvl2; }
+
+EvalKey::EvalKey() {}
+EvalKey::EvalKey(const SecretKey&) {}
+
+template <> void EvalKey::emplacebk<lvl01param>(const SecretKey& sk) { bklvl01 = generatedFor(sk).bk; }
+template <> void EvalKey::emplaceiksk<lvl10param>(const SecretKey& sk) { iksklvl10 = generatedFor(sk).ksk; }
+// the FFT-domain and lvl2 keys belong to upstream's CMUX memories (CPU side); the executed tests never read them
+template <> void EvalKey::emplacebk2bkfft<lvl01param>() {}
+template <> void EvalKey::emplacebkfft<lvl02param>(const SecretKey&) {}
+template <> void EvalKey::emplaceprivksk4cb<lvl21param>(const SecretKey&) {}
+
+template <> const BootstrappingKey<lvl01param>& EvalKey::getbk<lvl01param>() const
+{
+    if (!bklvl01)
+        notModelled("getbk<lvl01param>() before emplacebk");
+    return *bklvl01;
+}
+template <> const KeySwitchingKey<lvl10param>& EvalKey::getiksk<lvl10param>() const
+{
+    if (!iksklvl10)
+        notModelled("getiksk<lvl10param>() before emplaceiksk");
+    return *iksklvl10;
+}
+template <> const BootstrappingKeyFFT<lvl01param>& EvalKey::getbkfft<lvl01param>() const { notModelled("getbkfft<lvl01param>"); }
+template <> const BootstrappingKeyFFT<lvl02param>& EvalKey::getbkfft<lvl02param>() const { notModelled("getbkfft<lvl02param>"); }
+
+template <> void HomCONSTANTONE<lvl0param>(TLWE<lvl0param>& out)
+{
+    const iyk_params p = params();
+    iyk_client_trivial(&p, 1, out.data());
+}
+template <> void HomCONSTANTZERO<lvl0param>(TLWE<lvl0param>& out)
+{
+    const iyk_params p = params();
+    iyk_client_trivial(&p, 0, out.data());
+}
+template <> void HomNOT<lvl0param>(TLWE<lvl0param>& out, const TLWE<lvl0param>& in)
+{
+    for (size_t i = 0; i < out.size(); i++)
+        out[i] = 0u - in[i];
+}
+template <> void HomCOPY<lvl0param>(TLWE<lvl0param>& out, const TLWE<lvl0param>& in) { out = in; }
+
+#define EXEC_GATE(name, op)                                                                                             \
+    template <>                                                                                                         \
+    void name<lvl01param, lvl1param::μ, lvl10param>(TLWE<lvl0param> & out, const TLWE<lvl0param>& a,                    \
+                                                    const TLWE<lvl0param>& b, const EvalKey& ek)                        \
+    {                                                                                                                   \
+        orc_gate(oracleFor(ek), op, a.data(), b.data(), nullptr, out.data(), 0);                                        \
+    }
+EXEC_GATE(HomAND, OP_AND)
+EXEC_GATE(HomNAND, OP_NAND)
+EXEC_GATE(HomANDYN, OP_ANDNOT)
+EXEC_GATE(HomOR, OP_OR)
+EXEC_GATE(HomNOR, OP_NOR)
+EXEC_GATE(HomORYN, OP_ORNOT)
+EXEC_GATE(HomXOR, OP_XOR)
+EXEC_GATE(HomXNOR, OP_XNOR)
+#undef EXEC_GATE
+// ANDNY = ~a & b = ANDYN with the operands exchanged (used by upstream's serialisation test only)
+template <>
+void HomANDNY<lvl01param, lvl1param::μ, lvl10param>(TLWE<lvl0param>& out, const TLWE<lvl0param>& a, const TLWE<lvl0param>& b,
+                                                    const EvalKey& ek)
+{
+    orc_gate(oracleFor(ek), OP_ANDNOT, b.data(), a.data(), nullptr, out.data(), 0);
+}
+// HomMUX(out, cs, c1, c0): the oracle's MUX takes (in0 = c0, in1 = c1, in2 = cs), /root/reference/src/iyokan_tfhepp.hpp:140-141
+template <>
+void HomMUX<lvl0param>(TLWE<lvl0param>& out, const TLWE<lvl0param>& cs, const TLWE<lvl0param>& c1, const TLWE<lvl0param>& c0,
+                       const EvalKey& ek)
+{
+    orc_gate(oracleFor(ek), OP_MUX, c0.data(), c1.data(), cs.data(), out.data(), 0);
+}
+
+template <> std::vector<TLWE<lvl0param>> bootsSymEncrypt<lvl0param>(const std::vector<uint8_t>& bits, const SecretKey& sk)
+{
+    const iyk_params p = params();
+    std::vector<TLWE<lvl0param>> out(bits.size());
+    if (!bits.empty())
+        iyk_client_encrypt_bits(&p, sk.key.lvl0.data(), freshSeed(), 1, bits.data(), bits.size(), out[0].data());
+    return out;
+}
+template <> std::vector<uint8_t> bootsSymDecrypt<lvl0param>(const std::vector<TLWE<lvl0param>>& cts, const SecretKey& sk)
+{
+    const iyk_params p = params();
+    std::vector<uint8_t> bits(cts.size());
+    if (!cts.empty())
+        iyk_client_decrypt_bits(&p, sk.key.lvl0.data(), cts[0].data(), cts.size(), bits.data());
+    return bits;
+}
+
+template <> void SampleExtractIndex<lvl1param>(TLWE<lvl1param>&, const TRLWE<lvl1param>&, int)
+{
+    notModelled("SampleExtractIndex (upstream's CPU-side ROM / RAM read)");
+}
+template <>
+void IdentityKeySwitch<lvl10param>(TLWE<lvl0param>&, const TLWE<lvl1param>&, const KeySwitchingKey<lvl10param>&)
+{
+    notModelled("IdentityKeySwitch (upstream's CPU-side ROM / RAM read)");
+}
+
+// ---- everything below belongs to upstream's CMUX memories and circuit bootstrapping on the CPU: linked, never executed --------
+template <>
+void HomMUXwoSE<lvl01param>(TRLWE<lvl1param>&, const TLWE<lvl0param>&, const TLWE<lvl0param>&, const TLWE<lvl0param>&,
+                            const EvalKey&)
+{
+    notModelled("HomMUXwoSE");
+}
+template <> void CircuitBootstrappingFFT<lvl02param, lvl21param>(TRGSWFFT<lvl1param>&, const TLWE<lvl0param>&, const EvalKey&)
+{
+    notModelled("CircuitBootstrappingFFT");
+}
+template <> void CircuitBootstrappingFFTInv<lvl02param, lvl21param>(TRGSWFFT<lvl1param>&, const TLWE<lvl0param>&, const EvalKey&)
+{
+    notModelled("CircuitBootstrappingFFTInv");
+}
+template <>
+void CircuitBootstrappingFFTwithInv<lvl02param, lvl21param>(TRGSWFFT<lvl1param>&, TRGSWFFT<lvl1param>&, const TLWE<lvl0param>&,
+                                                            const EvalKey&)
+{
+    notModelled("CircuitBootstrappingFFTwithInv");
+}
+template <> void CMUXFFT<lvl1param>(TRLWE<lvl1param>&, const TRGSWFFT<lvl1param>&, const TRLWE<lvl1param>&, const TRLWE<lvl1param>&)
+{
+    notModelled("CMUXFFT");
+}
+template <> void PolynomialMulByXaiMinusOne<lvl1param>(Polynomial<lvl1param>&, const Polynomial<lvl1param>&, lvl1param::T)
+{
+    notModelled("PolynomialMulByXaiMinusOne");
+}
+template <> void trgswfftExternalProduct<lvl1param>(TRLWE<lvl1param>&, const TRLWE<lvl1param>&, const TRGSWFFT<lvl1param>&)
+{
+    notModelled("trgswfftExternalProduct");
+}
+template <>
+void BlindRotate<lvl01param>(TRLWE<lvl1param>&, const TLWE<lvl0param>&, const BootstrappingKeyFFT<lvl01param>&,
+                             const Polynomial<lvl1param>&)
+{
+    notModelled("BlindRotate");
+}
+template <> Polynomial<lvl1param> μpolygen<lvl1param, lvl1param::μ>() { notModelled("μpolygen"); }
+template <> std::array<bool, lvl1param::n> trlweSymDecrypt<lvl1param>(const TRLWE<lvl1param>&, const Key<lvl1param>&)
+{
+    notModelled("trlweSymDecrypt");
+}
+
+}  // namespace TFHEpp
+
+// ---- toml11: blueprints are not read by the executed tests -----------------------------------------------------------------
+namespace toml {
+value::value() {}
+value::value(const value&) {}
+value& value::operator=(const value&) { return *this; }
+value::~value() {}
+bool value::is_array() const { notModelled("toml"); }
+bool value::is_string() const { notModelled("toml"); }
+bool value::is_table() const { notModelled("toml"); }
+bool value::contains(const std::string&) const { notModelled("toml"); }
+value parse(const std::string&) { notModelled("toml::parse"); }
+template <> std::string find<std::string>(const value&, const std::string&) { notModelled("toml::find"); }
+template <> size_t find<size_t>(const value&, const std::string&) { notModelled("toml::find"); }
+template <> std::string get<std::string>(const value&) { notModelled("toml::get"); }
+template <> std::vector<std::string> get<std::vector<std::string>>(const value&) { notModelled("toml::get"); }
+template <> std::vector<value> find_or<std::vector<value>>(const value&, const std::string&, std::vector<value>&&)
+{
+    notModelled("toml::find_or");
+}
+template <> table find_or<table>(const value&, const std::string&, table&&) { notModelled("toml::find_or"); }
+}  // namespace toml
