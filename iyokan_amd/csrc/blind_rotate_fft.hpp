@@ -54,18 +54,7 @@ struct Gadget {
 template <class G>
 IYK_HD void diff16(int L, u32 abar, const u32* acc_c, u32 (&u)[16])
 {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(IYK_FFT_DIFF_PLAIN)   // A/B: the compiler's own schedule (a wait per coefficient)
-    typedef const __attribute__((address_space(3))) u32* lds_u32;
-    const u32 acc_base = (u32)(size_t)(lds_u32)acc_c;
-    const u32 base4 = ((u32)L - abar) << 2;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const u32 idx4 = base4 + 256u * (u32)q;
-        const u32 neg = (u32)((i32)(idx4 << 19) >> 31);
-        const u32 a = *(lds_u32)(size_t)((idx4 & 0xFFCu) | acc_base);
-        u[q] = G::prepare((a ^ neg) + ((0u - acc_c[L + 64 * q]) - neg));
-    }
-#elif defined(__HIP_DEVICE_COMPILE__) && !defined(IYK_FFT_DIFF_R04)
+#if defined(__HIP_DEVICE_COMPILE__)
     // Round 5: 7 vector instructions per coefficient instead of the 10-11 the round-4 form compiled to (ISA count, tools/isa_blocks.py:
     // 165 -> ~125 per polynomial).  idx4 = byte index of the rotated coefficient (its bit 12 = the wrap of X^N = -1):
     //     address  (idx4 & 0xFFC) | base            add + v_and_or / v_bfi
@@ -101,39 +90,6 @@ IYK_HD void diff16(int L, u32 abar, const u32* acc_c, u32 (&u)[16])
             const u32 mask = (u32)__builtin_amdgcn_sbfe((i32)idx[e], 12u, 1u);
             const u32 t = r[e] + mask;
             u[4 * h + e] = ((t ^ mask) + (BrConsts<G::L, G::BGBIT>::offset_plus_round() - own[e])) ^ G::flip();
-        }
-    }
-#elif defined(__HIP_DEVICE_COMPILE__)
-    // (round 4's form, kept for the A/B: -DIYK_FFT_DIFF_R04)
-    // The LDS reads are issued from four assembly blocks with one wait each (left to the compiler, every rotated word was read
-    // and waited for in turn: 16 exposed LDS round trips per polynomial and step; all 32 reads in one block would hold 32
-    // registers the kernel does not have).  Then 4 instructions per coefficient:
-    // mask (1 where X^N = -1 flips the sign), (offset + round - own) - mask, (rot ^ mask) + that, flip.
-    typedef const __attribute__((address_space(3))) u32* lds_u32;
-    const u32 acc_base = (u32)(size_t)(lds_u32)acc_c;
-    const u32 base4 = ((u32)L - abar) << 2;
-    const u32 own_base = acc_base + ((u32)L << 2);
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {   // four blocks of 4 + 2 reads with one wait each: 8 transient registers per block
-        u32 r0 = ((base4 + 256u * (u32)(4 * h + 0)) & 0xFFCu) | acc_base, r1 = ((base4 + 256u * (u32)(4 * h + 1)) & 0xFFCu) | acc_base;
-        u32 r2 = ((base4 + 256u * (u32)(4 * h + 2)) & 0xFFCu) | acc_base, r3 = ((base4 + 256u * (u32)(4 * h + 3)) & 0xFFCu) | acc_base;
-        u64 o01, o23;
-        asm volatile(
-            "ds_read_b32 %0, %0\n" "ds_read_b32 %1, %1\n" "ds_read_b32 %2, %2\n" "ds_read_b32 %3, %3\n"
-            "ds_read2st64_b32 %4, %6 offset0:0 offset1:1\n"
-            "ds_read2st64_b32 %5, %6 offset0:2 offset1:3\n"
-            "s_waitcnt lgkmcnt(0)"
-            : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "=&v"(o01), "=&v"(o23)
-            : "v"(own_base + 1024u * (u32)h)
-            : "memory");
-        const u32 rot[4] = {r0, r1, r2, r3};
-        const u32 own[4] = {(u32)o01, (u32)(o01 >> 32), (u32)o23, (u32)(o23 >> 32)};   // acc_c[L + 64 q]
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int q = 4 * h + e;
-            const u32 mask = (u32)((i32)((base4 + 256u * (u32)q) << 19) >> 31);        // bit 12 of the byte index = bit 10 of the index
-            const u32 c = (BrConsts<G::L, G::BGBIT>::offset_plus_round() - own[e]) - mask;
-            u[q] = ((rot[e] ^ mask) + c) ^ G::flip();
         }
     }
 #else

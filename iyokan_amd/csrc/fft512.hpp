@@ -266,37 +266,26 @@ IYK_HD void lf_bfly_i(cplx& a, cplx& b, double t, double c)
 //   2: (m, m + 2) with zeta^2 | i zeta^2            -> k = 0 mod 4, 2 mod 4 | 1 mod 4, 3 mod 4
 //   3: (m, m + 1) with zeta, i zeta, zeta w, i zeta w -> X[0], X[4] | X[2], X[6] | X[1], X[5] | X[3], X[7]
 // l3a / l3b run between level 2 and the first / second half of level 3 (the kernel fetches the level-3 constants late)
-// IYK_LF_FENCE (opt-in, -DIYK_FFT_LF_FENCE): the scheduler may not mix more than two butterflies.  Written when the forward phase
-// was short of registers; with the half-block key ring it is not, and the unfenced schedule measures 0.5-0.8 % faster
-// (profiles/r05_fft_ab.txt: unf vs lf5).
-#if defined(__HIP_DEVICE_COMPILE__) && defined(IYK_FFT_LF_FENCE)
-#define IYK_LF_FENCE __builtin_amdgcn_sched_barrier(0)
-#else
-#define IYK_LF_FENCE ((void)0)
-#endif
+// (A fenced schedule — at most two butterflies mixed — was written when the forward phase was short of registers; with the half-block
+// key ring it is not, and the unfenced schedule measured 0.5-0.8 % faster: profiles/r05_fft_ab.txt, unf vs lf5.)
 template <class F>
 IYK_HD void tdft8_levels12(cplx (&x)[8], Lf z4, Lf z2, F between)
 {
     lf_bfly(x[0], x[4], z4.t, z4.c);
     lf_bfly(x[1], x[5], z4.t, z4.c);
-    IYK_LF_FENCE;
     lf_bfly(x[2], x[6], z4.t, z4.c);
     lf_bfly(x[3], x[7], z4.t, z4.c);
     between();
-    IYK_LF_FENCE;
     lf_bfly(x[0], x[2], z2.t, z2.c);
     lf_bfly_i(x[4], x[6], z2.t, z2.c);
-    IYK_LF_FENCE;
     lf_bfly(x[1], x[3], z2.t, z2.c);
     lf_bfly_i(x[5], x[7], z2.t, z2.c);
-    IYK_LF_FENCE;
 }
 // level 3 leaves X[0], X[4], X[2], X[6], X[1], X[5], X[3], X[7] in x[0 .. 7]; the callers store / rename through lf_out()
 IYK_HD void tdft8_level3(cplx (&x)[8], Lf z1, Lf z1w)
 {
     lf_bfly(x[0], x[1], z1.t, z1.c);
     lf_bfly_i(x[2], x[3], z1.t, z1.c);
-    IYK_LF_FENCE;
     lf_bfly(x[4], x[5], z1w.t, z1w.c);
     lf_bfly_i(x[6], x[7], z1w.t, z1w.c);
 }

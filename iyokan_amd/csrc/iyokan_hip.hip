@@ -29,7 +29,13 @@
 
 #include "../../include/iyokan_hip.h"
 #include "kernels.hpp"
+#ifdef IYK_EXPERIMENT_KERNELS_FFT   // A/B builds only (tools/ab_*.sh): a header of tools/experiments/ in place of the product's FFT kernels
+#include IYK_EXPERIMENT_KERNELS_FFT
+#define IYK_BUILD_ID_SUFFIX "+x"
+#else
 #include "kernels_fft.hpp"
+#define IYK_BUILD_ID_SUFFIX ""
+#endif
 
 using namespace iyk;
 
@@ -125,7 +131,7 @@ iyk_level_cost default_level_cost(int cus, int path, bool set80)
     c.max_passes = 0;
     if (path != 0)
         while (c.max_passes < 8 && c.pass_ms[c.max_passes] < c.round_ms) ++c.max_passes;
-    std::snprintf(c.build_id, sizeof c.build_id, "%s", IYK_BUILD_ID);
+    std::snprintf(c.build_id, sizeof c.build_id, "%s", IYK_BUILD_ID IYK_BUILD_ID_SUFFIX);
     return c;
 }
 double level_cost_ms(const iyk_level_cost& c, long rot)
@@ -825,7 +831,7 @@ int iyk_hip_fft_round_error(int gpu_index, double* out)
 int iyk_hip_decomposition_levels(void) { return G.init.load() ? (int)G.p.l * (G.use_fp && !G.use_fft ? G.split : 1) : IYK_ERR_STATE; }
 
 /* first 16 hex digits of the SHA-256 over the sources this library was built from (tools/src_hash.py) */
-const char* iyk_hip_build_id(void) { return IYK_BUILD_ID; }
+const char* iyk_hip_build_id(void) { return IYK_BUILD_ID IYK_BUILD_ID_SUFFIX; }
 
 int iyk_hip_rotation_round(int gpu_index)
 {

@@ -1,3 +1,13 @@
+// RECORD OF EXPERIMENTS — not part of the product build or of its build id (tools/src_hash.py reads iyokan_amd/csrc only).
+// This is round 5's kernels_fft.hpp WITH all of its A/B knobs (35 IYK_FFT_* / IYK_LATFFT_* macros): phase-priority assignments,
+// key-ring depths, barrier period, the round-4 forward transform, the phase-stamp builds of tools/ubench/*_trace.hip and the
+// IYK_FFT_TIMING_* builds that compute WRONG results on purpose.  Round 6 took the knobs out of the product header
+// (iyokan_amd/csrc/kernels_fft.hpp now holds the shipped choice only); the A/B scripts (tools/ab_*.sh) and the trace
+// micro-benchmarks build THIS file instead:  -DIYK_EXPERIMENT_KERNELS_FFT='"../../tools/experiments/kernels_fft_r05_knobs.hpp"'
+// (iyokan_hip.hip includes it in place of kernels_fft.hpp, and the library's build id gets the suffix "+x").  It describes round
+// 5's kernel: changes made to the product kernel later are NOT in here.  Knobs of other headers that were removed at the same
+// time (IYK_FFT_DIFF_PLAIN / _R04 in blind_rotate_fft.hpp, IYK_FFT_LF_FENCE in fft512.hpp) are gone for good; their results
+// are in profiles/r05_fft_ab.txt.
 // kernels_fft.hpp — the complex-FFT rotation kernels (fft512.hpp, blind_rotate_fft.hpp).
 //
 //   init        bk_fft_kernel                           torus-domain BK rows -> two spectra (signed 16-bit halves) per polynomial
@@ -14,36 +24,73 @@
 
 #include <type_traits>
 
-#include "blind_rotate_fft.hpp"
-#include "fft256.hpp"
-#include "kernels.hpp"
+#include "../../iyokan_amd/csrc/blind_rotate_fft.hpp"
+#include "../../iyokan_amd/csrc/fft256.hpp"
+#include "../../iyokan_amd/csrc/kernels.hpp"
+
+// A/B knobs of tools/ab_fft_variants.sh (defaults = the shipped kernel).  IYK_FFT_TIMING_* variants compute WRONG results on
+// purpose (they remove one cost to measure it) and never ship.
+#ifndef IYK_FFT_BARRIER_EVERY
+#define IYK_FFT_BARRIER_EVERY 4   // round 5: 4 with the phase priorities below (16 before; 1 .. 8 within 0.5 %, 32 / 64 slower)
+#endif
+// Phase priorities of the throughput kernel (round 5; s_setprio, 14 instructions per CMUX step).  The two waves of a SIMD run the same
+// code, fall into step (the barrier aligns them) and then want the LDS, the texture path and the VALU at the same moments.  With a
+// DIFFERENT arbitration priority in every phase — digits and pass 1 of a forward transform 2, its passes 2 and 3 (the exchanges) 3,
+// the first half of a row's MAC 0, the second half 1, the three passes of a pair of inverse transforms 1 / 0 / 3 — whichever wave is
+// in the plain FMA stream of a MAC yields to its partner's exchange traffic, and the pair settles out of phase: +4.1 .. 4.7 % gates/s
+// at the 128-bit set, +3.9 .. 4.4 % at the 80-bit set on four boxes with the inverse at one level (2); +5.5 .. 5.9 % / +5.1 .. 5.6 %
+// together with the barrier every 4 steps (the waves of a CU drift further apart now, and the barrier is what keeps their key rows in
+// the L1); the inverse's own three levels another +1.5 % / +1.1 %, and pass 1 of the forward transform at 2 instead of 1 after that +1.7 %
+// (a coordinate search: every neighbour of the shipped assignment measured lower).  Any assignment with three or more distinct levels gains 2 .. 3 %,
+// two levels 1.2 %, a split inside the MAC the rest; the ORDER of the levels matters less than that they differ
+// (profiles/r05_prio_ab.txt).  -DIYK_FFT_PRIO_OFF = no priorities (with -DIYK_FFT_BARRIER_EVERY=16: round 5's kernel before this).
+#ifndef IYK_FFT_PRIO_OFF
+#ifndef IYK_FFT_PRIO_FWD
+#define IYK_FFT_PRIO_FWD 2
+#define IYK_FFT_PRIO_FWD2 3
+#define IYK_FFT_PRIO_MAC 0
+#define IYK_FFT_PRIO_MAC2 1
+#define IYK_FFT_PRIO_INVSEG 103   // a pair of inverse transforms: pass 1 / pass 2 / pass 3
+#endif
+#endif
+#ifndef IYK_FFT_KH_AHEAD
+#define IYK_FFT_KH_AHEAD 4   // half blocks of the next row in flight across the transform
+#endif
+#ifndef IYK_FFT_KH_DEPTH
+#define IYK_FFT_KH_DEPTH 5   // half blocks in flight during the MAC (4 .. 7 measure within 1 %; 8 spills: profiles/r05_fft_ab.txt)
+#endif
+#ifdef IYK_FFT_NO_SCHED_BARRIER
+#define IYK_FFT_SB
+#else
+#define IYK_FFT_SB __builtin_amdgcn_sched_barrier(0)
+#endif
 
 namespace iyk {
 
-// The tuned constants of the throughput kernel.  Round 5 found them by same-box A/B over ~35 preprocessor knobs; round 6 took the
-// knobs out of this header: the A/B version of the file — every alternative, the phase-stamp builds of tools/ubench/*_trace.hip and
-// the timing-only builds that compute wrong results on purpose — is tools/experiments/kernels_fft_r05_knobs.hpp, which the A/B
-// scripts build through -DIYK_EXPERIMENT_KERNELS_FFT (a different build id: tools/src_hash.py hashes the flags, too).
-//   FFT_BARRIER_EVERY   steps between the workgroup barriers that keep the eight waves of a CU on the same key rows (the L1 then serves
-//                       seven of eight reads).  4 with the phase priorities (16 before; 1 .. 8 within 0.5 %, 32 / 64 slower).
-//   FFT_PRIO_*          s_setprio levels, 18 instructions per CMUX step.  The two waves of a SIMD run the same code, fall into step
-//                       (the barrier aligns them) and then want the LDS, the texture path and the VALU at the same moments.  With a
-//                       DIFFERENT arbitration priority in every phase — digits and pass 1 of a forward transform 2, its passes 2 and 3
-//                       (the exchanges) 3, the first half of a row's MAC 0, the second half 1, the three passes of a pair of inverse
-//                       transforms 1 / 0 / 3 — whichever wave is in the plain FMA stream of a MAC yields to its partner's exchange
-//                       traffic, and the pair settles out of phase: ~ +9 % gates/s in all (profiles/r05_prio_ab.txt; a coordinate
-//                       search: every neighbour of this assignment measured lower; that the levels DIFFER matters more than their order).
-//   FFT_KH_AHEAD/DEPTH  half blocks of key words in flight across a transform / during a MAC (4 .. 7 within 1 %; 8 spills:
-//                       profiles/r05_fft_ab.txt).
-static constexpr unsigned FFT_BARRIER_EVERY = 4;
-static constexpr int FFT_PRIO_FWD1 = 2, FFT_PRIO_FWD23 = 3, FFT_PRIO_MAC_A = 0, FFT_PRIO_MAC_B = 1;
-static constexpr int FFT_PRIO_INV1 = 1, FFT_PRIO_INV2 = 0, FFT_PRIO_INV3 = 3;
-static constexpr int FFT_KH_AHEAD = 4, FFT_KH_DEPTH = 5;
-// narrow-frontier kernel: a half transform changes level with its segments (before the first exchange / between the exchanges /
-// after the second): forward halves 1 / 3 / 1, inverse halves 0 / 3 / 1; whole-row waves at 1 (profiles/r05_latfft_ab.txt)
-static constexpr int LATFFT_PRIO_FULL = 1, LATFFT_PRIO_F1 = 1, LATFFT_PRIO_F2 = 3, LATFFT_PRIO_F3 = 1;
-static constexpr int LATFFT_PRIO_I1 = 0, LATFFT_PRIO_I2 = 3, LATFFT_PRIO_I3 = 1;
-
+// Phase stamps for tools/ubench/fft_trace.hip only (-DIYK_FFT_TRACE=<step>): s_memtime at the phase boundaries of the FIRST row
+// (unpaired build) or pair (paired build) of that step.  A stamp first waits for every LDS operation in flight, so the interval
+// that ends at it includes the exchange round trip that would otherwise be charged to the next phase's first instruction.
+#ifdef IYK_FFT_TRACE
+// (stamps go straight to memory: twelve 64-bit values held in registers cost the kernel 24 VGPRs it does not have — the first
+// version of this trace ran four times slower than the kernel it was meant to observe)
+#define IYK_FFT_STAMP_AT(k, wait)                                                                              \
+    do { /* unconditional, every row of every step (the last one survives): a branch around it made the allocator spill */ \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        if (wait) __builtin_amdgcn_s_waitcnt(0xC07F);                                                          \
+        ((unsigned long long*)out_index)[(blockIdx.x * BR_WAVES + wave) * 12 + (k)] = __builtin_readcyclecounter(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    } while (0)
+#define IYK_FFT_STAMP(k) IYK_FFT_STAMP_AT(k, true)
+#define IYK_FFT_STAMP_NOWAIT(k) IYK_FFT_STAMP_AT(k, false)
+#else
+#define IYK_FFT_STAMP(k) ((void)0)
+#define IYK_FFT_STAMP_NOWAIT(k) ((void)0)
+#endif
+#ifdef IYK_FFT_TRACE
+#define IYK_FFT_OUT_INDEX(job) (job)   // the trace build borrows out_index for its stamps
+#else
+#define IYK_FFT_OUT_INDEX(job) (out_index ? out_index[job] : job)
+#endif
 
 static constexpr size_t BR_FFT_T1_BYTES = 8 * 64 * sizeof(fft::cplx);
 static constexpr size_t BR_FFT_T2_BYTES = 8 * 8 * sizeof(fft::cplx);
@@ -52,14 +99,6 @@ static constexpr size_t BR_FFT_LDS_BYTES =
     BR_FFT_T1_BYTES + (size_t)BR_WAVES * 2 * NTT_N * sizeof(u32) + (size_t)BR_WAVES * fft::XCHG_BYTES + BR_FFT_T2_BYTES + BR_FFT_LF_BYTES;
 static_assert(BR_FFT_LDS_BYTES <= 160 * 1024, "FFT rotation kernel does not fit the CU's LDS");
 static_assert(BR_FFT_T1_BYTES % 4096 == 0, "diff16 needs every accumulator polynomial 4 KB aligned");
-
-// s_setprio takes an immediate: the level is a template argument
-template <int LEVEL>
-__device__ __forceinline__ void set_prio()
-{
-    static_assert(LEVEL >= 0 && LEVEL <= 3, "s_setprio has four levels");
-    __builtin_amdgcn_s_setprio(LEVEL);
-}
 
 // The lane twiddles of a pass (T1: 8, T2: 7 values of 16 bytes in LDS tables) are read TWO AHEAD of their products: the
 // first two before the DFT8 they follow (they land under its 56 instructions), then one more per product.  Left to the
@@ -137,6 +176,13 @@ __device__ __forceinline__ void fft_forward_b(int lane, fft::cplx (&a)[8], const
     lds_sync();
     fft::fwd_p3(a);
 }
+__device__ __forceinline__ void fft_forward(int lane, fft::cplx (&a)[8], const fft::Twist& u, const fft::cplx* t1_lane,
+                                            const fft::cplx* t2, fft::cplx* xb)
+{
+    fft_forward_a(lane, a, u, t1_lane, xb);
+    fft_forward_b(lane, a, t2, xb, [] {});
+}
+
 // Round 5: the same transform as three twisted DFT8 passes of Linzer-Feig butterflies (fft512.hpp: Lf, tdft8_*): no twiddle
 // layers, 216 instead of 256 arithmetic instructions, 8 instead of 15 table reads.  lf2 = LDS copy of Consts::lf2 ([which][k0]),
 // lf3 = of Consts::lf3 ([which][lane'']).  The level-1 / level-2 constants of a pass are requested BEFORE the exchange reads whose
@@ -184,8 +230,46 @@ __device__ __forceinline__ void fft_forward_lf_b(int lane, fft::cplx (&a)[8], co
 __device__ __forceinline__ void fft_forward_lf(int lane, fft::cplx (&a)[8], const fft::LfU& u, const fft::Lf* lf2, const fft::Lf* lf3,
                                                fft::cplx* xb)
 {
+#ifdef IYK_FFT_TIMING_EARLYREAD
+    // TIMING ONLY (wrong results): every exchange's reads are issued BEFORE the pass that produces the data, so that their latency
+    // runs under that pass's arithmetic — the upper bound of what pairing two rows' transforms can hide (same LDS operations, 32
+    // more registers in flight)
+    fft::cplx b[8];
+    fft::x1_get_b(lane, b, xb);
+    fft::tdft8_levels12(a, fft::Lf{1.0, fft::RSQRT2}, fft::Lf{u.t2, u.c2}, [] {});
+    fft::tdft8_level3(a, fft::Lf{u.t1, u.c1}, fft::Lf{u.t1w, u.c1w});
+#pragma unroll
+    for (int r = 0; r < 8; ++r) xb[fft::x1_wbase(lane) + 72 * fft::lf_out(r)] = a[r];
+    lds_sync();
+    {
+        const fft::Lf* t = lf2 + (lane >> 3);
+        const fft::Lf z4 = t[8 * fft::LF_Z4], z2 = t[8 * fft::LF_Z2];
+        fft::x2_get_c(lane, a, xb);
+        lds_sync();
+        fft::Lf z1, z1w;
+        fft::tdft8_levels12(b, z4, z2, [&] { z1 = t[8 * fft::LF_Z1]; lds_sync(); });
+        z1w = t[8 * fft::LF_Z1W];
+        lds_sync();
+        fft::tdft8_level3(b, z1, z1w);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) xb[fft::x2_wbase(lane) + 9 * fft::lf_out(r)] = b[r];
+    }
+    lds_sync();
+    {
+        const fft::Lf* t = lf3 + lane;
+        const fft::Lf z4 = t[64 * fft::LF_Z4], z2 = t[64 * fft::LF_Z2];
+        lds_sync();
+        fft::Lf z1, z1w;
+        fft::tdft8_levels12(a, z4, z2, [&] { z1 = t[64 * fft::LF_Z1]; lds_sync(); });
+        z1w = t[64 * fft::LF_Z1W];
+        lds_sync();
+        fft::tdft8_level3(a, z1, z1w);
+        fft::lf_natural(a);
+    }
+#else
     fft_forward_lf_a(lane, a, u, xb);
     fft_forward_lf_b(lane, a, lf2, lf3, xb, [] {});
+#endif
 }
 
 // Two independent inverse transforms (the lo and hi halves of one output polynomial) through ONE exchange buffer, software-
@@ -224,12 +308,16 @@ __device__ __forceinline__ void fft_inverse2(int lane, fft::cplx (&a)[8], fft::c
         fft::dft8<true>(x);
         fft::twist8<true>(x, u);
     };
-    p1(a);   // at FFT_PRIO_INV1, set by the caller
+    p1(a);
     p1(b);
-    set_prio<FFT_PRIO_INV2>();
+#ifdef IYK_FFT_PRIO_INVSEG
+    __builtin_amdgcn_s_setprio(IYK_FFT_PRIO_INVSEG / 10 % 10);
+#endif
     p2(a);
     p2(b);
-    set_prio<FFT_PRIO_INV3>();
+#ifdef IYK_FFT_PRIO_INVSEG
+    __builtin_amdgcn_s_setprio(IYK_FFT_PRIO_INVSEG % 10);
+#endif
     p3(a);
     p3(b);
 }
@@ -403,10 +491,16 @@ __global__ __launch_bounds__(64) void bk_fft_kernel(const u32* __restrict__ bk, 
 
 __device__ __forceinline__ int fft_lane_id(int lane0)
 {
+#ifdef IYK_FFT_LANE_R04
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));   // keep lane-dependent address math inside the iteration
+    return lane;
+#else
     (void)lane0;
     int lane;   // volatile: neither hoisted out of the row loop nor merged (hoisted, the lane's address math is live across the step and spills)
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
     return lane;
+#endif
 }
 
 template <class G, bool CHECK>
@@ -458,12 +552,24 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
     // the descriptor's bounds check returns zeros nobody uses).  Round 4 moved whole blocks (4 loads) with 4 blocks = 64 registers in
     // flight at the top of the MAC; 6 half blocks = 48 registers leave room for the level-3 constants of the new forward
     // transform, which otherwise cost 7-11 spilled words of u (ISA: scratch reloads with s_waitcnt vmcnt(0) at the top of every row).
-    constexpr int KH_AHEAD = FFT_KH_AHEAD, KH_DEPTH = FFT_KH_DEPTH, KH_RING = 8;
+    constexpr int KH_AHEAD = IYK_FFT_KH_AHEAD, KH_DEPTH = IYK_FFT_KH_DEPTH, KH_RING = 8;
     static_assert(KH_AHEAD <= KH_DEPTH && KH_DEPTH <= KH_RING, "key ring: ahead <= depth <= 8 half blocks");
     fft::cplx kh[KH_RING][2];
+#if defined(IYK_FFT_TIMING_NOKEYS) || defined(IYK_FFT_TIMING_HALFKEYS)
+#pragma unroll
+    for (int h = 0; h < KH_RING; ++h) kh[h][0] = kh[h][1] = fft::cplx{1.0, 0.5};
+#endif
     auto load_half = [&](fft::cplx (&dst)[2], u32 koff, u32 row_off, int h) {
+#if defined(IYK_FFT_TIMING_NOKEYS)      // TIMING ONLY: no key loads at all (the sums use whatever the registers hold)
+        (void)koff, (void)row_off, (void)h, (void)dst;
+#elif defined(IYK_FFT_TIMING_HALFKEYS)  // TIMING ONLY: every other half block is loaded, the rest reuse stale registers: half the L1 traffic
+        if (h & 1) return;
 #pragma unroll
         for (int e = 0; e < 2; ++e) dst[e] = keys.at_lane(koff, row_off, 2 * (h & 1) + e, h >> 1);
+#else
+#pragma unroll
+        for (int e = 0; e < 2; ++e) dst[e] = keys.at_lane(koff, row_off, 2 * (h & 1) + e, h >> 1);
+#endif
     };
 #pragma unroll
     for (int h = 0; h < KH_AHEAD; ++h) load_half(kh[h], (u32)lane0 * 16u, 0u, h);
@@ -471,17 +577,32 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
 #pragma unroll
         for (int h = 0; h < 16; ++h) {
             const int q = h >> 1;
+#ifndef IYK_FFT_FINE_WAITS
             {   // one s_waitcnt for the half block's two loads instead of one per load: a wait is an issue slot like any other
                 fft::cplx(&k)[2] = kh[h % KH_RING];
                 asm volatile("" : "+v"(k[0].re), "+v"(k[0].im), "+v"(k[1].re), "+v"(k[1].im));
             }
+#endif
 #pragma unroll
             for (int e = 0; e < 2; ++e) fft::cmac<false>(S[h & 1][e][q], a[q], kh[h % KH_RING][e]);
-            if (h == 7) set_prio<FFT_PRIO_MAC_B>();
-            __builtin_amdgcn_sched_barrier(0);
+#ifdef IYK_FFT_PRIO_MAC2
+            if (h == 7) __builtin_amdgcn_s_setprio(IYK_FFT_PRIO_MAC2);
+#endif
+#ifdef IYK_FFT_PRIO_MACPAT   // A/B: priority of half block h + 1 where it differs from h's
+            {
+                constexpr int pat[16] = IYK_FFT_PRIO_MACPAT;
+                if (h < 15 && pat[h + 1] != pat[h]) {   // h is an unrolled loop's counter: the builtin wants a literal
+                    if (pat[h + 1] == 0) __builtin_amdgcn_s_setprio(0);
+                    else if (pat[h + 1] == 1) __builtin_amdgcn_s_setprio(1);
+                    else if (pat[h + 1] == 2) __builtin_amdgcn_s_setprio(2);
+                    else __builtin_amdgcn_s_setprio(3);
+                }
+            }
+#endif
+            IYK_FFT_SB;
             if (h + KH_DEPTH < 16) load_half(kh[(h + KH_DEPTH) % KH_RING], koff, row_off, h + KH_DEPTH);
             else if (h + KH_DEPTH - 16 < KH_AHEAD) load_half(kh[(h + KH_DEPTH) % KH_RING], koff, row_off + 4u * (u32)fft::M, h + KH_DEPTH - 16);
-            __builtin_amdgcn_sched_barrier(0);
+            IYK_FFT_SB;
         }
     };
 
@@ -490,7 +611,7 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
         const u32 ab = ab_next;
         ab_next = abar[i + 1 < n ? i + 1 : i];
         // the eight waves of a CU walk the same key rows: kept in step, the CU's L1 serves seven of eight requests (kernels.hpp)
-        if (i % FFT_BARRIER_EVERY == 0u) asm volatile("s_barrier" ::: "memory");
+        if (i % (u32)(IYK_FFT_BARRIER_EVERY) == 0u) asm volatile("s_barrier" ::: "memory");
 
         fft::cplx S[2][2][8];   // [c'][half][k2]
         u32 u[16];
@@ -507,29 +628,86 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
         for (int r = 0; r < 2 * L; ++r) {
             // the lane id is RECOMPUTED (two v_mbcnt) where it is needed: kept in a register across the step it was the one
             // value the allocator spilled at 256 VGPRs, and its reload (scratch_load + s_waitcnt vmcnt(0)) waited for every key
-            // load in flight, three times per step (round 5)
+            // load in flight, three times per step (round 5; -DIYK_FFT_LANE_R04 = the round-4 form)
             int lane = fft_lane_id(lane0);
             const int c = r >= L ? 1 : 0, lvl = r - c * L;
             if (lvl == 0) fft::diff16<G>(lane, ab, acc_lds + c * NTT_N, u);
             fft::cplx a[8];
             fft::digits8<G>(lvl, u, a);
-            set_prio<FFT_PRIO_FWD1>();
+#ifdef IYK_FFT_FWD_R04
+            fft_forward(lane, a, U, s_t1 + lane, s_t2 + (lane & 7), xb);
+#else
+#ifdef IYK_FFT_TRACE
+            IYK_FFT_STAMP(0);
+            fft_forward_lf_a(lane, a, LU, xb);            // P1 + exchange-1 stores
+            IYK_FFT_STAMP_NOWAIT(1);
+            fft::x1_get_b(lane, a, xb);
+            IYK_FFT_STAMP(2);                             // ... + the round trip of exchange 1
+            {
+                const fft::Lf* t = s_lf2 + (lane >> 3);
+                fft::tdft8_levels12(a, t[8 * fft::LF_Z4], t[8 * fft::LF_Z2], [] {});
+                fft::tdft8_level3(a, t[8 * fft::LF_Z1], t[8 * fft::LF_Z1W]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xb[fft::x2_wbase(lane) + 9 * fft::lf_out(e)] = a[e];
+                lds_sync();
+            }
+            IYK_FFT_STAMP_NOWAIT(3);                      // P2 + exchange-2 stores issued
+            fft::x2_get_c(lane, a, xb);
+            IYK_FFT_STAMP(4);                             // ... + the round trip of exchange 2
+            {
+                const fft::Lf* t = s_lf3 + lane;
+                fft::tdft8_levels12(a, t[64 * fft::LF_Z4], t[64 * fft::LF_Z2], [] {});
+                fft::tdft8_level3(a, t[64 * fft::LF_Z1], t[64 * fft::LF_Z1W]);
+                fft::lf_natural(a);
+            }
+            IYK_FFT_STAMP(5);                             // P3
+#else
+#ifdef IYK_FFT_PRIO_FWD
+            __builtin_amdgcn_s_setprio(IYK_FFT_PRIO_FWD);
+#endif
+#ifdef IYK_FFT_PRIO_FWD2
             fft_forward_lf_a(lane, a, LU, xb);
-            set_prio<FFT_PRIO_FWD23>();
+            __builtin_amdgcn_s_setprio(IYK_FFT_PRIO_FWD2);
+#ifdef IYK_FFT_PRIO_FWD3
+            fft_forward_lf_b(lane, a, s_lf2, s_lf3, xb, [] { __builtin_amdgcn_s_setprio(IYK_FFT_PRIO_FWD3); });
+#else
             fft_forward_lf_b(lane, a, s_lf2, s_lf3, xb, [] {});
-            set_prio<FFT_PRIO_MAC_A>();
+#endif
+#else
+            fft_forward_lf(lane, a, LU, s_lf2, s_lf3, xb);
+#endif
+#ifdef IYK_FFT_PRIO_MAC
+            __builtin_amdgcn_s_setprio(IYK_FFT_PRIO_MAC);
+#endif
+#endif
+#endif
+#ifdef IYK_FFT_TIMING_L1KEYS
+            const u32 row_off = 0u;
+#else
             const u32 row_off = (i * (u32)(2 * L) + (u32)r) * 4u * (u32)fft::M;
+#endif
             const u32 koff = (u32)lane * 16u;   // in-loop: the key loads' + 1024 (q & 3) become immediate offsets (one address register)
 #pragma unroll
             for (int h = KH_AHEAD; h < KH_DEPTH; ++h) load_half(kh[h], koff, row_off, h);
             __builtin_amdgcn_sched_barrier(0);
             mac_row(S, a, koff, row_off);
+#ifdef IYK_FFT_TRACE
+            IYK_FFT_STAMP(6);                             // MAC
+#endif
         }
+#ifdef IYK_FFT_PRIO_INV
+        __builtin_amdgcn_s_setprio(IYK_FFT_PRIO_INV);
+#endif
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
             int lane = fft_lane_id(lane0);
             u32 lo[16];
-            set_prio<FFT_PRIO_INV1>();
+#ifdef IYK_FFT_PRIO_INVB
+            if (cc == 1) __builtin_amdgcn_s_setprio(IYK_FFT_PRIO_INVB);
+#endif
+#ifdef IYK_FFT_PRIO_INVSEG
+            __builtin_amdgcn_s_setprio(IYK_FFT_PRIO_INVSEG / 100 % 10);
+#endif
             fft_inverse2(lane, S[cc][0], S[cc][1], U, s_t1 + lane, s_t2 + (lane & 7), xb);
             if (CHECK) {
                 const double e0 = fft::round_err8(S[cc][0]), e1 = fft::round_err8(S[cc][1]);
@@ -540,6 +718,11 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
             fft::acc_update16(lane, S[cc][1], lo, acc_lds + cc * NTT_N);
         }
         lds_sync();
+#ifdef IYK_FFT_TRACE
+        {
+            IYK_FFT_STAMP(7);                                 // end of the step
+        }
+#endif
     }
 
     if (CHECK && max_err_bits) {   // non-negative doubles order like their bit patterns
@@ -550,11 +733,11 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
     if (live) {
         const int lane = lane0;
         if (trlwe_mode) {  // raw accumulator: TRLWE (a(X), b(X)), 2N words per job
-            u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (2 * NTT_N);
+            u32* out = tlwe1_out + (size_t)(IYK_FFT_OUT_INDEX(job)) * (2 * NTT_N);
             for (int j = lane; j < 2 * NTT_N; j += 64) out[j] = acc_lds[j];
         }
         else {             // sample extract at index 0: a'[0] = a[0], a'[j] = -a[N-j], b' = b[0]
-            u32* out = tlwe1_out + (size_t)(out_index ? out_index[job] : job) * (NTT_N + 1);
+            u32* out = tlwe1_out + (size_t)(IYK_FFT_OUT_INDEX(job)) * (NTT_N + 1);
             for (int j = lane; j < NTT_N; j += 64) out[j] = (j == 0) ? acc_lds[0] : 0u - acc_lds[NTT_N - j];
             if (lane == 0) out[NTT_N] = acc_lds[NTT_N];
         }
@@ -595,6 +778,23 @@ struct BrLatFft {
     __host__ __device__ static constexpr int half_buf(int row, int par) { return NFULL ? 2 * (row - NFULL) + par : row + 4 * par; }
 };
 
+#if !defined(IYK_LATFFT_PRIO_OFF) && !defined(IYK_LATFFT_PRIO_SEGF)
+#define IYK_LATFFT_PRIO_SEGF 131    // digits: levels before the first exchange / between the exchanges / after the second
+#define IYK_LATFFT_PRIO_SEGI 1031   // (a leading 1 keeps a leading zero from making the literal octal)
+#endif
+// Phase stamps for tools/ubench/latfft_trace.hip only (compiled with -DIYK_LATFFT_TRACE=<step>): s_memtime at the phase
+// boundaries of ONE step, written per wave to the buffer passed in place of out_index.  Not part of the product build.
+#ifdef IYK_LATFFT_TRACE
+#define IYK_FTRACE_DECL unsigned long long ftrace_[16] = {}
+#define IYK_FTRACE(k)                                                                                     \
+    do {                                                                                                  \
+        if (i == (u32)(IYK_LATFFT_TRACE)) ftrace_[k] = __builtin_readcyclecounter();                      \
+    } while (0)
+#else
+#define IYK_FTRACE_DECL
+#define IYK_FTRACE(k)
+#endif
+
 template <class G, bool CHECK>
 __global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_kernel(
     const u32* __restrict__ abar_all, int njobs, const fft::cplx* __restrict__ bk_fft, u32 bk_bytes,
@@ -614,9 +814,21 @@ __global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_ker
     fft::cplx* s_h = s_t2 + 64;                                                              // Consts256: inv[2][11][64], fwd[2][11][64]
     static_assert(BR_FFT_T1_BYTES % 8192 == 0, "diff16_doubled needs 8 KB aligned accumulators");
 
+#ifndef IYK_LATFFT_FWD_LF
     if (NFULL)
         for (int e = threadIdx.x; e < 8 * 64; e += M::THREADS) s_t1[e] = C.t1[e >> 6][e & 63];
     if (NFULL && threadIdx.x < 64) s_t2[threadIdx.x] = C.t2t[threadIdx.x >> 3][threadIdx.x & 7];
+#else
+    // A/B only (-DIYK_LATFFT_FWD_LF): the whole rows' forward transform as in the throughput kernel (three twisted DFT8 passes of
+    // Linzer-Feig butterflies, 40 instructions fewer), its constants in place of the T1 table.  Not faster here — 2.565 against
+    // 2.578 ms at 16 rotations, 2.585 against 2.557 at 64, 2.75 against 2.69 at 256 (profiles/r05_latfft_ab.txt): this kernel
+    // waits on exchanges and barriers, not on its instruction count
+    fft::Lf* s_lf3 = reinterpret_cast<fft::Lf*>(s_t1);   // [which][lane'']
+    fft::Lf* s_lf2 = s_lf3 + 4 * 64;                      // [which][k0]
+    (void)s_t2;
+    if (NFULL && threadIdx.x < 4 * 64) s_lf3[threadIdx.x] = C.lf3[threadIdx.x >> 6][threadIdx.x & 63];
+    if (NFULL && threadIdx.x < 4 * 8) s_lf2[threadIdx.x] = C.lf2[threadIdx.x >> 3][threadIdx.x & 7];
+#endif
     {
         const fft::cplx* src = &Cp->h.inv[0][0][0];
         for (int e = threadIdx.x; e < (int)(sizeof(fft::Consts256) / sizeof(fft::cplx)); e += M::THREADS) s_h[e] = src[e];
@@ -650,6 +862,10 @@ __global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_ker
     asm volatile("" : "+v"(in_pos));
     fft::Twist U = C.u;
     asm volatile("" : "+s"(U.c1), "+s"(U.s1), "+s"(U.c2), "+s"(U.s2), "+s"(U.c3), "+s"(U.s3));
+#ifdef IYK_LATFFT_FWD_LF
+    fft::LfU LU = C.lu;
+    asm volatile("" : "+s"(LU.t2), "+s"(LU.c2), "+s"(LU.t1), "+s"(LU.c1), "+s"(LU.t1w), "+s"(LU.c1w));
+#endif
     const fft::Keys keys(bk_fft, bk_bytes, lane0);
     fft::cplx kb[XF][4];                             // this wave's key values of one step: frequency block q = wave
     // One row of a step's key values (4 x 1 KiB per wave).  The eight waves of the CU share ONE texture path (16 cycles per
@@ -678,33 +894,43 @@ __global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_ker
     hfft_twiddles(s_h + (0 + ip) * 11 * 64 + lane0, tinv);
 #pragma unroll
     for (int k = 0; k < 11; ++k) asm volatile("" : "+v"(tinv[k].re), "+v"(tinv[k].im));
+    IYK_FTRACE_DECL;
     u32 ab_next = abar[0];
     for (u32 i = 0; i < n; ++i) {
         const u32 ab = ab_next;
         ab_next = abar[i + 1 < n ? i + 1 : i];
         int lane = lane0;
         asm volatile("" : "+v"(lane));
+        IYK_FTRACE(0);
         // ---- forward
         if (full) {   // row = wave -> spectrum in the wave's buffer, [k2][lane'']
-            // round 5, arbitration priorities (s_setprio; profiles/r05_latfft_ab.txt).  (1) The whole-row wave of a SIMD — the longer job of
-            // the forward phase — runs at level 1 throughout, above the START of its half-row partner (w + 4): 2.579 -> 2.515 ms at 16
-            // rotations.  (2) A half transform changes level with its segments: forward halves 1 / 3 / 1 (before the first exchange /
-            // between the exchanges / after the second), inverse halves 0 / 3 / 1 — the two waves of a SIMD leave a barrier together,
-            // and unequal levels along the code pull them apart (the throughput kernel's finding): 2.515 -> 2.461 ms at 16, 2.51 ->
-            // 2.47 at 64, 80-bit set 1.93 -> 1.85 at 256; nothing at 256 rotations of the 128-bit set.  Segmenting the whole-row
-            // waves as well: slower (2.49).  Round 4 had tried half-row waves up: +3 % time.  (The whole rows' forward transform in
-            // Linzer-Feig form, as in the throughput kernel, is not faster here: this kernel waits on exchanges and barriers.)
-            set_prio<LATFFT_PRIO_FULL>();
+#ifndef IYK_LATFFT_PRIO_OFF   // round 5, arbitration priorities (s_setprio; profiles/r05_latfft_ab.txt).  (1) The whole-row wave of a SIMD
+            // — the longer job of the forward phase — runs at level 1 throughout, above the START of its half-row partner (w + 4):
+            // 2.579 -> 2.515 ms at 16 rotations.  (2) A half transform changes level with its segments: forward halves 1 / 3 / 1
+            // (before the first exchange / between the exchanges / after the second), inverse halves 0 / 3 / 1 — the two waves of a
+            // SIMD leave a barrier together, and unequal levels along the code pull them apart (the throughput kernel's finding):
+            // 2.515 -> 2.461 ms at 16, 2.51 -> 2.47 at 64, 80-bit set 1.93 -> 1.85 at 256; nothing at 256 rotations of the 128-bit
+            // set.  Segmenting the whole-row waves as well: slower (2.49).  Round 4 had tried half-row waves up: +3 % time.
+            __builtin_amdgcn_s_setprio(1);
+#endif
             u32 u[16];
             fft::cplx a[8];
             load_row(i, XF - 2);
             fft::diff16_doubled<G>(lane, ab, acc2 + cF * 2 * NTT_N, u);
             fft::digits8<G>(lvl, u, a);
+            IYK_FTRACE(1);
+#ifndef IYK_LATFFT_FWD_LF
             fft_forward_a(lane, a, U, s_t1 + lane, xbf);
             load_row(i, XF - 1);
             fft_forward_b(lane, a, s_t2 + (lane & 7), xbf, [] {});
+#else
+            fft_forward_lf_a(lane, a, LU, xbf);
+            load_row(i, XF - 1);
+            fft_forward_lf_b(lane, a, s_lf2, s_lf3, xbf, [] {});
+#endif
 #pragma unroll
             for (int q = 0; q < 8; ++q) xbf[q * 64 + lane] = a[q];
+            IYK_FTRACE(2);
         }
         else {        // half fp of row fr -> F_0 resp. W^k' F_1 in the wave's buffer, [a][lane''] (frequency r + 64 a of lane (r0, r1, r2))
             u32 u[8];
@@ -714,16 +940,28 @@ __global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_ker
             hfft_twiddles(s_h + (2 + fp) * 11 * 64 + lane, t);
             fft::diff8_doubled<G>(lane, fp, ab, acc2 + cF * 2 * NTT_N, u);
             fft::digits4<G>(lvl, u, x);
-            set_prio<LATFFT_PRIO_F1>();
-            auto k1 = [&] { load_row(i, XF - 1); set_prio<LATFFT_PRIO_F2>(); };
-            auto k2 = [] { set_prio<LATFFT_PRIO_F3>(); };
+            IYK_FTRACE(1);
+#ifdef IYK_LATFFT_PRIO_SEGF   // A/B: a different priority in every segment of a half transform (a, b, c = the three levels)
+            __builtin_amdgcn_s_setprio(IYK_LATFFT_PRIO_SEGF / 100 % 10);
+            auto k1 = [&] { load_row(i, XF - 1); __builtin_amdgcn_s_setprio(IYK_LATFFT_PRIO_SEGF / 10 % 10); };
+            auto k2 = [] { __builtin_amdgcn_s_setprio(IYK_LATFFT_PRIO_SEGF % 10); };
+#else
+            auto k1 = [&] { load_row(i, XF - 1); };
+            auto k2 = [] {};
+#endif
             if (fp) hfft_forward<1>(HA, x, U, t, k1, k2);
             else hfft_forward<0>(HA, x, U, t, k1, k2);
 #pragma unroll
             for (int q = 0; q < 4; ++q) xbf[q * 64 + in_pos] = x[q];
+            IYK_FTRACE(2);
         }
-        set_prio<0>();
+#if defined(IYK_LATFFT_PRIO_SEGF)
+        __builtin_amdgcn_s_setprio(0);
+#elif !defined(IYK_LATFFT_PRIO_OFF)
+        if (NFULL) __builtin_amdgcn_s_setprio(0);
+#endif
         wg_barrier_lds();
+        IYK_FTRACE(3);
         // ---- MAC: frequency block q = wave of all four sums
         {
             fft::cplx s[4], d[XF], o[XF - NFULL];
@@ -749,7 +987,9 @@ __global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_ker
 #pragma unroll
             for (int pc = 0; pc < 4; ++pc) s_sum[pc * fft::M + wave * 64 + lane] = s[pc];
         }
+        IYK_FTRACE(4);
         wg_barrier_lds();
+        IYK_FTRACE(5);
         // ---- inverse: output parity ip of sum si -> accumulator polynomial si >> 1
         {
             fft::cplx c[8], y[4], t[11];
@@ -757,22 +997,40 @@ __global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_ker
             for (int q = 0; q < 8; ++q) c[q] = s_sum[si * fft::M + q * 64 + in_pos];
 #pragma unroll
             for (int k = 0; k < 11; ++k) t[k] = tinv[k];
-            set_prio<LATFFT_PRIO_I1>();
-            auto k1 = [&] { load_row(i + 1, 0); set_prio<LATFFT_PRIO_I2>(); };
-            auto k2 = [&] { load_row(i + 1, 1); set_prio<LATFFT_PRIO_I3>(); };
+#ifdef IYK_LATFFT_PRIO_SEGI
+            __builtin_amdgcn_s_setprio(IYK_LATFFT_PRIO_SEGI / 100 % 10);
+            auto k1 = [&] { load_row(i + 1, 0); __builtin_amdgcn_s_setprio(IYK_LATFFT_PRIO_SEGI / 10 % 10); };
+            auto k2 = [&] { load_row(i + 1, 1); __builtin_amdgcn_s_setprio(IYK_LATFFT_PRIO_SEGI % 10); };
             auto k3 = [&] { if (XF > 4) load_row(i + 1, 2); };
+#else
+            auto k1 = [&] { load_row(i + 1, 0); };
+            auto k2 = [&] { load_row(i + 1, 1); };
+            auto k3 = [&] { if (XF > 4) load_row(i + 1, 2); };
+#endif
             if (ip) hfft_inverse<1>(HA, c, y, U, t, k1, k2, k3);
             else hfft_inverse<0>(HA, c, y, U, t, k1, k2, k3);
             if (CHECK) {
                 const double e = fft::round_err4(y);
                 worst = e > worst ? e : worst;
             }
+            IYK_FTRACE(6);
             fft::acc_update8_doubled(lane, ip, y, (si & 1) ? 16 : 0, acc2 + (si >> 1) * 2 * NTT_N);
             if (XF > 4) load_row(i + 1, 3);
+            IYK_FTRACE(7);
         }
-        set_prio<0>();
+#ifdef IYK_LATFFT_PRIO_SEGI
+        __builtin_amdgcn_s_setprio(0);
+#endif
         wg_barrier_lds();
+        IYK_FTRACE(8);
     }
+#ifdef IYK_LATFFT_TRACE
+    if (lane0 == 0 && blockIdx.x == 0) {
+        unsigned long long* tr = reinterpret_cast<unsigned long long*>(const_cast<int32_t*>(out_index));
+        for (int k = 0; k < 16; ++k) tr[wave * 16 + k] = ftrace_[k];
+    }
+    out_index = nullptr;
+#endif
     if (CHECK && max_err_bits) {
         unsigned long long b;
         __builtin_memcpy(&b, &worst, 8);

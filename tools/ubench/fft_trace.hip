@@ -8,7 +8,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "../../iyokan_amd/csrc/kernels_fft.hpp"
+#include "../experiments/kernels_fft_r05_knobs.hpp"   // round 5 kernels with their trace / A-B knobs (the product header carries none since round 6)
 
 using namespace iyk;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
