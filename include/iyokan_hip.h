@@ -280,8 +280,9 @@ int iyk_hip_ntt_path(void);
  * 16-bit halves (csrc/fft512.hpp): every inverse-transform output is provably within 2^-8.5 (128-bit set) / 2^-5.1 (80-bit
  * set) of the exact integer sum for ANY key and digits, so rint() makes the product the exact schoolbook
  * one — the same ciphertext words as paths 1 and 0 — at two thirds of the instructions per CMUX step.  The field form of the
- * key stays resident beside the spectra (iyk_hip_resident_key_bytes) so that the field kernels can be forced per batch as a
- * cross-check.  IYK_HIP_NTT = fft / fp / goldilocks at iyk_hip_init selects 2 / 1 / 0; IYK_HIP_ROT_KERNEL = fft / latfft
+ * key is NOT resident on this path (round 6): the first batch that forces a field kernel (IYK_HIP_ROT_KERNEL = w32 / lat3, a
+ * cross-check) builds it on that GPU from a host copy of the torus-domain key — one upload and one transform pass, synchronous —
+ * and iyk_hip_resident_key_bytes grows by it from then on.  IYK_HIP_NTT = fft / fp / goldilocks at iyk_hip_init selects 2 / 1 / 0; IYK_HIP_ROT_KERNEL = fft / latfft
  * forces a batch onto one of the FFT kernels.  With IYK_HIP_DEBUG=1 at init the FFT kernels also record the largest
  * |z - rint(z)| they produced: */
 int iyk_hip_fft_round_error(int gpu_index, double* out);
@@ -335,7 +336,9 @@ int iyk_hip_calibrate(int gpu_index);   /* gpu_index = -1: every GPU, concurrent
  * Valid until the next iyk_hip_init. */
 const char* iyk_hip_init_profile(void);
 
-/* Bytes of device memory holding keys on one GPU (NTT-domain BK + padded KSK + tables). */
+/* Bytes of device memory holding keys on one GPU: the key spectra (FFT path) or the NTT-domain BK (field / integer paths), the
+ * padded KSK and the tables — 179.8 MB at the 128-bit set on the default path — plus, once a cross-check kernel has asked for
+ * it, the field form of the BK (62.5 MB; round 5 built and kept it at init: 242.3 MB). */
 int iyk_hip_resident_key_bytes(uint64_t* out);
 
 #ifdef __cplusplus

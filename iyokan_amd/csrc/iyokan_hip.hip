@@ -164,7 +164,13 @@ struct Global {
     std::vector<Device> devs;
     std::vector<char> peer;       // [a * ngpu + b]: device a reads device b's memory directly (peer access enabled)
     std::atomic<int> nstreams{0};
-    uint64_t key_bytes = 0;
+    uint64_t key_bytes = 0;       // resident key bytes per GPU without the lazily built field key
+    // Round 6: on the FFT path (the default) the field form of the bootstrapping key — 62.5 MB per GPU at the 128-bit set, read only
+    // by the cross-check kernels IYK_HIP_ROT_KERNEL=w32 / lat3 — is built on FIRST USE of such a kernel on a GPU, not at
+    // iyk_hip_init: the torus-domain key stays on the host for that (the caller's arrays may be freed on return).
+    std::vector<u32> bk_torus_host;
+    uint64_t field_key_bytes = 0;
+    std::mutex field_mu;
 } G;
 
 }  // namespace
@@ -290,9 +296,12 @@ int launch_br(iyk_hip_stream* st, int njobs, const RotOut& o)
     return IYK_OK;
 }
 
+int ensure_field_key(int gpu);
+
 template <class DC>
 int launch_br_fp(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
 {
+    if (int rc = ensure_field_key(st->gpu)) return rc;
     const Device& D = G.devs[st->gpu];
     dim3 grid((njobs + BR_WAVES - 1) / BR_WAVES), block(64 * BR_WAVES);
     hipLaunchKernelGGL(blind_rotate_fp_kernel<DC>, grid, block, BR_FP_LDS_BYTES, st->s,
@@ -337,6 +346,7 @@ int launch_br_fft_lat(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
 template <class DC>
 int launch_br_fp_lat3(iyk_hip_stream* st, int first, int njobs, const RotOut& o)
 {
+    if (int rc = ensure_field_key(st->gpu)) return rc;
     const Device& D = G.devs[st->gpu];
     const u32* abar = (const u32*)st->d_abar + (size_t)first * ABAR_STRIDE;
     hipLaunchKernelGGL(blind_rotate_fp_lat3_kernel<DC>, dim3((unsigned)njobs), dim3(BrLat3<DC>::THREADS), BrLat3<DC>::LDS_BYTES,
@@ -656,7 +666,7 @@ int init_devices(std::vector<Device>& devs, const int* device_ids, int avail, co
             return rc;
         }
         INIT_TRY(hipStreamCreateWithFlags(&pd[g].s, hipStreamNonBlocking));
-        INIT_TRY(hipMalloc((void**)&D.bk_ntt, bk_words * sizeof(u64) * (use_fp ? split : 1)));
+        if (!use_fft) INIT_TRY(hipMalloc((void**)&D.bk_ntt, bk_words * sizeof(u64) * (use_fp ? split : 1)));   // FFT path: lazily (ensure_field_key)
         INIT_TRY(hipMalloc((void**)&D.ksk, ksk_pad.size() * sizeof(u32)));
         INIT_TRY(hipMalloc((void**)&D.tw_fwd, NTT_N * sizeof(u64)));
         INIT_TRY(hipMalloc((void**)&D.tw_inv, 2 * NTT_N * sizeof(u64)));
@@ -689,7 +699,9 @@ int init_devices(std::vector<Device>& devs, const int* device_ids, int avail, co
         INIT_TRY(hipMemcpyAsync(D.ksk, ksk_pad.data(), ksk_pad.size() * sizeof(u32), hipMemcpyHostToDevice, s));
         INIT_TRY(hipMemcpyAsync(D.tw_fwd, twf.data(), NTT_N * sizeof(u64), hipMemcpyHostToDevice, s));
         INIT_TRY(hipMemcpyAsync(D.tw_inv, twi.data(), 2 * NTT_N * sizeof(u64), hipMemcpyHostToDevice, s));
-        if (use_fp)
+        if (use_fft)
+            ;   // the field form is built by the first kernel that reads it
+        else if (use_fp)
             hipLaunchKernelGGL(bk_ntt_fp_kernel, dim3((unsigned)((polys * split + 1) / 2)), dim3(64), 0, s, pd[g].d_bk,
                                (double*)D.bk_ntt, (const double*)D.tw_fwd, D.fpc, polys * split, (int)p.l, split,
                                (int)p.Bgbit / 2);
@@ -717,6 +729,49 @@ int init_devices(std::vector<Device>& devs, const int* device_ids, int avail, co
     }
 #undef INIT_TRY
     cleanup();
+    return IYK_OK;
+}
+
+// The field (Z_p, FP64) form of the bootstrapping key on GPU `gpu`, built once on first use when the library runs on the FFT path:
+// upload of the torus-domain key kept on the host, one transform pass, synchronous (a cross-check path: nobody times its first call).
+int ensure_field_key(int gpu)
+{
+    Device& D = G.devs[gpu];
+    if (__atomic_load_n(&D.bk_ntt, __ATOMIC_ACQUIRE)) return IYK_OK;
+    std::lock_guard<std::mutex> lock(G.field_mu);
+    if (D.bk_ntt) return IYK_OK;
+    if (!G.use_fp || G.bk_torus_host.empty()) return fail(IYK_ERR_STATE, "field kernels need the FP64 path's key, which this initialisation does not have");
+    const iyk_params& p = G.p;
+    const size_t bk_words = G.bk_torus_host.size(), polys = bk_words / NTT_N;
+    HIP_TRY(hipSetDevice(D.ordinal));
+    u32* d_bk = nullptr;
+    u64* d_field = nullptr;
+    hipStream_t s = nullptr;
+    auto undo = [&] {
+        if (s) (void)hipStreamDestroy(s);
+        if (d_bk) (void)hipFree(d_bk);
+        if (d_field) (void)hipFree(d_field);
+    };
+#define FIELD_TRY(expr)                                                                   \
+    do {                                                                                  \
+        hipError_t e__ = (expr);                                                          \
+        if (e__ != hipSuccess) {                                                          \
+            undo();                                                                       \
+            return fail(IYK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+        }                                                                                 \
+    } while (0)
+    FIELD_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    FIELD_TRY(hipMalloc((void**)&d_bk, bk_words * sizeof(u32)));
+    FIELD_TRY(hipMalloc((void**)&d_field, bk_words * sizeof(u64) * G.split));
+    FIELD_TRY(hipMemcpyAsync(d_bk, G.bk_torus_host.data(), bk_words * sizeof(u32), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(bk_ntt_fp_kernel, dim3((unsigned)((polys * G.split + 1) / 2)), dim3(64), 0, s, d_bk, (double*)d_field,
+                       (const double*)D.tw_fwd, D.fpc, polys * G.split, (int)p.l, G.split, (int)p.Bgbit / 2);
+    FIELD_TRY(hipGetLastError());
+    FIELD_TRY(hipStreamSynchronize(s));
+#undef FIELD_TRY
+    (void)hipStreamDestroy(s);
+    (void)hipFree(d_bk);
+    __atomic_store_n(&D.bk_ntt, d_field, __ATOMIC_RELEASE);
     return IYK_OK;
 }
 
@@ -985,7 +1040,10 @@ int iyk_hip_resident_key_bytes(uint64_t* out)
 {
     if (!G.init.load()) return fail(IYK_ERR_STATE, "not initialised");
     if (!out) return fail(IYK_ERR_INVALID, "null out");
-    *out = G.key_bytes;
+    uint64_t field = 0;   // the lazily built field key counts once a cross-check kernel has asked for it (on any GPU)
+    for (const Device& D : G.devs)
+        if (G.use_fft && __atomic_load_n(&D.bk_ntt, __ATOMIC_ACQUIRE)) field = G.field_key_bytes;
+    *out = G.key_bytes + field;
     return IYK_OK;
 }
 
@@ -1103,7 +1161,11 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
     G.ksk_stride = stride;
     G.devs = devs;
     G.peer = peer;
-    G.key_bytes = bk_words * sizeof(u64) * (use_fp ? split : 1) + ksk_pad.size() * sizeof(u32) + 2 * NTT_N * sizeof(u64) + G.bk_fft_bytes;
+    G.field_key_bytes = use_fft ? bk_words * sizeof(u64) * split : 0;
+    G.key_bytes = (use_fft ? 0 : bk_words * sizeof(u64) * (use_fp ? split : 1)) + ksk_pad.size() * sizeof(u32) + 2 * NTT_N * sizeof(u64) +
+                  G.bk_fft_bytes;
+    if (use_fft) G.bk_torus_host.assign(bk_torus, bk_torus + bk_words);
+    else G.bk_torus_host.clear();
     G.init.store(true);
     return IYK_OK;
     IYK_API_END
@@ -1122,6 +1184,8 @@ int iyk_hip_cleanup(void)
     }
     for (Device& D : G.devs) D.release();
     G.devs.clear();
+    G.bk_torus_host.clear();
+    G.bk_torus_host.shrink_to_fit();
     G.init.store(false);
     return IYK_OK;
     IYK_API_END

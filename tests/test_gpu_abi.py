@@ -350,3 +350,4 @@ def test_zz_calibrated_cost_table_and_dispatch_threshold(gpu, keys128, oracle128
                              nthreads=os.cpu_count() or 1)
         assert np.array_equal(got[sample], ref[nin:])
     st.destroy()
+
