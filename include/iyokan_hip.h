@@ -87,7 +87,10 @@ const char* iyk_hip_last_error(void);
 int iyk_hip_stream_create(int gpu_index, iyk_hip_stream** out);
 
 /* Adopt an existing hipStream_t (e.g. the one torch.distributed / RCCL work is ordered on)
- * instead of creating one; the caller keeps ownership of hip_stream. */
+ * instead of creating one; the caller keeps ownership of hip_stream.  Everything enqueued through an adopted stream — including
+ * iyk_hip_gate_host, which for such a stream never parks the gate in a coalesced batch and never goes through the pinned mirror: its
+ * result is copied device-to-host straight into `out`, ordered on hip_stream — is complete once hip_stream itself is
+ * (hipStreamSynchronize, a hipEvent, a torch stream): no library-side poll is needed to see it. */
 int iyk_hip_stream_wrap(int gpu_index, void* hip_stream, iyk_hip_stream** out);
 
 /* Replaces cufhe::Stream::Destroy() (/root/reference/src/iyokan_cufhe.hpp:18-21). */
@@ -218,7 +221,9 @@ int iyk_hip_gate_batch(iyk_hip_stream* st, uint32_t* d_arena, uint64_t arena_slo
  * `out` belongs to the library from the call until the stream is seen idle and may be written EARLIER than that poll (when
  * another stream's iyk_hip_stream_sync has to drain the batch that holds this gate).  Threads: a stream is used by one host
  * thread at a time; different streams — of the same GPU too — may be driven from different threads (the parked gates of a GPU
- * are shared state behind one lock).  Destroying a stream with a parked gate completes the gate first. */
+ * are shared state behind one lock per GPU, never held across a blocking wait: a thread draining a batch does not stall the polls
+ * of the others).  Destroying a stream with a parked gate completes the gate first.  Streams adopted with iyk_hip_stream_wrap are
+ * exempt from all of this paragraph (see there). */
 int iyk_hip_gate_host(iyk_hip_stream* st, int op, const uint32_t* in0, const uint32_t* in1,
                       const uint32_t* in2, uint32_t* out);
 

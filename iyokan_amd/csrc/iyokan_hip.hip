@@ -940,12 +940,21 @@ int iyk_hip_calibrate(int gpu_index)
     std::vector<int> rc(n, IYK_OK);
     std::vector<std::string> msg(n);
     std::vector<std::thread> th;
-    for (int g = 0; g < n; ++g)
-        th.emplace_back([g, &rc, &msg] {
-            rc[g] = calibrate_one(g);
-            if (rc[g]) msg[g] = iyk_hip_last_error();
-        });
+    th.reserve(n);   // no reallocation while threads exist
+    bool spawn_failed = false;
+    for (int g = 0; g < n && !spawn_failed; ++g) {
+        try {
+            th.emplace_back([g, &rc, &msg] {
+                rc[g] = calibrate_one(g);
+                if (rc[g]) msg[g] = iyk_hip_last_error();
+            });
+        }
+        catch (...) {   // thread creation failed (resource exhaustion): the ones already running are joined below, never left joinable
+            spawn_failed = true;
+        }
+    }
     for (auto& t : th) t.join();
+    if (spawn_failed) return fail(IYK_ERR_NOMEM, "could not start a calibration thread per GPU");
     for (int g = 0; g < n; ++g)
         if (rc[g]) return fail(rc[g], "calibration of GPU " + std::to_string(g) + ": " + msg[g]);
     return IYK_OK;
@@ -961,8 +970,14 @@ static int calibrate_one(int gpu_index)
     iyk_hip_stream* st = nullptr;
     int rc = stream_new(gpu_index, nullptr, false, &st);
     if (rc) return rc;
+    // (the private stream counts in G.nstreams until done(): an iyk_hip_cleanup racing a calibration is REFUSED with "streams still
+    // alive" instead of freeing the keys under the timed kernels)
     Device& D = G.devs[gpu_index];
-    iyk_level_cost c = D.cost;
+    iyk_level_cost c;
+    {
+        std::lock_guard<std::mutex> lock(G.mu);   // D.cost is read and written under G.mu everywhere else
+        c = D.cost;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto done = [&](int code) {
         if (e0) (void)hipEventDestroy(e0);
@@ -1233,6 +1248,7 @@ static void deliver_gate_result(iyk_hip_stream* st)
 
 int iyk_hip_stream_query(iyk_hip_stream* st)
 {
+    IYK_API_BEGIN   // a poll may flush a coalesced batch (std::vector growth inside): nothing unwinds across the C ABI
     if (!st) return fail(IYK_ERR_INVALID, "null stream");
     if (co_gen_of(st)) {   // a gate of this stream travels in a coalesced batch (iyk_hip_gate_host): idle once that has come back
         const int r = coalescer_poll(st, false);
@@ -1245,10 +1261,12 @@ int iyk_hip_stream_query(iyk_hip_stream* st)
     }
     if (e == hipErrorNotReady) return 0;
     return fail(IYK_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(e));
+    IYK_API_END
 }
 
 int iyk_hip_stream_sync(iyk_hip_stream* st)
 {
+    IYK_API_BEGIN
     if (!st) return fail(IYK_ERR_INVALID, "null stream");
     if (co_gen_of(st)) {
         const int r = coalescer_poll(st, true);
@@ -1257,6 +1275,7 @@ int iyk_hip_stream_sync(iyk_hip_stream* st)
     HIP_TRY(hipStreamSynchronize(st->s));
     deliver_gate_result(st);
     return IYK_OK;
+    IYK_API_END
 }
 
 int iyk_hip_host_alloc(uint64_t bytes, void** out)
@@ -1620,10 +1639,15 @@ struct GateCoalescer {
     uint64_t next_gen = 1;
     size_t max_gates = 2048;
 };
-// One lock for all coalescers: parking, flushing and result hand-over touch state shared by every stream of a GPU, and the callers'
-// streams may live on different host threads (a stream itself is used by one thread at a time, like a hipStream_t's owner).
-std::mutex g_co_mu;
+// One lock PER GPU (round 6, ADVICE r05: it was one for the process): parking, flushing and result hand-over touch state shared by
+// every stream of a GPU, and the callers' streams may live on different host threads (a stream itself is used by one thread at a
+// time, like a hipStream_t's owner).  The lock is never held across a blocking HIP call: coalescer_poll releases it around
+// hipEventSynchronize, and the page-locked batch buffers are sized once, when the coalescer is created.  (An array beside the
+// devices rather than a member: Device stays copyable.)
+std::mutex g_co_mu[MAX_GPUS];
 inline uint64_t co_gen_of(const iyk_hip_stream* st) { return __atomic_load_n(&st->co_gen, __ATOMIC_ACQUIRE); }
+
+int coalescer_reserve(GateCoalescer::Side& sd, size_t gates);
 
 int coalescer_get(int gpu, GateCoalescer** out)
 {
@@ -1643,6 +1667,11 @@ int coalescer_get(int gpu, GateCoalescer** out)
                 return fail(IYK_ERR_HIP, "hipEventCreate");
             }
         if (const char* m = std::getenv("IYK_HIP_COALESCE_MAX")) c->max_gates = (size_t)std::max(1, std::atoi(m));
+        for (auto& sd : c->side)   // both batch buffers at their final size now: no hipHostMalloc / hipFree under the lock later
+            if ((rc = coalescer_reserve(sd, c->max_gates))) {
+                coalescer_free(D);
+                return rc;
+            }
         c->side[0].gen = c->next_gen++;
     }
     *out = D.co;
@@ -1677,9 +1706,15 @@ int coalescer_reserve(GateCoalescer::Side& sd, size_t gates)
     size_t cap = sd.cap ? sd.cap : 256;
     while (cap < gates) cap *= 2;
     u32 *hi = nullptr, *ho = nullptr, *da = nullptr;
-    HIP_TRY(hipHostMalloc((void**)&hi, cap * 3 * n1 * sizeof(u32), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void**)&ho, cap * n1 * sizeof(u32), hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void**)&da, cap * 4 * n1 * sizeof(u32)));
+    hipError_t e = hipHostMalloc((void**)&hi, cap * 3 * n1 * sizeof(u32), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ho, cap * n1 * sizeof(u32), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void**)&da, cap * 4 * n1 * sizeof(u32));
+    if (e != hipSuccess) {   // whatever was allocated before the failure goes back
+        if (hi) (void)hipHostFree(hi);
+        if (ho) (void)hipHostFree(ho);
+        if (da) (void)hipFree(da);
+        return fail(e == hipErrorOutOfMemory ? IYK_ERR_NOMEM : IYK_ERR_HIP, std::string("gate coalescer buffers: ") + hipGetErrorString(e));
+    }
     if (sd.h_in) {   // the side is filling: keep what has been parked so far
         std::memcpy(hi, sd.h_in, sd.ops.size() * 3 * n1 * sizeof(u32));
         (void)hipHostFree(sd.h_in);
@@ -1703,10 +1738,15 @@ int coalescer_flush(GateCoalescer* c)
     int rc = iyk_hip_gate_batch(c->st, sd.d_arena, 4 * sd.cap, count, sd.ops.data(), sd.in0.data(), sd.in1.data(), sd.in2.data(),
                                 sd.out.data());
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(sd.h_out, sd.d_arena + 3 * sd.cap * n1, count * n1 * sizeof(u32), hipMemcpyDeviceToHost, c->st->s));
-    HIP_TRY(hipEventRecord(sd.done, c->st->s));
+    // the gates are on the stream: from here on the side counts as flying, so that a failure below can never send them a second time
     sd.flying = true;
     sd.undelivered = count;
+    hipError_t e = hipMemcpyAsync(sd.h_out, sd.d_arena + 3 * sd.cap * n1, count * n1 * sizeof(u32), hipMemcpyDeviceToHost, c->st->s);
+    if (e == hipSuccess) e = hipEventRecord(sd.done, c->st->s);
+    if (e != hipSuccess) {   // fail hard: wait for what is in flight and take the batch back out of circulation with an error
+        (void)hipStreamSynchronize(c->st->s);
+        return fail(IYK_ERR_HIP, std::string("gate coalescer download: ") + hipGetErrorString(e));
+    }
     other.gen = c->next_gen++;
     other.ops.clear(), other.in0.clear(), other.in1.clear(), other.in2.clear(), other.owner.clear();
     c->open ^= 1;
@@ -1731,15 +1771,25 @@ void coalescer_deliver_all(GateCoalescer::Side& sd)
 }
 
 // 1: the stream's parked gate has finished and `out` is written; 0: not yet; < 0: error.  `block`: wait for it.
+// The GPU's lock is held while shared state is read or changed and RELEASED around every hipEventSynchronize: while one host thread
+// waits for a batch, the polls and gate_host calls of other threads go on (they used to stall for the whole batch).  After a wait the
+// state is looked at afresh — another thread may have delivered this stream's result in the meantime.
 int coalescer_poll(iyk_hip_stream* st, bool block)
 {
-    std::lock_guard<std::mutex> lock(g_co_mu);
+    std::unique_lock<std::mutex> lock(g_co_mu[st->gpu]);
     GateCoalescer* c = G.devs[st->gpu].co;
     if (!c || !st->co_gen) return 1;
     int rc = set_device(st->gpu);
     if (rc) return rc;
     st->co_polls++;
+    auto wait_unlocked = [&](hipEvent_t ev) -> int {
+        lock.unlock();
+        const hipError_t e = hipEventSynchronize(ev);
+        lock.lock();
+        return e == hipSuccess ? IYK_OK : fail(IYK_ERR_HIP, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
+    };
     for (;;) {
+        if (!st->co_gen) return 1;   // delivered by another thread's coalescer_deliver_all while this one waited
         GateCoalescer::Side* sd = nullptr;
         for (auto& x : c->side)
             if (x.gen == st->co_gen) sd = &x;
@@ -1752,13 +1802,20 @@ int coalescer_poll(iyk_hip_stream* st, bool block)
                 // blocked behind the other side: wait for it and hand its results to their owners right away (a ciphertext written
                 // before its stream is polled is within the contract: `out` belongs to the library until the stream is seen idle)
                 GateCoalescer::Side& other = c->side[(sd == &c->side[0]) ? 1 : 0];
-                if (other.flying) HIP_TRY(hipEventSynchronize(other.done));
+                if (other.flying) {
+                    const uint64_t gen = other.gen;
+                    if ((rc = wait_unlocked(other.done))) return rc;
+                    if (other.gen != gen || !other.flying) continue;   // somebody else dealt with it
+                }
                 coalescer_deliver_all(other);
                 continue;
             }
         }
         if (block) {
-            HIP_TRY(hipEventSynchronize(sd->done));
+            const uint64_t gen = sd->gen;
+            if ((rc = wait_unlocked(sd->done))) return rc;
+            if (!st->co_gen) return 1;
+            if (sd->gen != gen || st->co_gen != gen) continue;
         }
         else {
             hipError_t e = hipEventQuery(sd->done);
@@ -1794,12 +1851,17 @@ int iyk_hip_gate_host(iyk_hip_stream* st, int op, const uint32_t* in0, const uin
         deliver_gate_result(st);
     }
     const uint32_t* ins[3] = {in0, in1, in2};
-    if (G.coalesce) {
+    // A stream the caller ADOPTED (iyk_hip_stream_wrap) is one it synchronises natively (hipStreamSynchronize, a torch stream or
+    // event): everything must be observable on that very stream.  So no parking and no pinned mirror for it — H2D, kernels and the
+    // D2H straight into `out`, all ordered on st->s, as before round 5 (a coalesced gate never ran on such a stream,
+    // and an uncoalesced one left its result in the mirror until a library-side poll).
+    const bool direct = !st->owned;
+    if (G.coalesce && !direct) {
         const int need = op == IYK_OP_MUX ? 3 : (op == IYK_OP_NOT || op == IYK_OP_COPY) ? 1 : (op >= 0 && op <= IYK_OP_XNOR) ? 2 : 0;
         if (op < 0 || op >= IYK_OP__COUNT) return fail(IYK_ERR_INVALID, "unknown gate op");
         for (int k = 0; k < need; ++k)
             if (!ins[k]) return fail(IYK_ERR_INVALID, "gate needs more input ciphertexts");
-        std::lock_guard<std::mutex> lock(g_co_mu);
+        std::lock_guard<std::mutex> lock(g_co_mu[st->gpu]);
         GateCoalescer* c = nullptr;
         if ((rc = coalescer_get(st->gpu, &c))) return rc;
         GateCoalescer::Side& sd = c->side[c->open];
@@ -1832,6 +1894,10 @@ int iyk_hip_gate_host(iyk_hip_stream* st, int op, const uint32_t* in0, const uin
         HIP_TRY(hipMemcpyAsync(st->d_scratch + n1, st->h_gate + n1, (size_t)last * n1 * sizeof(u32), hipMemcpyHostToDevice, st->s));
     const int32_t o = 0, opv = op;
     if ((rc = iyk_hip_gate_batch(st, st->d_scratch, 4, 1, &opv, &idx[0], &idx[1], &idx[2], &o))) return rc;
+    if (direct) {   // pageable destination: the runtime stages it, ordered on st->s; the caller's own synchronisation sees it
+        HIP_TRY(hipMemcpyAsync(out, st->d_scratch, n1 * sizeof(u32), hipMemcpyDeviceToHost, st->s));
+        return IYK_OK;
+    }
     HIP_TRY(hipMemcpyAsync(st->h_gate, st->d_scratch, n1 * sizeof(u32), hipMemcpyDeviceToHost, st->s));
     st->gate_out_user = out;
     return IYK_OK;

@@ -475,14 +475,21 @@ inline iyk_level_cost levelCostTable()
         (void)iyk_hip_level_cost_defaults(&c);
         return c;
     }
+    // Start from the compiled-in table and take the first GPU that answers as the base (a failing GPU 0 used to leave
+    // round == 0, and levelCostMs then divided by it); round and pass depend on a GPU's CU count: the smallest ones price a cut.
+    (void)iyk_hip_level_cost_defaults(&c);
+    bool have = false;
     const int ngpu = iyk_hip_num_gpus();
     for (int g = 0; g < ngpu; ++g) {
         iyk_level_cost t{};
-        if (iyk_hip_level_cost_table(g, &t) != IYK_OK) continue;
-        if (g == 0) {
+        if (iyk_hip_level_cost_table(g, &t) != IYK_OK || t.round <= 0 || t.pass <= 0) continue;
+        if (!have) {
             c = t;
+            have = true;
             continue;
         }
+        c.round = std::min(c.round, t.round);
+        c.pass = std::min(c.pass, t.pass);
         c.round_ms = std::max(c.round_ms, t.round_ms);
         for (int j = 0; j < 8; ++j) c.pass_ms[j] = std::max(c.pass_ms[j], t.pass_ms[j]);
         c.max_passes = std::min(c.max_passes, t.max_passes);

@@ -155,6 +155,32 @@ def test_error_codes(gpu, keys128):
     st.destroy()
 
 
+def test_gate_host_on_an_adopted_stream_is_complete_when_that_stream_is(gpu, keys128, oracle128):
+    """a caller that adopted its own hipStream_t (iyk_hip_stream_wrap) and synchronises it natively must find the result
+    of iyk_hip_gate_host in `out` — with the coalescer (the default) the gate used to be parked and never launched until a
+    library-side poll, and without it the result sat in the pinned mirror.  Now such a stream bypasses both: H2D, kernels, D2H into
+    `out`, all on the adopted stream.  Checked with the torch stream's own synchronize and NO iyk_hip_stream_query / _sync."""
+    import ctypes
+
+    import torch
+
+    p = keys128.params
+    cts = client.encrypt_bits(keys128, [1, 0, 1], seed=191)
+    ts = torch.cuda.Stream()
+    st = gpu.Stream(0, hip_stream=ts.cuda_stream)
+    u32p = ctypes.POINTER(ctypes.c_uint32)
+    L = gpu.lib()
+    for op, ins in (("NAND", (0, 1)), ("MUX", (0, 1, 2)), ("NOT", (2,))):
+        out = np.full(p.n + 1, 0xDEADBEEF, dtype=np.uint32)
+        args = [np.ascontiguousarray(cts[i]) for i in ins] + [None] * (3 - len(ins))
+        ptr = [a.ctypes.data_as(u32p) if a is not None else None for a in args]
+        assert L.iyk_hip_gate_host(st.h, OPS[op], ptr[0], ptr[1], ptr[2], out.ctypes.data_as(u32p)) == 0
+        ts.synchronize()                                   # the CALLER's synchronisation only
+        want = oracle128.gate(OPS[op], *[cts[i] for i in ins])
+        assert np.array_equal(out, want), op
+    st.destroy()
+
+
 def test_bulk_slot_io_and_arena_copy(gpu, keys128):
     """upload_slots / download_slots (Mem::set/get of many cells in one transfer) and the device-side copy."""
     st = gpu.Stream(0)
