@@ -117,6 +117,53 @@ def test_frontier_two_ranks_gloo():
     assert got[0][1] == got[1][1] == 2 * 14      # one collective per level per clock
 
 
+def _gloo_worker8(rank, world, port, q):
+    import hashlib
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        nl = N.load_iyokanl1_json(gold("mux-ram-8-16-16.min.json"))
+        req = load_packet(gold("test08.in"))
+        ex = _frontier_vs_sim(nl, input_streams(req), 2, world, rank, dist)
+        # the WHOLE replicated arena, pad slots of ragged levels included: every rank must hold the same bytes
+        q.put((rank, ex.collectives, hashlib.sha256(ex.be.arena.numpy().tobytes()).hexdigest()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frontier_eight_ranks_gloo():
+    """The 8-GPU shape rehearsed where it can be: world_size 8 over gloo on config #3's netlist.  Every rank
+    evaluates its own block [base + r B, base + (r + 1) B) of each level, ONE in-place all-gather per level makes the arenas
+    identical — byte for byte, the pad slots of ragged levels included — every output and register equals the plaintext simulator
+    on every rank, and collectives == levels per clock.  The netlist has levels whose width is not a multiple of 8 (ragged last
+    ranks: exactly what a first 8-rank run would trip on)."""
+    import torch.multiprocessing as mp
+
+    world = 8
+    nl = N.load_iyokanl1_json(gold("mux-ram-8-16-16.min.json"))
+    plan = FrontierPlan(nl, world)
+    widths = [len(L["boot"]) for L in plan.levels]
+    assert any(w % world for w in widths), widths
+    ragged = [L for L in plan.levels if len({len(d[0]) for d in L["rank_desc"]}) > 1]
+    assert ragged, "config #3 must exercise ranks with unequal shares"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=10) for _ in range(world))
+    assert [g[0] for g in got] == list(range(world))
+    assert {g[1] for g in got} == {2 * len(plan.levels)}      # one collective per level per clock, on every rank
+    assert len({g[2] for g in got}) == 1                      # identical arenas
+
+
 def test_plan_shards_are_balanced():
     nl = N.load_iyokanl1_json(gold("mux-ram-8-16-16.min.json"))
     plan = FrontierPlan(nl, 8)

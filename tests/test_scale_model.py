@@ -55,3 +55,47 @@ def test_one_gpu_column_agrees_with_the_bench_lines_and_scaling_has_the_expected
         assert rows["1"]["s_per_clock"] == pytest.approx(nets[net], rel=0.04)
         speedup8 = rows["1"]["s_per_clock"] / rows["8"]["s_per_clock"]
         assert 2.0 < speedup8 < 4.0, (cfg, speedup8)      # deep, thin levels: one narrow-frontier pass per level on any number of GPUs
+
+
+def test_check_compares_a_measured_table_with_the_model(tmp_path, capsys):
+    """tools/scale_model.py --check: the first real SCALE record is compared with the prediction by a program, not in prose
+    (VERDICT r05 #6).  A synthetic table built FROM the model passes; one with a flat N = 8 line at 0.8 efficiency and a config #4
+    clock of 0.2 s is reported as off the model and as missing both numeric targets."""
+    import scale_model
+
+    model_path = os.path.join(ROOT, "profiles", "r05_scale_model.json")
+    cfgs = _load("r05_scale_model.json")["configs"]
+    good = tmp_path / "good.jsonl"
+    with open(good, "w") as f:
+        for n in ("1", "2", "4", "8"):
+            f.write(json.dumps({"n_gpus": int(n), "value": cfgs["2_flat_nand_128bit"]["by_gpus"][n]["strong_gates_per_s"],
+                                "config": {"workload": "65536 NAND 128bit"}}) + "\n")
+        for n in ("1", "8"):
+            f.write(json.dumps({"net": "cahp-system", "gpus": int(n), "s_per_clock": cfgs["4_cahp_system"]["by_gpus"][n]["s_per_clock"]}) + "\n")
+    rows = scale_model.check(str(good), model_path)
+    assert rows and all(v in ("ok", "met") for *_, v in rows), rows
+    assert any("efficiency" in r[0] for r in rows) and any("0.115" in r[0] for r in rows)
+
+    bad = tmp_path / "bad.jsonl"
+    one = cfgs["2_flat_nand_128bit"]["by_gpus"]["1"]["strong_gates_per_s"]
+    with open(bad, "w") as f:
+        f.write(json.dumps({"n_gpus": 1, "value": one, "config": {"workload": "128bit"}}) + "\n")
+        f.write(json.dumps({"n_gpus": 8, "value": 0.8 * 8 * one, "config": {"workload": "128bit"}}) + "\n")
+        f.write(json.dumps({"net": "cahp-system", "gpus": 8, "s_per_clock": 0.2}) + "\n")
+    verdicts = {r[0]: r[3] for r in scale_model.check(str(bad), model_path)}
+    assert verdicts["2_flat_nand_128bit x8 gates/s"] == "OFF MODEL"
+    assert verdicts["target: 2_flat_nand_128bit efficiency >= 0.97 at N = 8"] == "MISSED"
+    assert verdicts["target: config #4 <= 0.115 s per clock at N = 8"] == "MISSED"
+
+
+def test_scale_all_dry_run_prints_every_command():
+    import subprocess
+
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "scale_all.sh"), "/dev/null"], env=dict(os.environ, DRY_RUN="1"),
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    for n in (1, 2, 4, 8):
+        assert f"python bench.py --gpus {n} --params 128bit" in out and f"python bench.py --gpus {n} --params 80bit" in out
+    assert "tools/bench_netlist.py --net cahp-system --gpus 8" in out and "tools/bench_netlist.py --net mux-ram --gpus 1" in out
+    assert "nothing executed" in out

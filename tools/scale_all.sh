@@ -8,6 +8,9 @@
 # from fewer than N devices; this script then stops with status 3 after writing what it has — a partial table is labelled
 # by its last line {"refused": ...}, never silently padded.  The reference takes its GPU count the same way
 # (/root/reference/src/main.cpp:147-148).  GPUS="1 2" restricts the counts (e.g. a 2-GPU box).
+#   DRY_RUN=1 bash tools/scale_all.sh      # print the exact commands, in order, and run nothing (no GPU needed; tests/test_scale_model.py)
+# When the table exists, compare it with the model's prediction: python tools/scale_model.py --check <outfile>
+# (profiles/r05_scale_model.json: flat batches >= 0.97 efficiency at N = 8, config #4 <= 0.115 s per clock at N = 8).
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 out=${1:-gpurun_out/scale_all.jsonl}
 mkdir -p "$(dirname "$out")"; : > "$out"
@@ -15,6 +18,7 @@ GPUS=${GPUS:-"1 2 4 8"}
 NET_GPUS=${NET_GPUS:-"1 8"}
 run() {   # run <label> <cmd...>
   local label=$1; shift
+  if [ -n "$DRY_RUN" ]; then echo "[$label] $*"; return 0; fi
   local line rc
   "$@" > /tmp/scale_all.out 2>/tmp/scale_all.err; rc=$?
   line=$(tail -1 /tmp/scale_all.out)
@@ -29,8 +33,14 @@ run() {   # run <label> <cmd...>
 }
 # FIRST, where the box has more than one GPU: the in-process replica exchange between DISTINCT devices (hipMemcpyPeerAsync over
 # xGMI, iyk_hip_arena_sync_slots_multi) and the concurrent multi-GPU init — the two paths a 1-GPU box can only run aliased
-ndev=$(python -c "import torch; print(torch.cuda.device_count())" 2>/dev/null || echo 0)
-if [ "${ndev:-0}" -ge 2 ]; then
+if [ -n "$DRY_RUN" ]; then
+  echo "[distinct-device tests, only where >= 2 GPUs are visible] python -m pytest tests/test_gpu_zz_debug.py -q -m gpu -k 'fan_out or multi_gpu_init'"
+  ndev=0
+else
+  ndev=$(python -c "import torch; print(torch.cuda.device_count())" 2>/dev/null || echo 0)
+fi
+if [ -n "$DRY_RUN" ]; then :
+elif [ "${ndev:-0}" -ge 2 ]; then
   timeout 900 python -m pytest tests/test_gpu_zz_debug.py -q -m gpu -k "fan_out or multi_gpu_init" > /tmp/scale_all.peer 2>&1; rc=$?
   echo "{\"distinct_device_tests\": \"$(tail -1 /tmp/scale_all.peer | tr -d '"\\' | cut -c1-120)\", \"status\": $rc, \"devices\": $ndev}" >> "$out"
   echo "distinct-device tests: $(tail -1 /tmp/scale_all.peer)"
@@ -47,4 +57,5 @@ for net in mux-ram cahp-system; do
     run "netlist $net x$n" python tools/bench_netlist.py --net $net --gpus $n --clocks ${CLOCKS:-10}
   done
 done
+[ -n "$DRY_RUN" ] && { echo "scale_all: dry run, nothing executed"; exit 0; }
 echo "scale_all: table complete -> $out"

@@ -164,14 +164,64 @@ def model(inputs, exch_lat_us, exch_gbps):
     return res
 
 
+def check(table_path, model_path, tolerance=0.10):
+    """A measured scaling table (tools/scale_all.sh's JSON lines, or the driver's SCALE_rNN.json) against the model's prediction.
+    Returns a list of (label, measured, predicted, verdict) and prints it; the two numeric targets the round-5 review named are
+    judged explicitly: flat batches >= 0.97 efficiency at N = 8, config #4 <= 0.115 s per clock at N = 8."""
+    with open(model_path) as f:
+        model_ = json.load(f)["configs"]
+    lines = []
+    with open(table_path) as f:
+        text = f.read().strip()
+    try:
+        doc = json.loads(text)
+        lines = doc if isinstance(doc, list) else doc.get("runs") or doc.get("results") or [doc]
+    except ValueError:
+        lines = [json.loads(line) for line in text.splitlines() if line.strip().startswith("{")]
+    rows = []
+    flat = {}
+    for d in lines:
+        if not isinstance(d, dict):
+            continue
+        d = d.get("parsed", d)
+        if "n_gpus" in d and "value" in d:
+            cfg = "5_flat_nand_80bit" if "80" in json.dumps(d.get("config", {})) else "2_flat_nand_128bit"
+            n = str(d["n_gpus"])
+            want = model_[cfg]["by_gpus"].get(n, {}).get("strong_gates_per_s")
+            flat.setdefault(cfg, {})[int(n)] = d["value"]
+            ok = want is not None and abs(d["value"] / want - 1.0) <= tolerance
+            rows.append((f"{cfg} x{n} gates/s", d["value"], want, "ok" if ok else "OFF MODEL"))
+        elif "s_per_clock" in d and "net" in d:
+            cfg = {"mux-ram": "3_mux_ram_8_16_16", "cahp-system": "4_cahp_system"}.get(d["net"])
+            n = str(d.get("gpus", d.get("n_gpus", 1)))
+            if cfg:
+                want = model_[cfg]["by_gpus"].get(n, {}).get("s_per_clock")
+                ok = want is not None and abs(d["s_per_clock"] / want - 1.0) <= tolerance
+                rows.append((f"{cfg} x{n} s/clock", d["s_per_clock"], want, "ok" if ok else "OFF MODEL"))
+                if cfg == "4_cahp_system" and n == "8":
+                    rows.append(("target: config #4 <= 0.115 s per clock at N = 8", d["s_per_clock"], 0.115,
+                                 "met" if d["s_per_clock"] <= 0.115 else "MISSED"))
+    for cfg, by_n in flat.items():
+        if 1 in by_n and 8 in by_n:
+            eff = by_n[8] / (8 * by_n[1])
+            rows.append((f"target: {cfg} efficiency >= 0.97 at N = 8", eff, 0.97, "met" if eff >= 0.97 else "MISSED"))
+    for label, got, want, verdict in rows:
+        print(f"{label:58s} measured {got:12.4f}   model/target {want if want is None else round(want, 4)!s:>12}   {verdict}")
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--check", default=None, help="a measured table (scale_all.sh's .jsonl or SCALE_rNN.json) to compare with --out's model")
     ap.add_argument("--measure", default=None, help="GPU box: write the model's inputs to this file")
     ap.add_argument("--inputs", default=os.path.join(ROOT, "gpurun_out", "r05_model_inputs.json"))
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_scale_model.json"))
     ap.add_argument("--exch-lat-us", type=float, default=40.0)
     ap.add_argument("--exch-gbps", type=float, default=45.0)
     args = ap.parse_args()
+    if args.check:
+        rows = check(args.check, args.out)
+        sys.exit(0 if rows and all(v in ("ok", "met") for *_, v in rows) else 1)
     if args.measure:
         measure(args.measure)
         return
