@@ -27,6 +27,7 @@
  *   sample extract idx 0; identity key switch with prec offset 2^(31 - basebit*t)
  */
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -192,6 +193,10 @@ struct orc_fft_ctx* orc_fft_new(const iyk_params* p, const u32* bk);
 void orc_fft_free(struct orc_fft_ctx* c);
 void orc_fft_blind_rotate(struct orc_fft_ctx* c, const u32* tlwe0, u32* acc);
 double orc_fft_worst(const struct orc_fft_ctx* c);
+/* TIMING ONLY (bench.py's fourth CPU-baseline entry): TFHEpp's algorithm — unsplit key, inexact FP64 products, decrypt-equal but NOT
+ * word-equal to everything above; two rotations per call (tfhe_oracle_fft.c, last section); mode 4 of orc_gate_batch_mode */
+struct orc_fft_ctx* orc_fftx_new(const iyk_params* p, const u32* bk);
+void orc_fftx_blind_rotate2(const struct orc_fft_ctx* c, const u32* tlweA, const u32* tlweB, u32* accA, u32* accB);
 
 typedef struct orc_ctx {
     iyk_params p;
@@ -199,6 +204,7 @@ typedef struct orc_ctx {
     orc_ntt* ntt;
     struct orc_fp_ctx* fp; /* NULL when the parameter set does not meet the FP64 field's exactness bound */
     struct orc_fft_ctx* fft; /* NULL when the parameter set is outside tfhe_oracle_fft.c's bound */
+    struct orc_fft_ctx* fftx; /* mode 4 (inexact, timing only): built on first use */
     const u32* bk;   /* torus domain, borrowed: [n][(k+1)l][k+1][N] */
     const u32* ksk;  /* borrowed: [kN][t][2^basebit-1][n+1] */
     u64* bk_ntt;     /* owned, same indexing, oracle's own (bit-reversed) NTT order */
@@ -239,6 +245,7 @@ void orc_free(orc_ctx* c)
     ntt_free(c->ntt);
     orc_fp_free(c->fp);
     orc_fft_free(c->fft);
+    orc_fft_free(c->fftx);
     free(c->bk_ntt);
     free(c);
 }
@@ -447,10 +454,52 @@ void orc_gate_batch(const orc_ctx* c, u32 count, const i32* ops, const i32* in0,
 {
     orc_gate_batch_mode(c, count, ops, in0, in1, in2, outs, arena, nthreads, 0);
 }
+/* mode 4: binary gates only, two at a time through orc_fftx_blind_rotate2 (an odd last gate is paired with itself) */
+static void gate_pair_inexact(const orc_ctx* c, const i32* ops, const i32* in0, const i32* in1, const i32* outs, u32* arena, u32 g0, u32 g1)
+{
+    const iyk_params* p = &c->p;
+    const size_t n1 = p->n + 1;
+    u32* lin = (u32*)malloc(sizeof(u32) * 2 * n1);
+    u32* acc = (u32*)malloc(sizeof(u32) * 2 * (p->k + 1) * p->N);
+    u32* t1 = (u32*)malloc(sizeof(u32) * (p->N + 1));
+    const u32 gs[2] = {g0, g1};
+    for (int e = 0; e < 2; ++e) {
+        i32 sa, sb; u32 off;
+        gate_coeffs(ops[gs[e]], p->mu, &sa, &sb, &off);
+        const u32* a = arena + (size_t)in0[gs[e]] * n1;
+        const u32* b = arena + (size_t)in1[gs[e]] * n1;
+        for (u32 x = 0; x < n1; ++x) lin[e * n1 + x] = (u32)sa * a[x] + (u32)sb * b[x];
+        lin[e * n1 + p->n] += off;
+    }
+    orc_fftx_blind_rotate2(c->fftx, lin, lin + n1, acc, acc + (p->k + 1) * p->N);
+    for (int e = 0; e < (g1 == g0 ? 1 : 2); ++e) {
+        orc_sample_extract0(c, acc + (size_t)e * (p->k + 1) * p->N, t1);
+        orc_keyswitch(c, t1, arena + (size_t)outs[gs[e]] * n1);
+    }
+    free(lin); free(acc); free(t1);
+}
+
 void orc_gate_batch_mode(const orc_ctx* c, u32 count, const i32* ops, const i32* in0, const i32* in1,
                          const i32* in2, const i32* outs, u32* arena, int nthreads, int mode)
 {
     const size_t n1 = c->p.n + 1;
+    if (mode == 4) {
+        for (u32 g = 0; g < count; ++g)
+            if (ops[g] < OP_AND || ops[g] > OP_XNOR) {
+                fprintf(stderr, "tfhe_oracle: mode 4 (TFHEpp's algorithm, timing only) evaluates binary gates only\n");
+                abort();
+            }
+        orc_ctx* cw = (orc_ctx*)c;   /* lazily built, once, before the parallel region */
+        if (!cw->fftx) cw->fftx = orc_fftx_new(&c->p, c->bk);
+        if (!cw->fftx) {
+            fprintf(stderr, "tfhe_oracle: mode 4 is not available for this parameter set\n");
+            abort();
+        }
+        const u32 pairs = (count + 1) / 2;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
+        for (u32 q = 0; q < pairs; ++q) gate_pair_inexact(c, ops, in0, in1, outs, arena, 2 * q, 2 * q + 1 < count ? 2 * q + 1 : 2 * q);
+        return;
+    }
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
     for (u32 g = 0; g < count; ++g) {
         const u32* a = in0[g] >= 0 ? arena + (size_t)in0[g] * n1 : NULL;

@@ -65,7 +65,9 @@ class Oracle:
         lib().orc_gate(self.ctx, int(op), _p(args[0]), _p(args[1]), _p(args[2]), _p(out), int(schoolbook))
         return out
 
-    MODES = {"goldilocks": 0, "schoolbook": 1, "fp": 2, "fft": 3}
+    # 0 .. 3: exact restatements, word-equal to each other.  4: TFHEpp's ALGORITHM (unsplit key, inexact FP64 products, two gates per
+    # call; binary gates only) — decrypt-equal, NOT word-equal; timing only (bench.py's cpu_baseline), never a parity reference
+    MODES = {"goldilocks": 0, "schoolbook": 1, "fp": 2, "fft": 3, "tfhepp_algorithm_inexact": 4}
 
     def has_fft(self):
         """True when the split-key complex-FFT restatement (oracle/tfhe_oracle_fft.c, the GPU's arithmetic) covers this set."""

@@ -193,3 +193,34 @@ def test_adversarial_rows_same_words_in_both_restatements(keys128, oracle128):
     oracle128.gate_batch(ops, in0, in1, in2, out, b, nthreads=nt, mode="fp")
     assert np.array_equal(a, b)
     assert len({a[nin + i].tobytes() for i in range(nin)}) == nin      # nine different outputs: nothing degenerate
+
+
+@pytest.mark.parametrize("which", ["128", "80"])
+def test_tfhepp_algorithm_timing_mode_is_decrypt_equal(which, keys128, keys80, oracle128, oracle80):
+    """Mode 4 of the oracle library (bench.py's fourth cpu_baseline entry, round 6): TFHEpp's ALGORITHM — unsplit key, inexact FP64
+    products, two rotations per call.  It is a TIMING figure, not a parity reference: the claim checked here is the only one made for
+    it — every binary gate kind decrypts to its truth table on fresh encryptions, both parameter sets, odd batch sizes included (the
+    last gate is paired with itself) — plus that the exact modes are NOT affected by it having run."""
+    keys, orc = (keys128, oracle128) if which == "128" else (keys80, oracle80)
+    p = keys.params
+    rng = np.random.default_rng(64 + int(which))
+    kinds = ["AND", "NAND", "ANDNOT", "OR", "NOR", "ORNOT", "XOR", "XNOR", "NAND"]        # 9: odd on purpose
+    nin = 8
+    bits = rng.integers(0, 2, size=nin).astype(np.uint8)
+    in0 = rng.integers(0, nin, size=len(kinds)).astype(np.int32)
+    in1 = rng.integers(0, nin, size=len(kinds)).astype(np.int32)
+    ops = np.array([OPS[k] for k in kinds], dtype=np.int32)
+    out = np.arange(nin, nin + len(kinds), dtype=np.int32)
+    arena = np.zeros((nin + len(kinds), p.n + 1), dtype=np.uint32)
+    arena[:nin] = client.encrypt_bits(keys, bits, seed=65)
+    exact = orc.gate_batch(ops, in0, in1, [-1] * len(kinds), out, arena.copy(), nthreads=os.cpu_count() or 1)
+    fast = orc.gate_batch(ops, in0, in1, [-1] * len(kinds), out, arena.copy(), nthreads=os.cpu_count() or 1,
+                          mode="tfhepp_algorithm_inexact")
+    want = [PLAIN[k](int(bits[a]), int(bits[b])) for k, a, b in zip(kinds, in0, in1)]
+    assert list(client.decrypt_bits(keys, fast[nin:])) == want
+    assert list(client.decrypt_bits(keys, exact[nin:])) == want
+    assert np.array_equal(fast[:nin], arena[:nin])
+    # inexact means: the words MAY differ from the exact ones in their lowest bits — never by more than a rounding each over the
+    # n steps of a rotation plus what the key switch makes of it; far inside the noise (the decrypts above) either way
+    again = orc.gate_batch(ops, in0, in1, [-1] * len(kinds), out, arena.copy(), nthreads=os.cpu_count() or 1)
+    assert np.array_equal(again, exact)
