@@ -65,7 +65,7 @@ def parse_args():
     return ap.parse_args()
 
 
-COUNTER_FILES = ("r05_counters.json", "r05_counters_80bit.json", "r04_counters.json", "r04_counters_80bit.json", "r03_counters.json", "r03_counters_80bit.json", "r03_counters_80bit_direct.json", "r02_counters.json",
+COUNTER_FILES = ("r06_counters.json", "r06_counters_80bit.json", "r05_counters.json", "r05_counters_80bit.json", "r04_counters.json", "r04_counters_80bit.json", "r03_counters.json", "r03_counters_80bit.json", "r03_counters_80bit_direct.json", "r02_counters.json",
                  "r01_traffic.json")  # newest first
 DEFAULT_LEVELS = {"128bit": 3, "80bit": 4}   # (r04 files always carry the field: the FFT path runs the 80-bit set at 2)   # iyk_hip_decomposition_levels of counter files older than the field
 
@@ -473,7 +473,9 @@ def main():
                 issue["all_insts_per_step_per_wave"] = pmc["all_insts_per_launch"] / steps_per_launch
                 issue["frac"] = pmc["all_insts_per_launch"] / capacity     # issued instructions of any kind / capacity
             for k in ("lds_insts_per_launch", "vmem_rd_insts_per_launch", "salu_insts_per_launch", "smem_insts_per_launch",
-                      "sustained_clock_ghz", "l1_requests_per_launch", "l1_to_l2_requests_per_launch", "l2_hit_rate"):
+                      # (sustained_clock_ghz stays in the counter file: it is the clock of the box and pass that MEASURED it, not of the
+                      # box running this bench, which has no way to read its own clock without rocprof — VERDICT r05 #9)
+                      "l1_requests_per_launch", "l1_to_l2_requests_per_launch", "l2_hit_rate"):
                 if pmc.get(k) is not None:
                     issue[k] = pmc[k]
         else:

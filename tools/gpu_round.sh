@@ -2,7 +2,7 @@
 # One GPU call at round end (through gpurun): the whole GPU test suite, the three profile rounds (128-bit, 80-bit, 80-bit direct),
 # the netlist benches with both level plans, and the bench lines with the counters just measured.  bash tools/gpu_round.sh <tag>
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
-T=${1:-r05}
+T=${1:-r06}
 timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/${T}_gputests.txt 2>&1
 tail -3 gpurun_out/${T}_gputests.txt
 bash tools/profile_round.sh ${T} > gpurun_out/${T}_profile_round.log 2>&1
@@ -22,7 +22,7 @@ for t in ('${T}','${T}_80bit'):
 "
 head -8 gpurun_out/${T}_kernel_trace.txt
 # bench lines WITH the counters just measured (bench.py reads profiles/: copy first)
-cp gpurun_out/${T}_counters.json profiles/r05_counters.json; cp gpurun_out/${T}_80bit_counters.json profiles/r05_counters_80bit.json
+cp gpurun_out/${T}_counters.json profiles/r06_counters.json; cp gpurun_out/${T}_80bit_counters.json profiles/r06_counters_80bit.json
 python bench.py 2>/dev/null | tail -1 > gpurun_out/${T}_bench_final.json
 python bench.py --params 80bit 2>/dev/null | tail -1 > gpurun_out/${T}_80bit_bench_final.json
 python -c "

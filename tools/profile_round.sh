@@ -2,11 +2,11 @@
 # One-shot profile of the headline workload on the GPU box (run through gpurun):
 #   bash tools/profile_round.sh <tag>
 # writes gpurun_out/<tag>_bench.json, <tag>_kernel_trace.txt, <tag>_pmc.txt, <tag>_counters.json
-# (copy the ones to keep into profiles/; bench.py reads profiles/r05_counters.json and uses it only while its build_id —
+# (copy the ones to keep into profiles/; bench.py reads profiles/r06_counters.json and uses it only while its build_id —
 # the hash of the kernel sources, tools/src_hash.py — equals the loaded library's).  Counters are collected in their own
 # --pmc passes, never together with trace domains.  PARAMS=80bit profiles the 80-bit set; DECOMP=direct its opt-in
 # direct decomposition (bench.py --decomp).
-tag=${1:-r05}
+tag=${1:-r06}
 PARAMS=${PARAMS:-128bit}
 DEC=${DECOMP:+--decomp $DECOMP}
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
