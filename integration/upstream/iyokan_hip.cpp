@@ -536,6 +536,15 @@ public:
 
     ~HIPFrontend()
     {
+        // The networks go FIRST: their tasks own device scratch (the CMUX-memory pair) and may still share a worker's stream or
+        // frontier batch, and iyk_hip_cleanup refuses to run while a stream or buffer of the library is alive.  (Members are
+        // destroyed after this body — with the clean-up here and the networks there, every run ended in "streams still alive";
+        // found by EXECUTING this frontend under upstream's engine, tests/upstream_exec/frontend_exec.cpp.  cuFHE's CleanUp does
+        // not check, so the reference's order, /root/reference/src/iyokan_cufhe.cpp:718-722, gets away with it.)
+        toCPU_.clear();
+        toGPU_.clear();
+        gpuNets_.clear();
+        cpuNets_.clear();
         if (gpuReady_)
             hipbackend::cleanUp();
     }

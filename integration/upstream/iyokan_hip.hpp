@@ -220,7 +220,9 @@ public:
 
     bool hasFinished() const override
     {
-        return batch_ ? batch_->finished(generation_) : wi_.stream->idle();
+        if (batch_)
+            return batch_->finished(generation_);
+        return !wi_.stream || wi_.stream->idle();   // not started (or already retired): nothing in flight
     }
 
     void onBeforePropagate() override
@@ -229,6 +231,10 @@ public:
             batch_->result(index_, output());
         else
             output() = *wi_.result;
+        // the worker's stream, staging and batch are the WORKER's: a retired task must not keep them alive past the runner
+        // (iyk_hip_cleanup refuses to run while a stream exists)
+        batch_.reset();
+        wi_ = HIPWorkerInfo{};
     }
 
     template <class Archive>

@@ -91,7 +91,7 @@ struct lweKey {
 struct SecretKey {
     lweKey key;
     SecretKey();
-    template <class Archive> void serialize(Archive&) {}
+    template <class Archive> void serialize(Archive& ar) { ar(key.lvl0, key.lvl1, key.lvl2); }
 };
 struct EvalKey {
     // storage for the two keys the gate-bootstrapping path uses, under the member names TFHEpp's EvalKey gives them; empty
@@ -109,7 +109,7 @@ struct EvalKey {
     template <class P> const BootstrappingKey<P>& getbk() const;
     template <class P> const BootstrappingKeyFFT<P>& getbkfft() const;
     template <class P> const KeySwitchingKey<P>& getiksk() const;
-    template <class Archive> void serialize(Archive&) {}
+    template <class Archive> void serialize(Archive& ar) { ar(bklvl01, iksklvl10); }
 };
 
 template <class P> void HomCONSTANTONE(TLWE<P>&);

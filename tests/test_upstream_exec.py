@@ -11,6 +11,7 @@ import json
 import os
 import shutil
 import subprocess
+import sys
 
 import pytest
 
@@ -30,6 +31,14 @@ def _build(out, san):
     r = subprocess.run(["make", "-j8", "-C", EXEC, f"OUT={out}", f"SAN={san}"], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout + r.stderr)[-6000:]
     return os.path.join(out, "test0_hip_exec")
+
+
+# (blueprint, request, expected result, cycles): the reference's own integration vectors without CMUX memories
+# (/root/reference/test.rb:426-453,547-548), small enough for the CPU oracle behind the mock
+FRONTEND_CASES = [("const-4bit", "test22", 1, ("batch",)), ("addr-4bit", "test04", 1, ("batch", "per_gate")),
+                  ("pass-addr-pass-4bit", "test04", 1, ("batch",)), ("addr-register-4bit", "test16", 3, ("batch", "per_gate")),
+                  ("div-8bit", "test05", 1, ("batch",)), ("counter-4bit", "test13", 3, ("batch", "per_gate")),
+                  ("dff-reset", "test23", 1, ("per_gate",))]
 
 
 def _run(exe, extra_env=None, timeout=1500):
@@ -75,6 +84,45 @@ def test_upstreams_tests_pass_with_the_hip_plugin_under_upstreams_engine(exec_bi
     """testNOT / testMUX / testBinopGates / six JSON circuits / testSequentialCircuit / 4-bit counter / PrioritySetVisitor / bridges
     with HIPNetworkBuilder, through HIPBatchWorker and through 240 HIPWorkers; then fresh encryptions; then both runners."""
     _check_report(_run(exec_binary))
+
+
+@pytest.mark.parametrize("blueprint,vector,cycles,flavours", FRONTEND_CASES, ids=[c[0] + "-" + c[1] for c in FRONTEND_CASES])
+def test_upstream_frontend_flow_reproduces_the_reference_vectors(exec_binary, tmp_path, blueprint, vector, cycles, flavours):
+    """`doHIP(Options)` of integration/upstream/iyokan_hip.cpp — the s/cufhe/hip/ twin of `iyokan tfhe --enable-gpu`
+    (/root/reference/src/iyokan_cufhe.cpp:244-304,729-832,880-894) — EXECUTED: upstream's NetworkBlueprint reads the reference's TOML
+    blueprint, upstream's readers build one HIP network per [[file]], [connect] is wired, priorities set, the reset cycle and the
+    clocks run on upstream's NetworkRunner with this plugin's workers, and the result packet equals the reference's expected one
+    (test/out/*.out), for both worker flavours.  The request travels as a PlainPacket archive written by iyokan_amd/packet.py and read
+    by upstream's own PlainPacket::serialize (through the cereal stand-in), the result the other way: the member order of this
+    repository's packet format is checked against upstream's code on the way.  Executing this found a real defect: ~HIPFrontend
+    released the library before the networks whose tasks still shared the workers' streams ("streams still alive" on every run)."""
+    sys.path.insert(0, ROOT)
+    from iyokan_amd.packet import PlainPacket
+
+    exe = os.path.join(os.path.dirname(exec_binary), "frontend_exec")
+    request = PlainPacket.load(os.path.join(REF, "test", "in", vector + ".in"))
+    expected = PlainPacket.load(os.path.join(REF, "test", "out", vector + ".out"))
+    for flavour in flavours:
+        work = tmp_path / flavour
+        work.mkdir()
+        (work / "request.plain").write_bytes(request.to_archive())
+        env = dict(os.environ, IYK_EXEC_SEED="20260930", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+        env.pop("IYOKAN_HIP_PER_GATE", None)
+        if flavour == "per_gate":
+            env["IYOKAN_HIP_PER_GATE"] = "1"
+        r = subprocess.run([exe, os.path.join("test", "config-toml", blueprint + ".toml"), str(work / "request.plain"),
+                            str(work / "result.plain"), str(cycles), str(work)], cwd=REF, env=env, capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+        assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+        got = PlainPacket.from_archive((work / "result.plain").read_bytes())
+        assert got.same_content(expected), (flavour, got.bits, expected.bits)
+        stats = json.loads(r.stdout.strip().splitlines()[-1])
+        assert (stats["live_streams"], stats["live_arenas"], stats["live_pinned"]) == (0, 0, 0)
+        if flavour == "per_gate":
+            assert stats["gate_batches"] == 0
+        else:
+            assert stats["gate_host_calls"] == 0
 
 
 def test_the_harness_notices_a_wrong_gate(exec_binary):
