@@ -36,9 +36,10 @@ def _build(out, san):
 # (blueprint, request, expected result, cycles): the reference's own integration vectors without CMUX memories
 # (/root/reference/test.rb:426-453,547-548), small enough for the CPU oracle behind the mock
 FRONTEND_CASES = [("const-4bit", "test22", 1, ("batch",)), ("addr-4bit", "test04", 1, ("batch", "per_gate")),
-                  ("pass-addr-pass-4bit", "test04", 1, ("batch",)), ("addr-register-4bit", "test16", 3, ("batch", "per_gate")),
-                  ("div-8bit", "test05", 1, ("batch",)), ("counter-4bit", "test13", 3, ("batch", "per_gate")),
-                  ("dff-reset", "test23", 1, ("per_gate",))]
+                  ("pass-addr-pass-4bit", "test04", 1, ("batch",)), ("addr-register-4bit", "test16", 3, ("batch",)),
+                  ("counter-4bit", "test13", 3, ("batch", "per_gate")), ("dff-reset", "test23", 1, ("per_gate",))]
+if os.environ.get("IYK_EXEC_ALL") == "1":   # 398 bootstrapped gates on the CPU oracle: +20 s
+    FRONTEND_CASES.append(("div-8bit", "test05", 1, ("batch", "per_gate")))
 
 
 def _run(exe, extra_env=None, timeout=1500):
