@@ -471,12 +471,12 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
 #pragma unroll
         for (int h = 0; h < 16; ++h) {
             const int q = h >> 1;
-            {   // one s_waitcnt for the half block's two loads instead of one per load: a wait is an issue slot like any other
-                fft::cplx(&k)[2] = kh[h % KH_RING];
-                asm volatile("" : "+v"(k[0].re), "+v"(k[0].im), "+v"(k[1].re), "+v"(k[1].im));
-            }
+            // One s_waitcnt for the half block's two loads instead of one per load (a wait is an issue slot like any other): the LATER
+            // load's value is used first — loads return in order, so the wait for it covers the earlier one.  (Round 5 forced the single
+            // wait with an empty asm block that claimed all four registers; the compiler then put an s_nop behind every one of them: 15
+            // per row, 90 per CMUX step.)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) fft::cmac<false>(S[h & 1][e][q], a[q], kh[h % KH_RING][e]);
+            for (int e = 1; e >= 0; --e) fft::cmac<false>(S[h & 1][e][q], a[q], kh[h % KH_RING][e]);
             if (h == 7) set_prio<FFT_PRIO_MAC_B>();
             __builtin_amdgcn_sched_barrier(0);
             if (h + KH_DEPTH < 16) load_half(kh[(h + KH_DEPTH) % KH_RING], koff, row_off, h + KH_DEPTH);
