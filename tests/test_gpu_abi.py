@@ -181,6 +181,65 @@ def test_gate_host_on_an_adopted_stream_is_complete_when_that_stream_is(gpu, key
     st.destroy()
 
 
+def test_gate_host_from_two_host_threads(gpu, keys128, oracle128):
+    """the parked gates of a GPU are shared state behind a lock that one host thread used to hold for a whole batch while it
+    waited.  Two host threads, each with its own streams (a stream is used by one thread at a time: the contract), park gates, poll and
+    block concurrently — one mostly through iyk_hip_stream_sync (the blocking path that now drops the lock around its wait), the other
+    by polling.  Every result must be the oracle's, nothing may deadlock, and cleanup-relevant state must be consistent afterwards
+    (the module's fixture tears the library down after this test)."""
+    import ctypes
+    import threading
+
+    p = keys128.params
+    L = gpu.lib()
+    u32p = ctypes.POINTER(ctypes.c_uint32)
+    rng = np.random.default_rng(2026)
+    bits = rng.integers(0, 2, size=8).astype(np.uint8)
+    cts = client.encrypt_bits(keys128, bits, seed=2027)
+    kinds = ["NAND", "XOR", "ORNOT", "AND"]
+    want = {(k, a, b): oracle128.gate(OPS[k], cts[a], cts[b]) for k in kinds for a in range(8) for b in range(8) if (a + 3 * b) % 5 == 0}
+    jobs = sorted(want)
+    errors = []
+
+    def worker(tid, blocking):
+        try:
+            streams = [gpu.Stream(0) for _ in range(6)]
+            outs = [np.zeros(p.n + 1, dtype=np.uint32) for _ in streams]
+            for rnd in range(6):
+                mine = [jobs[(tid * 7 + rnd * len(streams) + i) % len(jobs)] for i in range(len(streams))]
+                for st, out, (k, a, b) in zip(streams, outs, mine):
+                    out[:] = 0xDEADBEEF
+                    rc = L.iyk_hip_gate_host(st.h, OPS[k], cts[a].ctypes.data_as(u32p), cts[b].ctypes.data_as(u32p), None,
+                                             out.ctypes.data_as(u32p))
+                    assert rc == 0, L.iyk_hip_last_error()
+                if blocking:
+                    for st in streams:
+                        st.sync()
+                else:
+                    pending = set(range(len(streams)))
+                    spins = 0
+                    while pending:
+                        for i in list(pending):
+                            if streams[i].query():
+                                pending.discard(i)
+                        spins += 1
+                        assert spins < 5_000_000, "a parked gate never came back"
+                for out, job in zip(outs, mine):
+                    assert np.array_equal(out, want[job]), (tid, rnd, job)
+            for st in streams:
+                st.destroy()
+        except BaseException as e:   # noqa: BLE001 - reported on the main thread
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(0, True)), threading.Thread(target=worker, args=(1, False))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+        assert not t.is_alive(), "deadlock between two host threads driving iyk_hip_gate_host"
+    assert not errors, errors
+
+
 def test_bulk_slot_io_and_arena_copy(gpu, keys128):
     """upload_slots / download_slots (Mem::set/get of many cells in one transfer) and the device-side copy."""
     st = gpu.Stream(0)
