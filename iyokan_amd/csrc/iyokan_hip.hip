@@ -1881,17 +1881,30 @@ int iyk_hip_gate_host(iyk_hip_stream* st, int op, const uint32_t* in0, const uin
         return IYK_OK;
     }
     if (!st->d_scratch) HIP_TRY(hipMalloc((void**)&st->d_scratch, 4 * n1 * sizeof(u32)));
-    if (!st->h_gate) HIP_TRY(hipHostMalloc((void**)&st->h_gate, 4 * n1 * sizeof(u32), hipHostMallocDefault));
     int32_t idx[3] = {-1, -1, -1};
-    int last = 0;
-    for (int k = 0; k < 3; ++k)
-        if (ins[k]) {
-            std::memcpy(st->h_gate + (k + 1) * n1, ins[k], n1 * sizeof(u32));
-            idx[k] = k + 1;
-            last = k + 1;
-        }
-    if (last)   // ONE pinned transfer for all operands
-        HIP_TRY(hipMemcpyAsync(st->d_scratch + n1, st->h_gate + n1, (size_t)last * n1 * sizeof(u32), hipMemcpyHostToDevice, st->s));
+    if (direct) {
+        // Straight from the caller's (pageable) arrays: the runtime reads a pageable source before hipMemcpyAsync returns ("the inputs
+        // are copied before the call returns"), and nothing of the library's is reused between two calls — a caller may queue gate
+        // after gate on an adopted stream without synchronising in between (a shared pinned mirror would be overwritten while the
+        // previous call's upload still read it)
+        for (int k = 0; k < 3; ++k)
+            if (ins[k]) {
+                HIP_TRY(hipMemcpyAsync(st->d_scratch + (k + 1) * n1, ins[k], n1 * sizeof(u32), hipMemcpyHostToDevice, st->s));
+                idx[k] = k + 1;
+            }
+    }
+    else {
+        if (!st->h_gate) HIP_TRY(hipHostMalloc((void**)&st->h_gate, 4 * n1 * sizeof(u32), hipHostMallocDefault));
+        int last = 0;
+        for (int k = 0; k < 3; ++k)
+            if (ins[k]) {
+                std::memcpy(st->h_gate + (k + 1) * n1, ins[k], n1 * sizeof(u32));
+                idx[k] = k + 1;
+                last = k + 1;
+            }
+        if (last)   // ONE pinned transfer for all operands
+            HIP_TRY(hipMemcpyAsync(st->d_scratch + n1, st->h_gate + n1, (size_t)last * n1 * sizeof(u32), hipMemcpyHostToDevice, st->s));
+    }
     const int32_t o = 0, opv = op;
     if ((rc = iyk_hip_gate_batch(st, st->d_scratch, 4, 1, &opv, &idx[0], &idx[1], &idx[2], &o))) return rc;
     if (direct) {   // pageable destination: the runtime stages it, ordered on st->s; the caller's own synchronisation sees it

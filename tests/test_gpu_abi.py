@@ -178,6 +178,17 @@ def test_gate_host_on_an_adopted_stream_is_complete_when_that_stream_is(gpu, key
         ts.synchronize()                                   # the CALLER's synchronisation only
         want = oracle128.gate(OPS[op], *[cts[i] for i in ins])
         assert np.array_equal(out, want), op
+    # gate after gate WITHOUT synchronising in between: nothing of the library's may be shared between two calls in flight
+    outs = [np.full(p.n + 1, 0xDEADBEEF, dtype=np.uint32) for _ in range(4)]
+    pairs = [(0, 1), (1, 2), (2, 0), (1, 1)]
+    keep = []
+    for out, (a, b) in zip(outs, pairs):
+        xa, xb = np.ascontiguousarray(cts[a]), np.ascontiguousarray(cts[b])
+        keep += [xa, xb]
+        assert L.iyk_hip_gate_host(st.h, OPS["XNOR"], xa.ctypes.data_as(u32p), xb.ctypes.data_as(u32p), None, out.ctypes.data_as(u32p)) == 0
+    ts.synchronize()
+    for out, (a, b) in zip(outs, pairs):
+        assert np.array_equal(out, oracle128.gate(OPS["XNOR"], cts[a], cts[b])), (a, b)
     st.destroy()
 
 
