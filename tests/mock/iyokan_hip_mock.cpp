@@ -315,6 +315,16 @@ int iyk_hip_stream_query(iyk_hip_stream* st)
     return 0;
 }
 
+int iyk_hip_stream_sync(iyk_hip_stream* st)
+{
+    REQUIRE_INIT();
+    REQUIRE_STREAM(st);
+    while (!st->idle())
+        std::this_thread::yield();
+    st->gateInFlight = false;
+    return IYK_OK;
+}
+
 int iyk_hip_stream_gpu(iyk_hip_stream* st)
 {
     REQUIRE_STREAM(st);

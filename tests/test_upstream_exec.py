@@ -126,6 +126,35 @@ def test_upstream_frontend_flow_reproduces_the_reference_vectors(exec_binary, tm
             assert stats["gate_host_calls"] == 0
 
 
+def test_tfhepp_crosscheck_tool_dry_run_and_key_import(exec_binary, tmp_path):
+    """tools/tfhepp_crosscheck.cpp — the ciphertext-level cross-check written for a REAL TFHEpp checkout ("220 lines, never
+    compiled") — built against the stand-ins and RUN: with stand-in TFHEpp = CPU oracle = mock GPU it must report every output word
+    identical for all ten gate kinds and exit 0, which keeps the tool's own logic (key hand-over to iyk_hip_init, the gate list, the
+    comparison, the archive writing) from rotting.  It says NOTHING about real TFHEpp.  The two key archives it writes through
+    cereal-format `serialize` calls are then read back by iyokan_amd/tfhepp_keys.py — an archive this repository's writer did not
+    assemble — and verified cryptographically against the secret key."""
+    sys.path.insert(0, ROOT)
+    exe = os.path.join(os.path.dirname(exec_binary), "tfhepp_crosscheck_dry")
+    r = subprocess.run([exe, "2"], cwd=str(tmp_path), env=dict(os.environ, IYK_EXEC_SEED="20260931"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "-> same" in r.stdout and "all decryptions agree" in r.stdout
+    rows = [l.split() for l in r.stdout.splitlines() if l.split() and l.split()[0] in
+            ("AND", "NAND", "ANDNOT", "OR", "NOR", "ORNOT", "XOR", "XNOR", "MUX", "NOT")]
+    assert len(rows) == 10 and all(row[1] == "2/2" and row[2] == "0" for row in rows), r.stdout
+
+    import numpy as np
+
+    from iyokan_amd import tfhepp_keys
+    from iyokan_amd.params import params_128bit
+
+    p = params_128bit()
+    bk, ksk = tfhepp_keys.read_eval_key((tmp_path / "crosscheck_ek.tfhepp").read_bytes(), p)
+    s0, s1 = tfhepp_keys.read_secret_key((tmp_path / "crosscheck_sk.tfhepp").read_bytes(), p)
+    assert bk.size == p.bk_words and ksk.size == p.N * p.t * 3 * (p.n + 1)
+    assert set(np.unique(s0)) <= {0, 1} and set(np.unique(s1)) <= {0, 1}
+    assert tfhepp_keys.verify(p, s0, s1, bk, ksk)
+
+
 def test_the_harness_notices_a_wrong_gate(exec_binary):
     """Negative control: with the mock computing AND for NAND the very same binary must die in one of upstream's assertions."""
     r = _run(exec_binary, {"IYK_MOCK_SABOTAGE": "1"})
