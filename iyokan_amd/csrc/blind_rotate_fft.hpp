@@ -60,36 +60,47 @@ IYK_HD void diff16(int L, u32 abar, const u32* acc_c, u32 (&u)[16])
     //     address  (idx4 & 0xFFC) | base            add + v_and_or / v_bfi
     //     mask     v_bfe_i32(idx4, 12, 1)           one sign-extending extract instead of shift-add, shift, arithmetic shift
     //     value    ((rot + mask) ^ mask) + (K - own), flipped: add, sub, v_xad, xor   (-x = ~(x - 1): no separate "+1")
-    // Reads stay in four assembly blocks of 4 + 2 with one wait each.
+    // Round 6: all 16 + 8 reads from ONE assembly block with one wait (round 5: four blocks of 4 + 2, four exposed LDS round trips per
+    // polynomial; the registers are there since the half-block key ring): +0.1 .. 0.4 % gates/s, profiles/r06_decomp_ab_raw.txt.
     typedef const __attribute__((address_space(3))) u32* lds_u32;
     const u32 acc_base = (u32)(size_t)(lds_u32)acc_c;
     const u32 base4 = ((u32)L - abar) << 2;
     const u32 own_base = acc_base + ((u32)L << 2);
     u32 lowmask = 0xFFCu;
     asm volatile("" : "+v"(lowmask));   // in a VGPR: v_and_or takes one scalar operand (acc_base) only
+    {   // ONE block of 16 + 8 reads with one wait (round 5: four blocks of 4 + 2 — four exposed LDS round trips per polynomial)
+        u32 idx[16], r[16];
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
-        u32 idx[4], r[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            idx[e] = base4 + 256u * (u32)(4 * h + e);
+        for (int e = 0; e < 16; ++e) {
+            idx[e] = base4 + 256u * (u32)e;
             r[e] = (idx[e] & lowmask) | acc_base;
         }
-        u64 o01, o23;
+        u64 o[8];
         asm volatile(
             "ds_read_b32 %0, %0\n" "ds_read_b32 %1, %1\n" "ds_read_b32 %2, %2\n" "ds_read_b32 %3, %3\n"
-            "ds_read2st64_b32 %4, %6 offset0:0 offset1:1\n"
-            "ds_read2st64_b32 %5, %6 offset0:2 offset1:3\n"
+            "ds_read_b32 %4, %4\n" "ds_read_b32 %5, %5\n" "ds_read_b32 %6, %6\n" "ds_read_b32 %7, %7\n"
+            "ds_read_b32 %8, %8\n" "ds_read_b32 %9, %9\n" "ds_read_b32 %10, %10\n" "ds_read_b32 %11, %11\n"
+            "ds_read_b32 %12, %12\n" "ds_read_b32 %13, %13\n" "ds_read_b32 %14, %14\n" "ds_read_b32 %15, %15\n"
+            "ds_read2st64_b32 %16, %24 offset0:0 offset1:1\n"
+            "ds_read2st64_b32 %17, %24 offset0:2 offset1:3\n"
+            "ds_read2st64_b32 %18, %24 offset0:4 offset1:5\n"
+            "ds_read2st64_b32 %19, %24 offset0:6 offset1:7\n"
+            "ds_read2st64_b32 %20, %24 offset0:8 offset1:9\n"
+            "ds_read2st64_b32 %21, %24 offset0:10 offset1:11\n"
+            "ds_read2st64_b32 %22, %24 offset0:12 offset1:13\n"
+            "ds_read2st64_b32 %23, %24 offset0:14 offset1:15\n"
             "s_waitcnt lgkmcnt(0)"
-            : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "=&v"(o01), "=&v"(o23)
-            : "v"(own_base + 1024u * (u32)h)
+            : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]),
+              "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]), "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]),
+              "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+            : "v"(own_base)
             : "memory");
-        const u32 own[4] = {(u32)o01, (u32)(o01 >> 32), (u32)o23, (u32)(o23 >> 32)};   // acc_c[L + 64 q]
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 16; ++e) {
+            const u32 own = (e & 1) ? (u32)(o[e >> 1] >> 32) : (u32)o[e >> 1];
             const u32 mask = (u32)__builtin_amdgcn_sbfe((i32)idx[e], 12u, 1u);
             const u32 t = r[e] + mask;
-            u[4 * h + e] = ((t ^ mask) + (BrConsts<G::L, G::BGBIT>::offset_plus_round() - own[e])) ^ G::flip();
+            u[e] = ((t ^ mask) + (BrConsts<G::L, G::BGBIT>::offset_plus_round() - own)) ^ G::flip();
         }
     }
 #else
