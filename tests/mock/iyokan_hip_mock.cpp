@@ -46,6 +46,7 @@ void orc_free(orc_ctx* c);
 void orc_gate(const orc_ctx* c, int op, const uint32_t* in0, const uint32_t* in1, const uint32_t* in2, uint32_t* out,
               int mode);
 void orc_blind_rotate(const orc_ctx* c, const uint32_t* tlwe0, uint32_t* acc, int mode);
+int orc_has_fft(const orc_ctx* c);
 void orc_sample_extract0(const orc_ctx* c, const uint32_t* acc, uint32_t* tlwe1);
 void orc_keyswitch(const orc_ctx* c, const uint32_t* tlwe1, uint32_t* out);
 }
@@ -115,6 +116,7 @@ struct State {
     iyk_params params{};
     std::vector<uint32_t> bk, ksk;
     orc_ctx* orc = nullptr;
+    int mode = 0;   // oracle restatement (tests/oracle_lib.py MODES)
     std::unique_ptr<Pool> pool;
     std::set<void*> streams, arenas, trlwes, pinned;
     // counters the test harness reads through iyk_mock_stats
@@ -228,6 +230,11 @@ int iyk_hip_init(int ngpu, const int*, const iyk_params* p, const uint32_t* bk, 
     G.bk.assign(bk, bk + iyk_bk_words(p));   // "host buffers may be freed on return"
     G.ksk.assign(ksk, ksk + iyk_ksk_words(p));
     G.orc = orc_new(&G.params, G.bk.data(), G.ksk.data());
+    // which of the oracle's restatements computes the gates: the exact FFT one where the set has it (5x the field one's speed, word for
+    // word the same outputs: tests/test_oracle.py pins the restatements against each other), IYK_MOCK_ORACLE_MODE to force another
+    G.mode = orc_has_fft(G.orc) ? 3 : 0;
+    if (const char* v = std::getenv("IYK_MOCK_ORACLE_MODE"))
+        G.mode = std::atoi(v);
     unsigned threads = std::thread::hardware_concurrency();
     if (const char* v = std::getenv("IYK_MOCK_THREADS"))
         threads = static_cast<unsigned>(std::atoi(v));
@@ -500,7 +507,7 @@ int iyk_hip_gate_batch(iyk_hip_stream* st, uint32_t* arena, uint64_t slots, uint
                 for (size_t g; (g = next++) < gates->size();) {
                     const Gate& x = (*gates)[g];
                     orc_gate(G.orc, sabotaged(x.op), x.a >= 0 ? arena + x.a * w : nullptr, x.b >= 0 ? arena + x.b * w : nullptr,
-                             x.c >= 0 ? arena + x.c * w : nullptr, arena + x.o * w, 0);
+                             x.c >= 0 ? arena + x.c * w : nullptr, arena + x.o * w, G.mode);
                 }
             });
         for (auto&& t : ts)
@@ -530,7 +537,7 @@ int iyk_hip_gate_host(iyk_hip_stream* st, int op, const uint32_t* in0, const uin
     st->enqueue([=] {
         std::vector<uint32_t> res(w);
         orc_gate(G.orc, sabotaged(op), has[0] ? ins->data() : nullptr, has[1] ? ins->data() + w : nullptr,
-                 has[2] ? ins->data() + 2 * w : nullptr, res.data(), 0);
+                 has[2] ? ins->data() + 2 * w : nullptr, res.data(), G.mode);
         std::memcpy(out, res.data(), w * sizeof(uint32_t));
     });
     return IYK_OK;
@@ -566,7 +573,7 @@ int iyk_hip_bootstrap_trlwe_batch(iyk_hip_stream* st, const uint32_t* arena, uin
                 lin[i] = static_cast<uint32_t>(x.sa) * arena[x.ia * w + i] +
                          (x.ib >= 0 ? static_cast<uint32_t>(x.sb) * arena[x.ib * w + i] : 0u);
             lin[w - 1] += x.off;
-            orc_blind_rotate(G.orc, lin.data(), d_trlwe + x.row * 2 * N, 0);
+            orc_blind_rotate(G.orc, lin.data(), d_trlwe + x.row * 2 * N, G.mode);
         }
     });
     return IYK_OK;

@@ -40,6 +40,10 @@ FRONTEND_CASES = [("const-4bit", "test22", 1, ("batch",)), ("addr-4bit", "test04
                   ("counter-4bit", "test13", 3, ("batch", "per_gate")), ("dff-reset", "test23", 1, ("per_gate",))]
 if os.environ.get("IYK_EXEC_ALL") == "1":   # 398 bootstrapped gates on the CPU oracle: +20 s
     FRONTEND_CASES.append(("div-8bit", "test05", 1, ("batch", "per_gate")))
+    # SURVEY 8(d) config #3's netlist, all 8 clocks of the reference's vector (/root/reference/test.rb:446-447): upstream's builtin
+    # "mux-ram" generator reads the netlist embedded as upstream's build embeds it, the request's RAM image travels through
+    # PlainPacket::encrypt's `ramInTLWE`, 18 985 rotations per clock on the CPU oracle behind the mock: +6 .. 10 min on 8 cores
+    FRONTEND_CASES.append(("mux-ram-8-16-16", "test08", 8, ("batch",)))
 
 
 def _run(exe, extra_env=None, timeout=1500):

@@ -28,15 +28,17 @@ int iyk_client_encrypt_bits(const iyk_params* p, const uint32_t* s0, uint64_t se
                             uint64_t count, uint32_t* out);
 int iyk_client_decrypt_bits(const iyk_params* p, const uint32_t* s0, const uint32_t* ct, uint64_t count, uint8_t* bits);
 int iyk_client_trivial(const iyk_params* p, int bit, uint32_t* out);
+int iyk_client_encrypt_trlwe(const iyk_params* p, const uint32_t* s1, uint64_t seed, int deterministic, const uint32_t* msg, uint64_t count,
+                             uint32_t* out);
+int iyk_client_trlwe_phases(const iyk_params* p, const uint32_t* s1, const uint32_t* ct, uint64_t count, uint32_t* phases);
 // oracle/tfhe_oracle.c
 struct orc_ctx;
 orc_ctx* orc_new(const iyk_params* p, const uint32_t* bk, const uint32_t* ksk);
 void orc_free(orc_ctx* c);
 void orc_gate(const orc_ctx* c, int op, const uint32_t* in0, const uint32_t* in1, const uint32_t* in2, uint32_t* out, int mode);
 
-// the MUX-RAM netlists upstream embeds with objcopy (/root/reference/src/CMakeLists.txt); the executed tests build no RAM
-char _binary_mux_ram_8_8_8_min_json_start[1] = {0}, _binary_mux_ram_8_8_8_min_json_end[1] = {0};
-char _binary_mux_ram_8_16_16_min_json_start[1] = {0}, _binary_mux_ram_8_16_16_min_json_end[1] = {0};
+// the MUX-RAM netlists upstream embeds with objcopy (/root/reference/src/CMakeLists.txt:1-19): the Makefile embeds the two the checkout
+// holds the same way, from where they lie ($(OUT)/mux_ram.o); the third file is not in the checkout
 char _binary_mux_ram_9_16_16_min_json_start[1] = {0}, _binary_mux_ram_9_16_16_min_json_end[1] = {0};
 }
 
@@ -285,13 +287,24 @@ void BlindRotate<lvl01param>(TRLWE<lvl1param>&, const TLWE<lvl0param>&, const Bo
     notModelled("BlindRotate");
 }
 template <> Polynomial<lvl1param> μpolygen<lvl1param, lvl1param::μ>() { notModelled("μpolygen"); }
-template <> TRLWE<lvl1param> trlweSymEncrypt<lvl1param>(const std::array<lvl1param::T, lvl1param::n>&, double, const Key<lvl1param>&)
+// the CMUX-memory images PlainPacket::encrypt makes of every `ram` / `rom` entry beside the TLWE form (/root/reference/src/packet.hpp:78-122):
+// the client library's TRLWE encryption, the function this repository's own packet code calls for the same job (host/packet.hpp)
+template <> TRLWE<lvl1param> trlweSymEncrypt<lvl1param>(const std::array<lvl1param::T, lvl1param::n>& pmu, double, const Key<lvl1param>& key)
 {
-    notModelled("trlweSymEncrypt (CMUX-memory images of a request packet)");
+    const iyk_params p = params();
+    TRLWE<lvl1param> out;
+    static_assert(sizeof(out) == 2 * lvl1param::n * sizeof(uint32_t), "TRLWE = a(X) then b(X), contiguous");
+    iyk_client_encrypt_trlwe(&p, key.data(), freshSeed(), 1, pmu.data(), 1, out[0].data());
+    return out;
 }
-template <> std::array<bool, lvl1param::n> trlweSymDecrypt<lvl1param>(const TRLWE<lvl1param>&, const Key<lvl1param>&)
+template <> std::array<bool, lvl1param::n> trlweSymDecrypt<lvl1param>(const TRLWE<lvl1param>& c, const Key<lvl1param>& key)
 {
-    notModelled("trlweSymDecrypt");
+    const iyk_params p = params();
+    std::array<uint32_t, lvl1param::n> phase;
+    iyk_client_trlwe_phases(&p, key.data(), c[0].data(), 1, phase.data());
+    std::array<bool, lvl1param::n> bits;
+    for (size_t i = 0; i < bits.size(); ++i) bits[i] = static_cast<int32_t>(phase[i]) > 0;
+    return bits;
 }
 
 }  // namespace TFHEpp
