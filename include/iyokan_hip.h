@@ -222,8 +222,10 @@ int iyk_hip_gate_batch(iyk_hip_stream* st, uint32_t* d_arena, uint64_t arena_slo
  * another stream's iyk_hip_stream_sync has to drain the batch that holds this gate).  Threads: a stream is used by one host
  * thread at a time; different streams — of the same GPU too — may be driven from different threads (the parked gates of a GPU
  * are shared state behind one lock per GPU, never held across a blocking wait: a thread draining a batch does not stall the polls
- * of the others).  Destroying a stream with a parked gate completes the gate first.  Streams adopted with iyk_hip_stream_wrap are
- * exempt from all of this paragraph (see there). */
+ * of the others).  Destroying a stream with a parked gate completes the gate first.  Errors: a batch that fails on the GPU after
+ * its gates were launched is reported by iyk_hip_stream_query / _sync of EVERY stream that had a gate in it (never a silent,
+ * unwritten `out`), and the GPU's coalescer accepts no further batch (HIP errors of that kind are sticky).  Streams adopted with
+ * iyk_hip_stream_wrap are exempt from all of this paragraph (see there). */
 int iyk_hip_gate_host(iyk_hip_stream* st, int op, const uint32_t* in0, const uint32_t* in1,
                       const uint32_t* in2, uint32_t* out);
 

@@ -1633,6 +1633,7 @@ struct GateCoalescer {
         uint64_t gen = 0;                // generation this side holds (0 = free)
         size_t undelivered = 0;          // results not yet picked up by their streams
         bool flying = false;
+        bool failed = false;             // its download or event record failed after the gates were launched: results never arrive
         hipEvent_t done = nullptr;
     } side[2];
     int open = 0;                        // side that is filling
@@ -1642,8 +1643,9 @@ struct GateCoalescer {
 // One lock PER GPU (round 6, ADVICE r05: it was one for the process): parking, flushing and result hand-over touch state shared by
 // every stream of a GPU, and the callers' streams may live on different host threads (a stream itself is used by one thread at a
 // time, like a hipStream_t's owner).  The lock is never held across a blocking HIP call: coalescer_poll releases it around
-// hipEventSynchronize, and the page-locked batch buffers are sized once, when the coalescer is created.  (An array beside the
-// devices rather than a member: Device stays copyable.)
+// hipEventSynchronize, and the page-locked batch buffers get their size when the coalescer is created (they grow later only if gates
+// keep arriving at a full batch while the previous one is still in flight).  (An array beside the devices rather than a member: Device
+// stays copyable.)
 std::mutex g_co_mu[MAX_GPUS];
 inline uint64_t co_gen_of(const iyk_hip_stream* st) { return __atomic_load_n(&st->co_gen, __ATOMIC_ACQUIRE); }
 
@@ -1743,8 +1745,9 @@ int coalescer_flush(GateCoalescer* c)
     sd.undelivered = count;
     hipError_t e = hipMemcpyAsync(sd.h_out, sd.d_arena + 3 * sd.cap * n1, count * n1 * sizeof(u32), hipMemcpyDeviceToHost, c->st->s);
     if (e == hipSuccess) e = hipEventRecord(sd.done, c->st->s);
-    if (e != hipSuccess) {   // fail hard: wait for what is in flight and take the batch back out of circulation with an error
-        (void)hipStreamSynchronize(c->st->s);
+    if (e != hipSuccess) {   // fail hard: wait for what is in flight; the side stays out of circulation and every poll of one of
+        (void)hipStreamSynchronize(c->st->s);   // its streams reports the error (its `done` event was never recorded for this batch)
+        sd.failed = true;
         return fail(IYK_ERR_HIP, std::string("gate coalescer download: ") + hipGetErrorString(e));
     }
     other.gen = c->next_gen++;
@@ -1794,14 +1797,16 @@ int coalescer_poll(iyk_hip_stream* st, bool block)
         for (auto& x : c->side)
             if (x.gen == st->co_gen) sd = &x;
         if (!sd) return fail(IYK_ERR_STATE, "coalesced gate lost its batch");
+        if (sd->failed) return fail(IYK_ERR_HIP, "the batch of this coalesced gate failed on the GPU (see the earlier error)");
         if (!sd->flying) {   // still filling
             if (block || st->co_polls >= 2 || sd->ops.size() >= c->max_gates)
                 if ((rc = coalescer_flush(c))) return rc;
             if (!sd->flying) {
+                GateCoalescer::Side& other = c->side[(sd == &c->side[0]) ? 1 : 0];
+                if (other.failed) return fail(IYK_ERR_HIP, "an earlier coalesced batch failed on the GPU; the coalescer is stopped");
                 if (!block) return 0;
                 // blocked behind the other side: wait for it and hand its results to their owners right away (a ciphertext written
                 // before its stream is polled is within the contract: `out` belongs to the library until the stream is seen idle)
-                GateCoalescer::Side& other = c->side[(sd == &c->side[0]) ? 1 : 0];
                 if (other.flying) {
                     const uint64_t gen = other.gen;
                     if ((rc = wait_unlocked(other.done))) return rc;
