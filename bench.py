@@ -230,6 +230,10 @@ def cpu_baseline(keys, params, op_code, sample, data_seed, budget_s=24.0):
         tried[t] = 4 * t / run(4 * t, data_seed, fast, t)
         t //= 2
     threads = max(tried, key=tried.get)
+    # cores that can actually be busy at once: the cgroup's quota when it is below the thread count (32 threads under a quota of 16
+    # are 16 cores' worth of work; the per-thread figures below are per BUSY core, or they would double on such a box)
+    quota = cpu_quota()
+    busy = min(float(threads), quota) if quota else float(threads)
     modes = (["fft"] if orc.has_fft() else []) + (["fp"] if orc.has_fp() else []) + ["goldilocks"]
     results = {}
     for mode in modes:
@@ -252,7 +256,7 @@ def cpu_baseline(keys, params, op_code, sample, data_seed, budget_s=24.0):
         n -= n % (2 * threads)
         n = max(n, 2 * threads)
         dt = run(n, data_seed + 1, mode, threads)
-        tfhepp_like = {"gates_per_s": n / dt, "sample_gates": n, "seconds": dt, "ms_per_gate_per_thread": threads / (n / dt) * 1e3,
+        tfhepp_like = {"gates_per_s": n / dt, "sample_gates": n, "seconds": dt, "ms_per_gate_per_thread": busy / (n / dt) * 1e3,
                        "what": "TFHEpp's ALGORITHM on this repository's transform code (oracle/tfhe_oracle_fft.c, last section): unsplit "
                                "32-bit key, (k+1) l forward + (k+1) inverse FP64 transforms per CMUX step, INEXACT products — decrypt-equal, "
                                "NOT word-equal to the oracle or the GPU; not TFHEpp's code (spqlios), which is not in this container"}
@@ -270,7 +274,7 @@ def cpu_baseline(keys, params, op_code, sample, data_seed, budget_s=24.0):
                                  tfhepp_algorithm_inexact=tfhepp_like),
             "threads_tried_gates_per_s": {str(k): v for k, v in tried.items()},
             "visible_cpus": cores, "cpu_quota": cpu_quota(),
-            "ms_per_gate_per_thread": threads / rate * 1e3}
+            "busy_cores": busy, "ms_per_gate_per_thread": busy / rate * 1e3}
 
 
 def word_check(params_name, op, first_gate, rows):
