@@ -130,6 +130,46 @@ def test_upstream_frontend_flow_reproduces_the_reference_vectors(exec_binary, tm
             assert stats["gate_host_calls"] == 0
 
 
+@pytest.mark.parametrize("blueprint,vector,first,rest", [("counter-4bit", "test13", 2, 1), ("addr-register-4bit", "test16", 1, 2)])
+def test_upstream_snapshot_taken_with_one_worker_flavour_resumes_under_the_other(exec_binary, tmp_path, blueprint, vector, first, rest):
+    """`iyokan tfhe --snapshot / --resume` (/root/reference/src/iyokan_cufhe.cpp:880-894) with s/cufhe/hip/: `first` clocks through the
+    frontier-batching worker, upstream's writeToArchive of the whole HIPFrontend (run parameters, request packet, every network with
+    every task's host ciphertext through cereal's POLYMORPHIC registration — the CEREAL_REGISTER_TYPE lines of
+    integration/upstream/iyokan_hip.hpp — weak_ptr edges, bridges, the cycle counter), a NEW process reads it back
+    (HIPFrontend::load: key, GPUs, then the graph), runs `rest` more clocks through the one-gate-per-stream workers, and the result
+    packet equals the reference's expected one for first + rest clocks.  Nothing about the GPU is part of a snapshot.  The archive
+    goes through tests/upstream_exec's cereal stand-in both ways (cereal's own encoding rules, polymorphic ids and names included)."""
+    sys.path.insert(0, ROOT)
+    from iyokan_amd.packet import PlainPacket
+
+    exe = os.path.join(os.path.dirname(exec_binary), "frontend_exec")
+    request = PlainPacket.load(os.path.join(REF, "test", "in", vector + ".in"))
+    expected = PlainPacket.load(os.path.join(REF, "test", "out", vector + ".out"))
+    (tmp_path / "request.plain").write_bytes(request.to_archive())
+    snap = str(tmp_path / "snapshot")
+
+    def run(cycles, result, **extra):
+        env = dict(os.environ, IYK_EXEC_SEED="20261001", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1", **extra)
+        for k in ("IYOKAN_HIP_PER_GATE", "IYK_EXEC_SNAPSHOT", "IYK_EXEC_RESUME"):
+            if k not in extra:
+                env.pop(k, None)
+        r = subprocess.run([exe, os.path.join("test", "config-toml", blueprint + ".toml"), str(tmp_path / "request.plain"),
+                            str(tmp_path / result), str(cycles), str(tmp_path)], cwd=REF, env=env, capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+        assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+        stats = json.loads(r.stdout.strip().splitlines()[-1])
+        assert (stats["live_streams"], stats["live_arenas"], stats["live_pinned"]) == (0, 0, 0)
+        return PlainPacket.from_archive((tmp_path / result).read_bytes()), stats
+
+    early, s1 = run(first, "early.plain", IYK_EXEC_SNAPSHOT=snap)
+    assert s1["gate_host_calls"] == 0 and os.path.getsize(snap) > 1000
+    assert not early.same_content(expected)          # the vector needs the remaining clocks
+    late, s2 = run(rest, "late.plain", IYK_EXEC_RESUME=snap, IYOKAN_HIP_PER_GATE="1")
+    assert s2["gate_batches"] == 0 and s2["gate_host_calls"] > 0
+    assert late.same_content(expected), (late.bits, expected.bits)
+
+
 def test_tfhepp_crosscheck_tool_dry_run_and_key_import(exec_binary, tmp_path):
     """tools/tfhepp_crosscheck.cpp — the ciphertext-level cross-check written for a REAL TFHEpp checkout ("220 lines, never
     compiled") — built against the stand-ins and RUN: with stand-in TFHEpp = CPU oracle = mock GPU it must report every output word

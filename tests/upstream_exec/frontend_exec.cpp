@@ -10,6 +10,7 @@
 #include "packet.hpp"
 
 #include <cstdio>
+#include <cstdlib>
 
 extern "C" {
 struct iyk_mock_stats_t {
@@ -40,12 +41,20 @@ int main(int argc, char** argv)
     writeToArchive(work + "/evalkey", ek);
 
     Options opt;
-    opt.blueprint = NetworkBlueprint{blueprint};
     opt.ekFile = work + "/evalkey";
-    opt.inputFile = work + "/request.tfhe";
     opt.outputFile = work + "/result.tfhe";
     opt.numCycles = cycles;
     opt.numCPUWorkers = 2;
+    // IYK_EXEC_SNAPSHOT=<file>: write upstream's snapshot after the run; IYK_EXEC_RESUME=<file>: start from one (`cycles` more clocks)
+    // instead of from the blueprint — `iyokan tfhe --snapshot / --resume` (/root/reference/src/iyokan_cufhe.cpp:880-894)
+    if (const char* f = std::getenv("IYK_EXEC_SNAPSHOT"))
+        opt.snapshotFile = f;
+    if (const char* f = std::getenv("IYK_EXEC_RESUME"))
+        opt.resumeFile = f;
+    else {
+        opt.blueprint = NetworkBlueprint{blueprint};
+        opt.inputFile = work + "/request.tfhe";
+    }
     doHIP(opt);
 
     const TFHEPacket result = readFromArchive<TFHEPacket>(work + "/result.tfhe");

@@ -22,6 +22,8 @@
 #include <string>
 #include <tuple>
 #include <type_traits>
+#include <typeindex>
+#include <typeinfo>
 #include <unordered_map>
 #include <utility>
 #include <vector>
@@ -77,9 +79,37 @@ template <class T> struct is_bitset : std::false_type {};
 template <size_t N> struct is_bitset<std::bitset<N>> : std::true_type {};
 }  // namespace exec_detail
 
+
+class PortableBinaryOutputArchive;
+class PortableBinaryInputArchive;
+namespace exec_detail {
+// one binding per CEREAL_REGISTER_TYPE: how to save / load an object of dynamic type D through a void* to the MOST-DERIVED object
+struct Binding {
+    std::string name;
+    void (*save)(PortableBinaryOutputArchive&, const void* mostDerived);
+    std::shared_ptr<void> (*load)(PortableBinaryInputArchive&);   // points at the D object
+    void (*raise)(void* mostDerived);                              // throw static_cast<D*>(p): the catch site up-casts
+};
+inline std::map<std::type_index, Binding>& bindingsByType()
+{
+    static std::map<std::type_index, Binding> m;
+    return m;
+}
+inline std::map<std::string, Binding>& bindingsByName()
+{
+    static std::map<std::string, Binding> m;
+    return m;
+}
+template <class D>
+struct Registrar {
+    explicit Registrar(const char* name);
+};
+}  // namespace exec_detail
+
 class PortableBinaryOutputArchive {
     std::ostream& os_;
     std::map<const void*, uint32_t> seen_;
+    std::map<std::string, uint32_t> polyNames_;
 
     void raw(const void* p, size_t n)
     {
@@ -131,26 +161,47 @@ class PortableBinaryOutputArchive {
         }
         else if constexpr (is_shared<T>::value) {
             using E = typename T::element_type;
-            if constexpr (std::is_polymorphic_v<E>) notModelled("a polymorphic shared_ptr (snapshot)");
-            else {
+            if constexpr (std::is_polymorphic_v<E>) {
                 if (!v) {
                     const uint32_t id = 0;
                     raw(&id, 4);
                     return;
                 }
-                auto it = seen_.find(v.get());
-                if (it != seen_.end()) {
-                    raw(&it->second, 4);
-                    return;
+                const std::type_info& dyn = typeid(*v);
+                if (dyn == typeid(E)) {   // the static type itself: bit 30, then the plain pointer wrapper
+                    if constexpr (!std::is_abstract_v<E>) {
+                        const uint32_t staticType = 0x40000000u;
+                        raw(&staticType, 4);
+                        pointerWrapper(static_cast<const std::remove_const_t<E>*>(v.get()));
+                        return;
+                    }
                 }
-                const uint32_t id = static_cast<uint32_t>(seen_.size()) + 1;
-                seen_.emplace(v.get(), id);
-                const uint32_t tagged = id | 0x80000000u;
-                raw(&tagged, 4);
-                one(*v);
+                auto b = bindingsByType().find(std::type_index(dyn));
+                if (b == bindingsByType().end())
+                    throw Exception(std::string("cereal stand-in: unregistered polymorphic type ") + dyn.name());
+                uint32_t nameId;
+                auto n = polyNames_.find(b->second.name);
+                if (n == polyNames_.end()) {
+                    nameId = static_cast<uint32_t>(polyNames_.size()) + 1;
+                    polyNames_.emplace(b->second.name, nameId);
+                    const uint32_t tagged = nameId | 0x80000000u;
+                    raw(&tagged, 4);
+                    one(b->second.name);
+                }
+                else {
+                    nameId = n->second;
+                    raw(&nameId, 4);
+                }
+                b->second.save(*this, dynamic_cast<const void*>(v.get()));
             }
+            else
+                pointerWrapper(v.get());
         }
-        else if constexpr (is_weak<T>::value || is_unique<T>::value || is_bitset<T>::value) notModelled("weak_ptr / unique_ptr / bitset");
+        else if constexpr (is_weak<T>::value) {
+            const std::shared_ptr<typename T::element_type> locked = v.lock();
+            one(locked);
+        }
+        else if constexpr (is_unique<T>::value || is_bitset<T>::value) notModelled("unique_ptr / bitset");
         else if constexpr (has_serialize<T, PortableBinaryOutputArchive>::value) const_cast<T&>(v).serialize(*this);
         else if constexpr (has_save<T, PortableBinaryOutputArchive>::value) v.save(*this);
         else notModelled("a type without serialize / save");
@@ -159,6 +210,27 @@ class PortableBinaryOutputArchive {
     void one(const base_class<B>& b) { one(*b.ptr); }
 
 public:
+    // cereal's ptr_wrapper: object id (msb set the first time, then the object follows); p is the most-derived object of type D
+    template <class D>
+    void pointerWrapper(const D* p)
+    {
+        if (!p) {
+            const uint32_t id = 0;
+            raw(&id, 4);
+            return;
+        }
+        auto it = seen_.find(static_cast<const void*>(p));
+        if (it != seen_.end()) {
+            raw(&it->second, 4);
+            return;
+        }
+        const uint32_t id = static_cast<uint32_t>(seen_.size()) + 1;
+        seen_.emplace(static_cast<const void*>(p), id);
+        const uint32_t tagged = id | 0x80000000u;
+        raw(&tagged, 4);
+        one(*p);
+    }
+
     explicit PortableBinaryOutputArchive(std::ostream& os) : os_(os)
     {
         const uint8_t littleEndian = 1;
@@ -174,7 +246,8 @@ public:
 
 class PortableBinaryInputArchive {
     std::istream& is_;
-    std::map<uint32_t, std::shared_ptr<void>> seen_;
+    std::map<uint32_t, std::shared_ptr<void>> seen_;   // keeps every loaded object alive until the archive goes (weak_ptr targets)
+    std::map<uint32_t, std::string> polyNames_;
 
     void raw(void* p, size_t n)
     {
@@ -244,26 +317,60 @@ class PortableBinaryInputArchive {
         }
         else if constexpr (is_shared<T>::value) {
             using E = typename T::element_type;
-            if constexpr (std::is_polymorphic_v<E>) notModelled("a polymorphic shared_ptr (snapshot)");
-            else {
-                uint32_t id;
-                raw(&id, 4);
-                if (id == 0) v.reset();
-                else if (id & 0x80000000u) {
-                    auto p = std::make_shared<std::remove_const_t<E>>();
-                    seen_[id & 0x7fffffffu] = p;
-                    one(*p);
-                    v = p;
+            using M = std::remove_const_t<E>;
+            if constexpr (std::is_polymorphic_v<E>) {
+                uint32_t nameId;
+                raw(&nameId, 4);
+                if (nameId == 0) {
+                    v.reset();
+                    return;
+                }
+                if (nameId & 0x40000000u) {   // the static type itself
+                    if constexpr (!std::is_abstract_v<E> && std::is_default_constructible_v<M>)
+                        v = std::static_pointer_cast<M>(pointerWrapper<M>());
+                    else
+                        throw Exception("cereal stand-in: static-type pointer to a type that cannot be constructed");
+                    return;
+                }
+                std::string name;
+                if (nameId & 0x80000000u) {
+                    one(name);
+                    polyNames_[nameId & 0x7fffffffu] = name;
                 }
                 else {
-                    auto it = seen_.find(id);
-                    if (it == seen_.end())
-                        throw Exception("cereal stand-in: unknown pointer id");
-                    v = std::static_pointer_cast<E>(it->second);
+                    auto n = polyNames_.find(nameId);
+                    if (n == polyNames_.end())
+                        throw Exception("cereal stand-in: unknown polymorphic name id");
+                    name = n->second;
                 }
+                auto b = bindingsByName().find(name);
+                if (b == bindingsByName().end())
+                    throw Exception("cereal stand-in: no binding for polymorphic type " + name);
+                std::shared_ptr<void> obj = b->second.load(*this);
+                if (!obj) {
+                    v.reset();
+                    return;
+                }
+                try {
+                    b->second.raise(obj.get());
+                }
+                catch (M* up) {   // derived-to-base conversion done by the handler match (multiple inheritance included)
+                    v = std::shared_ptr<E>(obj, up);
+                    return;
+                }
+                throw Exception("cereal stand-in: " + name + " is not derived from the pointer's static type");
+            }
+            else {
+                std::shared_ptr<void> obj = pointerWrapper<M>();
+                v = std::static_pointer_cast<E>(std::static_pointer_cast<M>(obj));
             }
         }
-        else if constexpr (is_weak<T>::value || is_unique<T>::value || is_bitset<T>::value) notModelled("weak_ptr / unique_ptr / bitset");
+        else if constexpr (is_weak<T>::value) {
+            std::shared_ptr<typename T::element_type> locked;
+            one(locked);
+            v = locked;
+        }
+        else if constexpr (is_unique<T>::value || is_bitset<T>::value) notModelled("unique_ptr / bitset");
         else if constexpr (has_serialize<T, PortableBinaryInputArchive>::value) v.serialize(*this);
         else if constexpr (has_load<T, PortableBinaryInputArchive>::value) v.load(*this);
         else notModelled("a type without serialize / load");
@@ -274,6 +381,25 @@ class PortableBinaryInputArchive {
     void one(base_class<B>&& b) { one(*b.ptr); }
 
 public:
+    // cereal's ptr_wrapper, reading: a new object is registered BEFORE its contents are read (cycles through weak_ptr resolve)
+    template <class D>
+    std::shared_ptr<void> pointerWrapper()
+    {
+        uint32_t id;
+        raw(&id, 4);
+        if (id == 0) return nullptr;
+        if (id & 0x80000000u) {
+            std::shared_ptr<D> p(new D());
+            seen_[id & 0x7fffffffu] = p;
+            one(*p);
+            return p;
+        }
+        auto it = seen_.find(id);
+        if (it == seen_.end())
+            throw Exception("cereal stand-in: unknown pointer id");
+        return it->second;
+    }
+
     explicit PortableBinaryInputArchive(std::istream& is) : is_(is)
     {
         uint8_t flag = 0;
@@ -292,15 +418,27 @@ public:
 
 #define CEREAL_EXEC_CAT2(a, b) a##b
 #define CEREAL_EXEC_CAT(a, b) CEREAL_EXEC_CAT2(a, b)
-// as in tests/shims: registering a polymorphic type instantiates its serialisation for both archives (type check); nothing runs
-#define CEREAL_REGISTER_TYPE(...)                                                                                \
-    namespace cereal_exec_registered {                                                                           \
-    inline void CEREAL_EXEC_CAT(touch_, __COUNTER__)(__VA_ARGS__ & t, ::cereal::PortableBinaryOutputArchive & o,  \
-                                                     ::cereal::PortableBinaryInputArchive & i)                    \
-    {                                                                                                            \
-        o(t);                                                                                                    \
-        i(t);                                                                                                    \
-    }                                                                                                            \
+namespace cereal::exec_detail {
+template <class D>
+Registrar<D>::Registrar(const char* name)
+{
+    static_assert(std::is_polymorphic_v<D>, "CEREAL_REGISTER_TYPE is for polymorphic types");
+    Binding b;
+    b.name = name;
+    b.save = [](PortableBinaryOutputArchive& ar, const void* p) { ar.pointerWrapper(static_cast<const D*>(p)); };
+    b.load = [](PortableBinaryInputArchive& ar) -> std::shared_ptr<void> {
+        if constexpr (std::is_default_constructible_v<D> && !std::is_abstract_v<D>) return ar.template pointerWrapper<D>();
+        else notModelled("loading a registered type without a default constructor");
+    };
+    b.raise = [](void* p) { throw static_cast<D*>(p); };
+    bindingsByType().emplace(std::type_index(typeid(D)), b);
+    bindingsByName().emplace(b.name, b);
+}
+}  // namespace cereal::exec_detail
+// cereal binds the type to its SPELLED name (#T) in every translation unit that sees the line; so does this (the maps ignore repeats)
+#define CEREAL_REGISTER_TYPE(...)                                                                                  \
+    namespace cereal_exec_registered {                                                                             \
+    inline const ::cereal::exec_detail::Registrar<__VA_ARGS__> CEREAL_EXEC_CAT(reg_, __COUNTER__){#__VA_ARGS__};   \
     }
 #define CEREAL_REGISTER_POLYMORPHIC_RELATION(...)
 #define CEREAL_CLASS_VERSION(...)
