@@ -33,17 +33,23 @@ def _build(out, san):
     return os.path.join(out, "test0_hip_exec")
 
 
-# (blueprint, request, expected result, cycles): the reference's own integration vectors without CMUX memories
+# (blueprint, request, expected result, cycles): the reference's own integration vectors
 # (/root/reference/test.rb:426-453,547-548), small enough for the CPU oracle behind the mock
 FRONTEND_CASES = [("const-4bit", "test22", 1, ("batch",)), ("addr-4bit", "test04", 1, ("batch", "per_gate")),
                   ("pass-addr-pass-4bit", "test04", 1, ("batch",)), ("addr-register-4bit", "test16", 3, ("batch",)),
-                  ("counter-4bit", "test13", 3, ("batch", "per_gate")), ("dff-reset", "test23", 1, ("per_gate",))]
+                  ("counter-4bit", "test13", 3, ("batch", "per_gate")), ("dff-reset", "test23", 1, ("per_gate",)),
+                  # CMUX memories (type = "rom"): TFHEpp's CPU-side tasks between HIP-side ports and bridges.  Circuit bootstrapping is
+                  # MODELLED IN THE CLEAR by the stand-in (tests/upstream_exec/tfhepp_runtime.cpp); everything else is real arithmetic
+                  ("rom-4-8", "test15", 1, ("batch",)), ("rom-7-32", "test12", 1, ("batch", "per_gate"))]
 if os.environ.get("IYK_EXEC_ALL") == "1":   # 398 bootstrapped gates on the CPU oracle: +20 s
     FRONTEND_CASES.append(("div-8bit", "test05", 1, ("batch", "per_gate")))
     # SURVEY 8(d) config #3's netlist, all 8 clocks of the reference's vector (/root/reference/test.rb:446-447): upstream's builtin
     # "mux-ram" generator reads the netlist embedded as upstream's build embeds it, the request's RAM image travels through
     # PlainPacket::encrypt's `ramInTLWE`, 18 985 rotations per clock on the CPU oracle behind the mock: +6 .. 10 min on 8 cores
     FRONTEND_CASES.append(("mux-ram-8-16-16", "test08", 8, ("batch",)))
+    # type = "ram" (CMUX RAM, 256 cells x 8 bits, 16 clocks): CPU-side CB / RAMUX / CMUXs, TRLWE bridges to the plugin's SampleExtract +
+    # key-switch and cell-refresh tasks on the (mock) GPU, 2 048 TRLWE rotations per clock on the CPU oracle: +20 min
+    FRONTEND_CASES.append(("ram-addr8bit", "test06", 16, ("batch",)))
 
 
 def _run(exe, extra_env=None, timeout=1500):

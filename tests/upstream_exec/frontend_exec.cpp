@@ -5,7 +5,7 @@
 //   frontend_exec <blueprint.toml> <request: PlainPacket archive> <result: PlainPacket archive> <cycles> <work dir>
 // The request archive is written by iyokan_amd/packet.py (this repository's restatement of cereal's format) and READ here by upstream's
 // own PlainPacket::serialize through the cereal stand-in; the result travels the other way.  Keys and encryption: stand-in TFHEpp
-// (tfhepp_runtime.cpp).  CMUX memories (type = "rom" / "ram") are not modelled.
+// (tfhepp_runtime.cpp); CMUX memories (type = "rom" / "ram") run with circuit bootstrapping modelled in the clear there.
 #include "iyokan_hip.hpp"
 #include "packet.hpp"
 
