@@ -443,6 +443,14 @@ __global__ __launch_bounds__(64 * BR_WAVES, 2) void blind_rotate_fft_kernel(
     br_init_acc(lane0 >> 5, lane0 & 31, abar[n], mu, acc_lds + (lane0 >> 5) * NTT_N);
     lds_sync();
 
+    // One-off start offset (round 6).  The 256 workgroups of the first resident generation start together and run identical
+    // instruction streams, so all eight XCDs ask L2 -> fabric -> HBM for the SAME key lines in the same microsecond, step after
+    // step.  Delaying workgroup b once by (5 b mod 64) x ~1 k cycles — at most 1.4 of the 636 steps; workgroups dispatched later
+    // inherit the offset of the CU that frees up — takes them out of step: +0.3 % gates/s on two boxes, both parameter sets
+    // (profiles/r06_stagger_ab.txt; offsets inside an XCD alone: nothing; offsets of several steps: -0.1 ... -0.3 %, the CUs of
+    // an XCD stop sharing key rows in L2).  The clock under the power limit does not move: it is a memory-side effect.
+    if (blockIdx.x < 256u)
+        for (unsigned k = (blockIdx.x * 5u) & 63u; k > 0; --k) __builtin_amdgcn_s_sleep(16);
     const fft::Keys keys(bk_fft, bk_bytes, lane0);
     double worst = 0.0;
     // the uniform twist constants: fetched once and pinned in SGPRs (left alone, the compiler re-reads them with scalar
@@ -669,6 +677,11 @@ __global__ __launch_bounds__(BrLatFft<G>::THREADS) void blind_rotate_fft_lat_ker
     for (int r = 0; r < XF - 2; ++r) load_row(0, r);
     double worst = 0.0;
     __syncthreads();
+    // One-off start offset by XCD (blockIdx & 7: workgroups go round-robin over the eight XCDs), ~1 k cycles per index, a step
+    // being 9.2 k: the XCDs stop asking the fabric for the same key lines in the same instant (the throughput kernel's finding,
+    // blind_rotate_fft_kernel above).  2.458 -> 2.443 ms at 16 rotations, 2.469 -> 2.449 at 64, 2.769 -> 2.729 at 256
+    // (profiles/r06_stagger_ab.txt; 64 offsets up to 7 steps: +0.4 % time).
+    for (unsigned k = (blockIdx.x & 7u) * 4u; k > 0; --k) __builtin_amdgcn_s_sleep(4);
 
     // The inverse's eleven lane constants stay in registers for the whole kernel (44 VGPRs the kernel has: 228 of 256): the LDS
     // pipe is 54 % busy (profiles/r04_latfft_pmc_sq.txt) and every wave spends a quarter of its time waiting for it, so 11 reads
