@@ -277,9 +277,13 @@ int iyk_hip_timing_log_end(iyk_hip_stream* st, uint64_t* batches, double* blind_
  * rotation kernel — fft: a wave per rotation, complex FFT, 8 points per lane (the default for full rounds); w32: a wave
  * per rotation on the FP64 field, 32 points per lane (the default for full rounds with IYK_HIP_NTT=fp); lat3: a workgroup
  * of 8 waves per rotation (the default for narrow frontiers).  Unset = chosen by batch size.
- * IYK_HIP_LATENCY_KERNEL = 0 / 3 is the older spelling of w32 / lat3.  IYK_HIP_KS_KERNEL = 0 / 1, read at every batch, forces
- * the key switch with 16 gates per workgroup (3 words per thread) or the one with 16 gates per wave (whole rows per
- * wave; the default where instantiated); both subtract the same rows mod 2^32, so they agree word for word. */
+ * IYK_HIP_LATENCY_KERNEL = 0 / 3 is the older spelling of w32 / lat3.  IYK_HIP_KS_KERNEL = 0 / 1 / 2, read at every batch, forces
+ * the key switch with 16 gates per workgroup (3 words per thread), the one with 16 gates per wave (whole rows per
+ * wave, digits decoded by compare and branch; the default for batches of up to 4 096 gates, in its shared-gates form) or —
+ * 2, the default for wider batches since round 6 — the one that takes the digits in pairs and selects a PRE-ADDED row by
+ * address (a table of 16 sums per digit pair, built on the GPU from the resident key-switching key by the first wide batch:
+ * + 136 MB per GPU, counted by iyk_hip_resident_key_bytes from then on); all three subtract the same rows mod 2^32, so
+ * they agree word for word. */
 int iyk_hip_ntt_path(void);
 
 /* Round 4: return value 2 = the default since — both rotation kernels (a wave per rotation for full rounds, a workgroup per

@@ -71,6 +71,7 @@ struct Device {
     int cus = 256;           // compute units (one wave-per-rotation workgroup each)
     u64* bk_ntt = nullptr;   // NTT-domain BK: u64 residues mod 2^64-2^32+1, or doubles mod p = 3*2^48+1097729 (fp path)
     u32* ksk = nullptr;
+    u32* ksk_lut = nullptr;  // pre-added key-switch rows (keyswitch_lut_kernel), built on first use: ensure_ks_lut
     u64* tw_fwd = nullptr;   // u64 or double tables, same size
     u64* tw_inv = nullptr;
     fp::NttConsts* fpc = nullptr;  // FP path: 32-point twiddles + twists, read by scalar loads
@@ -87,6 +88,8 @@ struct Device {
         (void)hipSetDevice(ordinal);
         if (bk_ntt) (void)hipFree(bk_ntt);
         if (ksk) (void)hipFree(ksk);
+        if (ksk_lut) (void)hipFree(ksk_lut);
+        ksk_lut = nullptr;
         if (tw_fwd) (void)hipFree(tw_fwd);
         if (tw_inv) (void)hipFree(tw_inv);
         if (fpc) (void)hipFree(fpc);
@@ -155,7 +158,7 @@ struct Global {
     bool coalesce = true;         // IYK_HIP_COALESCE=0 at init: iyk_hip_gate_host launches per gate on the caller's stream
     iyk_params p{};
     u32 ksk_stride = 0;
-    int ks_kernel = 1;    // 1: keyswitch_wave_kernel where instantiated, 0: keyswitch_kernel (IYK_HIP_KS_KERNEL)
+    int ks_kernel = 1;    // 1: keyswitch_wave_kernel where instantiated, 0: keyswitch_kernel, 2: keyswitch_lut_kernel for wide batches (IYK_HIP_KS_KERNEL)
     bool use_fp = false;          // FP64 path (fp50.hpp) instead of Goldilocks integers
     bool use_fft = false;         // wave-per-rotation kernel on the complex-FFT path (fft512.hpp); implies use_fp for the narrow-frontier kernel
     size_t bk_fft_bytes = 0;
@@ -170,6 +173,7 @@ struct Global {
     // iyk_hip_init: the torus-domain key stays on the host for that (the caller's arrays may be freed on return).
     std::vector<u32> bk_torus_host;
     uint64_t field_key_bytes = 0;
+    uint64_t ks_lut_bytes = 0;   // the pre-added key-switch rows, once built (ensure_ks_lut)
     std::mutex field_mu;
 } G;
 
@@ -456,6 +460,52 @@ int launch_keyswitch_wave(iyk_hip_stream* st, u32* d_arena, const KsJob* d_jobs,
     HIP_TRY(hipGetLastError());
     return IYK_OK;
 }
+static constexpr int KS_LUT_MIN_JOBS = 4096;   // below: the shared-gates form of keyswitch_wave_kernel (narrow frontiers)
+// The table of pre-added key-switch rows on GPU `gpu` (kernels.hpp: keyswitch_lut_kernel), built from the resident KSK on first use.
+template <int T, int NC>
+int ensure_ks_lut(int gpu)
+{
+    Device& D = G.devs[gpu];
+    if (__atomic_load_n(&D.ksk_lut, __ATOMIC_ACQUIRE)) return IYK_OK;
+    std::lock_guard<std::mutex> lock(G.field_mu);
+    if (D.ksk_lut) return IYK_OK;
+    HIP_TRY(hipSetDevice(D.ordinal));
+    const u32 lut_stride = KsLut<T, NC>::STRIDE;
+    const size_t words = ((size_t)NTT_N * ksl_rows_per_i(T) + 12) * lut_stride;   // + 12 rows: the kernel moves every stage as 16 rows
+    u32* d_lut = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_lut, words * sizeof(u32)));
+    hipError_t e = hipMemset(d_lut, 0, words * sizeof(u32));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(ks_lut_build_kernel<T>, dim3((unsigned)ksl_rows_per_i(T), (unsigned)NTT_N), dim3(256), 0, nullptr,
+                           (const u32*)D.ksk, d_lut, G.ksk_stride, lut_stride);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) {
+        (void)hipFree(d_lut);
+        return fail(IYK_ERR_HIP, std::string("key-switch table: ") + hipGetErrorString(e));
+    }
+    G.ks_lut_bytes = words * sizeof(u32);
+    __atomic_store_n(&D.ksk_lut, d_lut, __ATOMIC_RELEASE);
+    return IYK_OK;
+}
+template <int T, int NC>
+int launch_keyswitch_lut(iyk_hip_stream* st, u32* d_arena, const KsJob* d_jobs, int njobs)
+{
+    int rc = ensure_ks_lut<T, NC>(st->gpu);
+    if (rc) return rc;
+    const Device& D = G.devs[st->gpu];
+    const int groups = (njobs + KSL_WAVES * KSL_G - 1) / (KSL_WAVES * KSL_G);
+    int slices = 1;
+    while (slices < 8 && groups * slices < D.cus) slices *= 2;   // one workgroup per CU at a time
+    const u32 i_per_slice = (u32)NTT_N / (u32)slices;
+    const size_t lds = KsLut<T, NC>::LDS_BYTES;
+    hipLaunchKernelGGL((keyswitch_lut_kernel<T, NC>), dim3((unsigned)groups, (unsigned)slices), dim3(64 * KSL_WAVES),
+                       lds, st->s, (const u32*)st->d_rot, d_jobs, njobs, (const u32*)D.ksk_lut, d_arena, G.p.n,
+                       i_per_slice);
+    HIP_TRY(hipGetLastError());
+    return IYK_OK;
+}
 template <int T>
 int launch_keyswitch_t(iyk_hip_stream* st, u32* d_arena, const KsJob* d_jobs, int njobs)
 {
@@ -465,9 +515,13 @@ int launch_keyswitch_t(iyk_hip_stream* st, u32* d_arena, const KsJob* d_jobs, in
                        (const u32*)st->d_rot, d_jobs, d_arena, p.n);
     HIP_TRY(hipGetLastError());
     const char* force = std::getenv("IYK_HIP_KS_KERNEL");  // "0" / "1" per call (A/B, tests), like IYK_HIP_LATENCY_KERNEL
-    const int kind = force && (force[0] == '0' || force[0] == '1') ? force[0] - '0' : G.ks_kernel;
+    const int kind = force && (force[0] >= '0' && force[0] <= '2') ? force[0] - '0' : G.ks_kernel;
     const u32 nc = (G.ksk_stride + 127u) / 128u;
-    if (kind == 1) {
+    if (kind == 2 && njobs > KS_LUT_MIN_JOBS) {   // pre-added rows selected by address: wide batches (narrow ones: the shared-gates form below)
+        if (T == 7 && nc == 5) return launch_keyswitch_lut<7, 5>(st, d_arena, d_jobs, njobs);
+        if (T == 8 && nc == 4) return launch_keyswitch_lut<8, 4>(st, d_arena, d_jobs, njobs);
+    }
+    if (kind >= 1) {
         if (T == 7 && nc == 5) return launch_keyswitch_wave<7, 5, 16>(st, d_arena, d_jobs, njobs);
         if (T == 8 && nc == 4) return launch_keyswitch_wave<8, 4, 16>(st, d_arena, d_jobs, njobs);
     }
@@ -524,6 +578,8 @@ int set_kernel_attrs(const iyk_params& p, bool use_fp, int split)
     else rc = (p.l == 3) ? set_lds(blind_rotate_kernel<3, 6>, BR_LDS_BYTES) : set_lds(blind_rotate_kernel<2, 10>, BR_LDS_BYTES);
     if (rc) return rc;
     const size_t ks_lds = (size_t)KS_G * NTT_N * 2;
+    if (p.t == 7 && (rc = set_lds(keyswitch_lut_kernel<7, 5>, KsLut<7, 5>::LDS_BYTES))) return rc;
+    if (p.t == 8 && (rc = set_lds(keyswitch_lut_kernel<8, 4>, KsLut<8, 4>::LDS_BYTES))) return rc;
     switch (p.t) {
     case 7: return set_lds(keyswitch_kernel<7>, ks_lds);
     case 8: return set_lds(keyswitch_kernel<8>, ks_lds);
@@ -1058,7 +1114,10 @@ int iyk_hip_resident_key_bytes(uint64_t* out)
     uint64_t field = 0;   // the lazily built field key counts once a cross-check kernel has asked for it (on any GPU)
     for (const Device& D : G.devs)
         if (G.use_fft && __atomic_load_n(&D.bk_ntt, __ATOMIC_ACQUIRE)) field = G.field_key_bytes;
-    *out = G.key_bytes + field;
+    uint64_t lut = 0;     // likewise the table of pre-added key-switch rows (IYK_HIP_KS_KERNEL=2)
+    for (const Device& D : G.devs)
+        if (__atomic_load_n(&D.ksk_lut, __ATOMIC_ACQUIRE)) lut = G.ks_lut_bytes;
+    *out = G.key_bytes + field + lut;
     return IYK_OK;
 }
 
@@ -1165,7 +1224,7 @@ int iyk_hip_init(int ngpu, const int* device_ids, const iyk_params* params, cons
     if (const char* co = std::getenv("IYK_HIP_COALESCE")) G.coalesce = co[0] != '0';
     else G.coalesce = true;
     const char* dbg = std::getenv("IYK_HIP_DEBUG");
-    G.ks_kernel = 1;
+    G.ks_kernel = 2;   // wide batches: pre-added rows selected by address (round 6); narrow ones: the wave kernel's shared-gates form
     G.debug = dbg && dbg[0] == '1';
     G.p = p;
     G.use_fp = use_fp;

@@ -1137,6 +1137,193 @@ __global__ __launch_bounds__(256, (KSW_G > 10 ? 2 : KSW_G > 6 ? 3 : 4)) void key
 }
 
 // ------------------------------------------------------------------------------------------
+// Key switch through a table of PRE-ADDED rows (round 6; opt-in, IYK_HIP_KS_KERNEL=2; wide batches).
+// keyswitch_wave_kernel decodes one 2-bit digit per (gate, stage) with compares and branches and issues ~9.6 instructions
+// beside the 10 additions of a row.  Here the digits of a'_i + prec are taken in PAIRS from the most significant one
+// (t = 7: three pairs and a single, t = 8: four pairs): a stage's candidates are the 16 (4) sums
+//   lut[i][s][(vh << 2) | vl] = (vh ? KSK[i][2s][vh-1] : 0) + (vl ? KSK[i][2s+1][vl-1] : 0)        (row 0 = zeros)
+// — the very rows the reference subtracts one after the other, added once at key upload (ks_lut_build_kernel; integer sums
+// commute mod 2^32, so every output word stays the oracle's) — and a gate selects its row by ADDRESS: the workgroup stages the
+// stage's rows in LDS (double buffer, one barrier per stage), and each wave reads, per gate, the row at v * stride.  No
+// compare, no branch, half the stages: 2 scalar + 1 vector instruction, NC ds_read_b64 and 2 NC additions per (gate, stage).
+// A wave owns 16 gates (2 NC x 16 sums in registers), a workgroup 8 waves = 128 gates = one CU.
+__host__ __device__ constexpr int ksl_stages(int T) { return (T + 1) / 2; }
+__host__ __device__ constexpr int ksl_rows_per_i(int T) { return 16 * (T / 2) + 4 * (T % 2); }
+__host__ __device__ constexpr int ksl_stage_rows(int T, int s) { return 2 * s + 1 < T ? 16 : 4; }
+static constexpr int KSL_WAVES = 8, KSL_G = 16;
+#ifndef KSL_GG
+#define KSL_GG 4   // gates whose rows are in flight together
+#endif
+
+template <int T>
+__global__ __launch_bounds__(256) void ks_lut_build_kernel(const u32* __restrict__ ksk, u32* __restrict__ lut, u32 stride,
+                                                           u32 lut_stride)   // KSK rows of `stride` words -> table rows of NC * 128
+{
+    constexpr int RPI = ksl_rows_per_i(T);
+    const int i = blockIdx.y, r = blockIdx.x;
+    const bool pair = r < 16 * (T / 2);
+    const int s = pair ? r >> 4 : T / 2, v = pair ? r & 15 : r - 16 * (T / 2);
+    const u32* base = ksk + (size_t)i * T * 3 * stride;
+    u32* out = lut + ((size_t)i * RPI + r) * lut_stride;
+    for (u32 w = threadIdx.x; w < lut_stride; w += 256) {
+        u32 x = 0;
+        if (w < stride) {
+            if (pair) {
+                const int vh = v >> 2, vl = v & 3;
+                if (vh) x += base[(size_t)((2 * s) * 3 + vh - 1) * stride + w];
+                if (vl) x += base[(size_t)((2 * s + 1) * 3 + vl - 1) * stride + w];
+            }
+            else if (v) x = base[(size_t)((T - 1) * 3 + v - 1) * stride + w];
+        }
+        out[w] = x;
+    }
+}
+
+template <int T, int NC>
+struct KsLut {
+    static constexpr int STRIDE = NC * 128, S = ksl_stages(T), RPI = ksl_rows_per_i(T);
+    static constexpr size_t BUF_WORDS = 16 * (size_t)STRIDE;
+    static constexpr size_t LDS_BYTES = 2 * BUF_WORDS * 4 + (size_t)KSL_WAVES * KSL_G * KS2_CHUNK * 2;
+};
+
+template <int T, int NC>
+__global__ __launch_bounds__(64 * KSL_WAVES, 1) void keyswitch_lut_kernel(
+    const u32* __restrict__ rot, const KsJob* __restrict__ jobs, int njobs, const u32* __restrict__ lut,
+    u32* __restrict__ arena, u32 n, u32 i_per_slice)
+{
+    typedef KsLut<T, NC> M;
+    constexpr int STRIDE = M::STRIDE, S = M::S, RPI = M::RPI, G = KSL_G, THREADS = 64 * KSL_WAVES;
+    constexpr u32 dbits = 2u * T, prec = 1u << (32 - (1 + dbits));
+    constexpr int V4 = 16 * STRIDE / 4 / THREADS;   // uint4 items per thread of a 16-row stage (5 / 4)
+    static_assert(16 * STRIDE / 4 % THREADS == 0, "a 16-row stage divides over the workgroup");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_ksl[];
+    u32* s_rows = reinterpret_cast<u32*>(smem_ksl);   // [2][16][STRIDE]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    unsigned short* s_dig = reinterpret_cast<unsigned short*>(smem_ksl + 2 * M::BUF_WORDS * 4) + wave * (G * KS2_CHUNK);
+    const int gbase = blockIdx.x * (KSL_WAVES * G) + wave * G;
+    const u32 i0 = blockIdx.y * i_per_slice;
+    const u32 chunk = i_per_slice < (u32)KS2_CHUNK ? i_per_slice : (u32)KS2_CHUNK;
+
+    KsJob mine;   // lane k < G: the job of this wave's gate k
+    {
+        const int gi = gbase + (lane < G ? lane : 0);
+        mine = jobs[gi < njobs ? gi : njobs - 1];
+        if (gi >= njobs) mine.out = -1;
+    }
+    u32 acc[G][NC][2];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[g][c][0] = acc[g][c][1] = 0u;
+
+    // stage q = ii * S + s of the slice: rows lut[i0 + ii][16 s ..], 16 (or 4) rows of STRIDE words, contiguous
+    const u32 Q = i_per_slice * (u32)S;
+    // (a 16-row stage is 5 (4) moves of 16 bytes per thread; the single-digit stage of an odd t holds 4 rows = 1.25 moves: it takes
+    // two, unconditionally, and drags what lies behind its rows — the next stage's first rows, or the table's padding — into buffer
+    // rows nobody reads: 13.0 -> 12.6 ms against moving all 16.  Conditional moves sent the registers through scratch memory.  Past
+    // the last stage the last one is moved again.)
+    auto stage_src = [&](u32 q) {
+        const u32 qq = q < Q ? q : Q - 1u;
+        return reinterpret_cast<const uint4*>(lut + ((size_t)(i0 + qq / S) * RPI + 16u * (qq % S)) * STRIDE);
+    };
+    // (five named registers, not an array: as uint4 pf[V4] the compiler kept the block in scratch memory)
+    uint4 pf0, pf1, pf2 = make_uint4(0, 0, 0, 0), pf3 = pf2, pf4 = pf2;
+    // stage index -> does it hold 16 rows (a 4-row stage needs blocks 0 and 1 only: 4 x STRIDE / 4 <= 2 x THREADS items)
+    auto full_stage = [](int st) { return 2 * (st % S) + 1 < T; };
+    static_assert(V4 == 4 || V4 == 5, "staging registers are written out for 4 or 5 moves per thread");
+#define KSL_LOAD_STAGE(Q, FULL)                                 \
+    do {                                                        \
+        const uint4* src__ = stage_src(Q) + threadIdx.x;        \
+        pf0 = src__[0 * THREADS];                               \
+        pf1 = src__[1 * THREADS];                               \
+        if (FULL) {                                             \
+            pf2 = src__[2 * THREADS];                           \
+            pf3 = src__[3 * THREADS];                           \
+            if (V4 > 4) pf4 = src__[4 * THREADS];               \
+        }                                                       \
+    } while (0)
+#define KSL_STORE_STAGE(Q, FULL)                                                                             \
+    do {                                                                                                     \
+        uint4* dst__ = reinterpret_cast<uint4*>(s_rows + ((Q) & 1u) * M::BUF_WORDS) + threadIdx.x;           \
+        dst__[0 * THREADS] = pf0;                                                                            \
+        dst__[1 * THREADS] = pf1;                                                                            \
+        if (FULL) {                                                                                          \
+            dst__[2 * THREADS] = pf2;                                                                        \
+            dst__[3 * THREADS] = pf3;                                                                        \
+            if (V4 > 4) dst__[4 * THREADS] = pf4;                                                            \
+        }                                                                                                    \
+    } while (0)
+    KSL_LOAD_STAGE(0u, true);
+    KSL_STORE_STAGE(0u, true);
+    KSL_LOAD_STAGE(1u, full_stage(1));
+
+    u32 q = 0;
+    for (u32 cb = 0; cb < i_per_slice; cb += chunk) {
+        // this wave's digits of the next `chunk` coefficients: all 2 T digit bits of a'_i + prec, 16 bits per (gate, i)
+        lds_sync();
+#pragma unroll 1
+        for (int g = 0; g < G; ++g) {
+            const int ra = __builtin_amdgcn_readlane(mine.ra, g), rb = __builtin_amdgcn_readlane(mine.rb, g);
+            const int ok = __builtin_amdgcn_readlane(mine.out, g);
+            for (u32 k = (u32)lane; k < chunk; k += 64) {
+                u32 a = rot[(size_t)ra * (NTT_N + 1) + i0 + cb + k];
+                if (rb >= 0) a += rot[(size_t)rb * (NTT_N + 1) + i0 + cb + k];
+                a += prec;
+                s_dig[g * KS2_CHUNK + k] = ok >= 0 ? (unsigned short)(a >> (32 - dbits)) : (unsigned short)0;
+            }
+        }
+        __syncthreads();   // digits visible to the wave (own slice) and — first chunk — stage 0's rows to everybody
+#pragma unroll 1
+        for (u32 ii = 0; ii < chunk; ++ii) {
+            const u32 d = s_dig[(lane < G ? (u32)lane : 0u) * KS2_CHUNK + ii];
+#pragma unroll
+            for (int s = 0; s < S; ++s, ++q) {
+                const u32* rows = s_rows + (q & 1u) * M::BUF_WORDS + 2u * (u32)lane;
+                const bool pair = 2 * s + 1 < T;
+                const u32 sh = pair ? dbits - 4u * (u32)(s + 1) : 0u, mask = pair ? 15u : 3u;
+                // KSL_GG gates at a time: their rows are requested together and added when they arrive; the scheduling barriers keep the
+                // compiler from hoisting all 16 gates' reads to the top of the stage (160 registers in flight: 710 spilled)
+#pragma unroll
+                for (int g0 = 0; g0 < G; g0 += KSL_GG) {
+                    uint2 r[KSL_GG][NC];
+#pragma unroll
+                    for (int g = 0; g < KSL_GG; ++g) {
+                        const u32 v = ((u32)__builtin_amdgcn_readlane(d, g0 + g) >> sh) & mask;   // scalar
+                        const u32* row = rows + v * (u32)STRIDE;
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) r[g][c] = *reinterpret_cast<const uint2*>(row + c * 128);
+                    }
+#pragma unroll
+                    for (int g = 0; g < KSL_GG; ++g)
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            add_in_place(acc[g0 + g][c][0], r[g][c].x);   // pinned: left to the compiler the additions sink below the
+                            add_in_place(acc[g0 + g][c][1], r[g][c].y);   // staging branches and every row read is spilled first
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // (the same two moves BEFORE the stage's additions: 80-bit set 10.3 -> 10.9 ms, profiles/r06_ks_lut_ab.txt)
+                KSL_STORE_STAGE(q + 1u, full_stage(s + 1));   // into the buffer everybody left at the previous barrier
+                KSL_LOAD_STAGE(q + 2u, full_stage(s + 2));
+                __syncthreads();
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int out_slot = __builtin_amdgcn_readlane(mine.out, g);
+        if (out_slot < 0) continue;
+        u32* out = arena + (size_t)out_slot * ((size_t)n + 1);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const u32 w = (u32)c * 128 + 2u * (u32)lane;
+            if (w <= n) atomicSub(out + w, acc[g][c][0]);
+            if (w + 1 <= n) atomicSub(out + w + 1, acc[g][c][1]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void elementwise_kernel(u32* __restrict__ arena,
                                                           const EwJob* __restrict__ jobs, u32 n, u32 mu)
 {

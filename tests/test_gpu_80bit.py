@@ -111,6 +111,45 @@ def test_80bit_key_switch_forms_agree(ng, keys80, oracle80, monkeypatch):
     assert np.array_equal(got["shared"][out[sample]], ref[out[sample]])
 
 
+@pytest.mark.parametrize("ng", [4097, 6000])
+def test_80bit_key_switch_table_kernel_agrees(ng, keys80, oracle80, monkeypatch):
+    """The table key switch (round 6, batches wider than 4 096 gates) at the 80-bit set: t = 8 = four digit pairs, KSK rows of
+    504 words against table rows of 512.  Same words as the wave kernel, and the oracle's on a sample."""
+    from iyokan_amd import hip
+
+    monkeypatch.delenv("IYK_HIP_ROT_KERNEL", raising=False)
+    hip.initialize(keys80, device_ids=(0,))
+    try:
+        st = hip.Stream(0)
+        p = keys80.params
+        rng = np.random.default_rng(900 + ng)
+        nin = 24
+        bits = rng.integers(0, 2, size=nin).astype(np.uint8)
+        ops = rng.choice([OPS["NAND"], OPS["XNOR"], OPS["MUX"]], size=ng).astype(np.int32)
+        in0, in1, in2 = (rng.integers(0, nin, size=ng).astype(np.int32) for _ in range(3))
+        in2 = np.where(ops == OPS["MUX"], in2, -1).astype(np.int32)
+        out = np.arange(nin, nin + ng, dtype=np.int32)
+        host = np.zeros((nin + ng, p.n + 1), dtype=np.uint32)
+        host[:nin] = client.encrypt_bits(keys80, bits, seed=6)
+        got = {}
+        for mode in ("1", "2"):
+            monkeypatch.setenv("IYK_HIP_KS_KERNEL", mode)
+            arena = hip.Arena(host.shape[0])
+            st.upload(arena, 0, host)
+            st.gate_batch(arena, ops, in0, in1, in2, out)
+            st.sync()
+            got[mode] = st.download(arena, 0, host.shape[0])
+            arena.free()
+        st.destroy()
+    finally:
+        hip.cleanup()
+    assert np.array_equal(got["1"], got["2"])
+    sample = rng.choice(ng, size=16, replace=False)
+    ref = host.copy()
+    oracle80.gate_batch(ops[sample], in0[sample], in1[sample], in2[sample], out[sample], ref, nthreads=os.cpu_count() or 1)
+    assert np.array_equal(got["2"][out[sample]], ref[out[sample]])
+
+
 @pytest.mark.parametrize("path", ["fft", "fp50", "goldilocks"])
 def test_80bit_adversarial_rows(path, keys80, oracle80, monkeypatch):
     """Rows no encryption produces (oracle_lib.adversarial_rows) at the 80-bit set, split-digit FP64 field and

@@ -437,6 +437,37 @@ def test_key_switch_kernels_agree(gpu128, keys128, oracle128, ng, monkeypatch):
     assert np.array_equal(results["1"][out[sample]], ref[out[sample]])
 
 
+@pytest.mark.parametrize("ng", [4097, 4224, 9000])
+def test_key_switch_table_kernel_agrees(gpu128, keys128, oracle128, ng, monkeypatch):
+    """Round 6: batches wider than 4 096 gates take keyswitch_lut_kernel — digits in pairs, a table of pre-added KSK rows, the
+    row selected by address (IYK_HIP_KS_KERNEL=2, the default).  It subtracts the same rows as the wave kernel (1) in another
+    order: word-for-word equal at one gate above the threshold, at a whole number of 128-gate workgroups + a ragged one, and at
+    a batch the i range is sliced for; MUX included; a sample against the oracle; the resident key bytes grow by the table."""
+    hip, st = gpu128
+    p = keys128.params
+    rng = np.random.default_rng(700 + ng)
+    nin = 32
+    bits = rng.integers(0, 2, size=nin).astype(np.uint8)
+    ops = rng.choice([OPS["NAND"], OPS["XOR"], OPS["MUX"], OPS["ORNOT"]], size=ng).astype(np.int32)
+    in0, in1, in2 = (rng.integers(0, nin, size=ng).astype(np.int32) for _ in range(3))
+    in2 = np.where(ops == OPS["MUX"], in2, -1).astype(np.int32)
+    out = np.arange(nin, nin + ng, dtype=np.int32)
+    host = np.zeros((nin + ng, p.n + 1), dtype=np.uint32)
+    host[:nin] = client.encrypt_bits(keys128, bits, seed=81)
+    results = {}
+    for mode in ("1", "2"):
+        monkeypatch.setenv("IYK_HIP_KS_KERNEL", mode)
+        results[mode] = _run(hip, st, host, ops, in0, in1, in2, out)
+    monkeypatch.delenv("IYK_HIP_KS_KERNEL")
+    results["default"] = _run(hip, st, host, ops, in0, in1, in2, out)
+    assert np.array_equal(results["1"], results["2"]) and np.array_equal(results["2"], results["default"])
+    assert hip.resident_key_bytes() > 300e6     # keys 180 MB + the table's 136 MB
+    sample = rng.choice(ng, size=24, replace=False)
+    ref = host.copy()
+    oracle128.gate_batch(ops[sample], in0[sample], in1[sample], in2[sample], out[sample], ref, nthreads=os.cpu_count() or 1)
+    assert np.array_equal(results["2"][out[sample]], ref[out[sample]])
+
+
 @pytest.mark.parametrize("ng", [1, 15, 16, 17, 100, 1000, 4096, 4097])
 def test_key_switch_narrow_frontier_form_agrees(gpu128, keys128, ng, monkeypatch):
     """Round 5: batches of up to 4 096 gates take keyswitch_wave_kernel's SHARED form (a workgroup's four waves on the same 16
