@@ -144,6 +144,44 @@ def keyswitch(t1, ksk, p):
     return out.astype(U32)
 
 
+def keyswitch_pair_table(ksk, p):
+    """The table of iyokan_amd/csrc/kernels.hpp: ks_lut_build_kernel, restated (round 6).  The t 2-bit digits are taken in PAIRS from
+    the most significant one; stage s of coefficient i holds the 16 sums
+        table[i][16 s + ((v_h << 2) | v_l)] = (v_h ? KSK[i][2s][v_h-1] : 0) + (v_l ? KSK[i][2s+1][v_l-1] : 0)      (mod 2^32)
+    and an odd t ends in a stage of 4 rows for its last digit: 16 (t // 2) + 4 (t % 2) rows of n + 1 words per coefficient."""
+    N, t, bb, n = p.N, p.t, p.basebit, p.n
+    assert bb == 2
+    rows = ksk.reshape(N, t, 3, n + 1).astype(np.uint64)
+    zero = np.zeros((N, 1, n + 1), dtype=np.uint64)
+    cand = [np.concatenate([zero, rows[:, j]], axis=1) for j in range(t)]          # [N][4][n + 1]: digit value -> row (0 -> zeros)
+    out = []
+    for s in range(t // 2):
+        hi, lo = cand[2 * s], cand[2 * s + 1]
+        out.append(((hi[:, :, None, :] + lo[:, None, :, :]) & MASK32).reshape(N, 16, n + 1))   # index (v_h << 2) | v_l
+    if t % 2:
+        out.append(cand[t - 1])
+    return np.concatenate(out, axis=1).astype(U32)
+
+
+def keyswitch_by_table(t1, table, p):
+    """keyswitch() through keyswitch_pair_table(): one row per digit PAIR, selected by its 4-bit value — what
+    keyswitch_lut_kernel computes.  Equal to keyswitch() word for word (integer sums commute mod 2^32)."""
+    N, t, bb, n = p.N, p.t, p.basebit, p.n
+    dbits = bb * t
+    prec = 1 << (32 - (1 + dbits))
+    d = ((t1[:N].astype(np.uint64) + prec) & MASK32) >> (32 - dbits)                # all t digits of a'_i + prec
+    out = np.zeros(n + 1, dtype=np.uint64)
+    out[n] = int(t1[N])
+    idx = np.arange(N)
+    for s in range(t // 2):
+        v = ((d >> (dbits - 4 * (s + 1))) & 15).astype(np.int64)
+        out = (out - table[idx, 16 * s + v].astype(np.uint64).sum(axis=0)) & MASK32
+    if t % 2:
+        v = (d & 3).astype(np.int64)
+        out = (out - table[idx, 16 * (t // 2) + v].astype(np.uint64).sum(axis=0)) & MASK32
+    return out.astype(U32)
+
+
 GATE_COEFFS = {  # (sa, sb, offset in units of mu): out = sa * ca + sb * cb + (0, ..., 0, off)
     "NAND": (-1, -1, +1), "AND": (+1, +1, -1), "OR": (+1, +1, +1), "NOR": (-1, -1, -1),
     "XOR": (+2, +2, +2), "XNOR": (-2, -2, -2), "ANDNOT": (+1, -1, -1), "ORNOT": (+1, -1, +1),

@@ -56,6 +56,37 @@ def test_numpy_restatement_equals_the_oracle(which, request):
     assert np.array_equal(T.bootstrap(T.linear("ORNOT", ca, cb, p), p, kf, keys.ksk)[0], orc.gate(OPS["ORNOT"], ca, cb))
 
 
+@pytest.mark.parametrize("which", ["128", "80"])
+def test_key_switch_through_the_pair_table_equals_the_oracle(which, request):
+    """Round 6's key switch of wide batches adds PRE-ADDED rows — one per pair of 2-bit digits, from a table built from the
+    key-switching key (csrc/kernels.hpp: ks_lut_build_kernel / keyswitch_lut_kernel).  Its numpy restatement against the oracle's
+    IdentityKeySwitch on lvl1 samples with every digit pattern: uniform words (all 16 pair values, all four values of t = 7's single
+    last digit), all-zero digits (a' = -prec: nothing subtracted), all-ones digits, and words one below / at a digit boundary."""
+    keys = request.getfixturevalue("keys" + which)
+    orc = request.getfixturevalue("oracle" + which)
+    p = keys.params
+    table = T.keyswitch_pair_table(keys.ksk, p)
+    assert table.shape == (p.N, 16 * (p.t // 2) + 4 * (p.t % 2), p.n + 1)
+    assert not table[:, 0].any() and not table[:, 16].any()                          # row 0 of every stage: no digit, no row
+    rows = keys.ksk.reshape(p.N, p.t, 3, p.n + 1)
+    assert np.array_equal(table[:, 4 * 2 + 3], rows[:, 0, 1] + rows[:, 1, 2])      # stage 0, v_h = 2, v_l = 3
+    prec = 1 << (32 - (1 + 2 * p.t))
+    rng = np.random.default_rng(2026)
+    cases = [rng.integers(0, 1 << 32, size=p.N + 1, dtype=np.uint64).astype(np.uint32) for _ in range(3)]
+    zero = np.full(p.N + 1, (1 << 32) - prec, dtype=np.uint64).astype(np.uint32)    # a' + prec = 0: every digit 0
+    ones = np.full(p.N + 1, (1 << 32) - prec - 1, dtype=np.uint64).astype(np.uint32)  # a' + prec = 2^32 - 1: every digit 3
+    edge = rng.integers(0, 1 << 32, size=p.N + 1, dtype=np.uint64)
+    edge[::2] = ((edge[::2] >> (32 - 2 * p.t)) << (32 - 2 * p.t)) - prec             # exactly on a boundary of the last digit
+    edge[1::2] = ((edge[1::2] >> (32 - 2 * p.t)) << (32 - 2 * p.t)) - prec - 1       # one below it
+    cases += [zero, ones, (edge & 0xFFFFFFFF).astype(np.uint32)]
+    for t1 in cases:
+        t1 = np.ascontiguousarray(t1, dtype=np.uint32)
+        want = orc.keyswitch(t1)
+        assert np.array_equal(T.keyswitch(t1, keys.ksk, p), want)
+        assert np.array_equal(T.keyswitch_by_table(t1, table, p), want)
+    assert np.array_equal(T.keyswitch_by_table(zero, table, p)[:p.n], np.zeros(p.n, dtype=np.uint32))
+
+
 def test_formula_pieces_on_threshold_words():
     """mod-switch and decomposition at their rounding thresholds (the words adversarial_rows is built from)."""
     N = 1024
