@@ -87,14 +87,83 @@ def level_rotations(nl, levels, world=1):
     return [-(-sum(2 if nl.kinds[i] == "MUX" else 1 if nl.kinds[i] in BINARY else 0 for i in lv) // world) for lv in levels]
 
 
-def plan_levels(nl, world=1, cost=mi355x_level_cost):
-    """The cheapest, by `cost`, of levelise(), balanced_levels() at three cut granularities and beam_levels() with both of
-    its tie-breaks — the greedy is not monotone (a deferral can push a later level over a step), so the plain ASAP levels stay a candidate."""
+# What ONE pass of the narrow-frontier kernel costs by how much of it is filled, relative to a full pass: up to a quarter of the
+# CUs busy the kernel runs at the part's full clock, with all of them busy it runs into the power limit (profiles/r06_level_gaps.txt:
+# 2.466 / 2.497 / 2.554 / 2.635 ms at 64 / 128 / 192 / 256 rotations, steady state; right after narrow levels a full pass starts at
+# 3.1 ms).  Every level of a depth-bound netlist costs a pass whatever it holds, so rotations moved out of full passes into the
+# half-empty ones behind them are free — if the plan knows that a full pass is the dear one.
+SUB_PASS_SHAPE = (0.936, 0.947, 0.969, 1.0)
+
+
+def with_sub_pass_shape(cost):
+    """`cost` with the first pass priced by quarter: the figure plan_levels compares candidate plans by (the table's own
+    pass_ms[0] stays what a FULL pass costs; beam_levels / balanced_levels and the C++ planner keep cutting by the plain table)."""
+    _, small = getattr(cost, "quanta", (2048, 256))
+
+    def refined(rotations):
+        if 0 < rotations <= small:
+            return cost(small) * SUB_PASS_SHAPE[min(3, (4 * rotations - 1) // small)]
+        return cost(rotations)
+
+    refined.quanta = getattr(cost, "quanta", (2048, 256))
+    return refined
+
+
+def capped_levels(nl, world=1, cap=128):
+    """List scheduling with a CAP: level k takes the gates that must run now (ALAP level k) and, by ALAP order, as many of the
+    other ready gates as keep it at `cap` rotations per rank.  Same number of levels as levelise(); a netlist whose depth, not its
+    width, sets the clock ends up with its rotations spread over all its levels instead of piled into full passes at the front."""
+    depth, order, succ, npred0, alap, rot = _slack_graph(nl)
+    npred = list(npred0)
+    ready = [i for i in order if npred[i] == 0]
+    out = []
+    for k in range(1, depth + 1):
+        this, nxt, boots = [], [], []
+        for i in ready:
+            if rot[i] == 0:
+                this.append(i)
+                for s2 in succ[i]:
+                    npred[s2] -= 1
+                    if npred[s2] == 0:
+                        nxt.append(s2)
+            else:
+                boots.append(i)
+        boots.sort(key=lambda i: (alap[i], i))
+        acc = 0
+        for i in boots:
+            if alap[i] <= k or k == depth or acc + rot[i] <= cap * world:
+                this.append(i)
+                acc += rot[i]
+                for s2 in succ[i]:
+                    npred[s2] -= 1
+                    if npred[s2] == 0:
+                        nxt.append(s2)
+            else:
+                nxt.append(i)
+        out.append(this)
+        ready = nxt
+    assert not ready and sum(len(lv) for lv in out) == len(order)
+    return out
+
+
+def plan_levels(nl, world=1, cost=mi355x_level_cost, spread=True):
+    """The cheapest of levelise(), balanced_levels() at three cut granularities, beam_levels() with both of its tie-breaks and —
+    round 6 — capped_levels() at eighths of a pass up to a whole one, compared by with_sub_pass_shape(cost).  The greedy is not
+    monotone (a deferral can push a later level over a step), so the plain ASAP levels stay a candidate."""
     best, best_t = None, None
     big, small = getattr(cost, "quanta", (2048, 256))
-    for quanta in (None, (big, small), (small,), (big,), "id", "fanout"):
-        lv = nl.levelise() if quanta is None else beam_levels(nl, world, cost, tie=quanta) if isinstance(quanta, str) else balanced_levels(nl, world, cost, quanta)
-        t = sum(cost(r) for r in level_rotations(nl, lv, world))
+    price = with_sub_pass_shape(cost)
+    caps = sorted({max(1, small * e // 8) for e in range(2, 9)}) if spread else []   # spread=False: round 5's candidates only (A/B)
+    for quanta in [None, (big, small), (small,), (big,), "id", "fanout"] + [("cap", c) for c in caps]:
+        if quanta is None:
+            lv = nl.levelise()
+        elif isinstance(quanta, str):
+            lv = beam_levels(nl, world, cost, tie=quanta)
+        elif quanta[0] == "cap":
+            lv = capped_levels(nl, world, quanta[1])
+        else:
+            lv = balanced_levels(nl, world, cost, quanta)
+        t = sum(price(r) for r in level_rotations(nl, lv, world))
         if best is None or t < best_t - 1e-9:
             best, best_t = lv, t
     return best
@@ -275,9 +344,9 @@ class FrontierPlan:
     the level where the kernels' step-shaped cost is lowest (plan_levels; `cost` = make_level_cost(hip.rotation_round()) on
     a GPU other than the 256-CU MI355X the default describes); False: every gate at its earliest level."""
 
-    def __init__(self, nl, world=1, balance=True, cost=mi355x_level_cost):
+    def __init__(self, nl, world=1, balance=True, cost=mi355x_level_cost, spread=True):
         self.nl, self.world = nl, world
-        levels = plan_levels(nl, world, cost) if balance else nl.levelise()
+        levels = plan_levels(nl, world, cost, spread) if balance else nl.levelise()
         n = nl.num_nodes
         slot = [-1] * n
         nslots = 0

@@ -212,6 +212,40 @@ def test_balanced_levels_are_a_valid_cheaper_schedule(name, kind, world):
     assert cost(F.plan_levels(nl, world)) <= min(cost(asap), cost(F.balanced_levels(nl, world))) + 1e-9
 
 
+@pytest.mark.parametrize("world", [1, 8])
+def test_spread_plan_of_a_depth_bound_netlist(world):
+    """Round 6: every level of the CAHP core costs one pass of the narrow-frontier kernel whatever it holds, and a FULL pass is the
+    dear one (all CUs busy: the power limit; frontier.SUB_PASS_SHAPE).  capped_levels spreads the rotations over all 41 levels — a
+    valid schedule (every gate once, after its inputs, depth unchanged, gates at their ALAP level never deferred) — and plan_levels
+    prefers it: no level above half a pass per rank where round 5's plan had eleven full ones; spread=False is round 5's plan."""
+    from iyokan_amd import frontier as F
+
+    nl = N.load_yosys_json(gold("cahp-ruby-core-yosys.json"))
+    asap = nl.levelise()
+    for cap in (64, 128, 200):
+        lv = F.capped_levels(nl, world, cap)
+        assert len(lv) == len(asap) and sorted(i for l in lv for i in l) == sorted(i for l in asap for i in l)
+        where = {i: k for k, l in enumerate(lv) for i in l}
+        root = nl.roots()
+        for i, k in where.items():
+            for j in nl.ins[i]:
+                j = root[j]
+                assert nl.kinds[j] in ("INPUT", "DFF") or where[j] < k, (i, j)
+    cost = F.mi355x_level_cost
+    price = F.with_sub_pass_shape(cost)
+    big, small = cost.quanta
+    assert price(small) == cost(small) and price(small // 4) < price(small // 2) < price(small) and price(small + 1) == cost(small + 1)
+    new, old = F.plan_levels(nl, world), F.plan_levels(nl, world, spread=False)
+    total = lambda lv: sum(price(r) for r in F.level_rotations(nl, lv, world))
+    assert total(new) <= total(old)
+    if world == 1:
+        assert max(F.level_rotations(nl, new, 1)) <= small // 2 and sum(1 for r in F.level_rotations(nl, old, 1) if r == small) >= 8
+        assert total(new) < 0.99 * total(old)      # measured: 0.1073 -> 0.1057 s per clock, same box
+    # a netlist whose WIDTH sets the clock keeps its plan of whole rounds
+    ram = N.load_iyokanl1_json(gold("mux-ram-8-16-16.min.json"))
+    assert F.level_rotations(ram, F.plan_levels(ram, 1), 1) == F.level_rotations(ram, F.plan_levels(ram, 1, spread=False), 1)
+
+
 def test_balanced_plan_gains_on_the_benchmark_netlists():
     """What the planner is for (model milliseconds per clock on one GPU, profiles/r03_bench_netlist*.txt has the measured
     ones): config #4's system, config #3's RAM and the CAHP core lose an eighth of their clock."""

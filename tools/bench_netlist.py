@@ -72,7 +72,7 @@ def main():
                     help="clocks run back to back after the per-clock ones (tick + run, inputs held, ONE sync at the end): the shape of the "
                          "reference's clock loop, /root/reference/src/iyokan_cufhe.cpp:754-802; 0 = skip")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--plan", default="balanced", choices=["balanced", "asap"],
+    ap.add_argument("--plan", default="balanced", choices=["balanced", "asap", "nospread"],
                     help="level plan: gates with slack placed where a level's step-shaped cost is lowest (frontier.plan_levels, "
                          "the default) or every gate at its earliest level")
     ap.add_argument("--spawn", action="store_true", help="go through torch.distributed.run even for one GPU (RCCL with one rank)")
@@ -85,7 +85,7 @@ def main():
 
     from iyokan_amd import client, hip
     from iyokan_amd import netlist as N
-    from iyokan_amd.frontier import FrontierExecutor, FrontierPlan, HipBackend, level_rotations, make_level_cost
+    from iyokan_amd.frontier import FrontierExecutor, FrontierPlan, HipBackend, level_rotations, make_level_cost, with_sub_pass_shape
     from iyokan_amd.params import params_128bit
     from netlist_util import gold, drive_cycle, input_streams, load_packet
 
@@ -120,7 +120,7 @@ def main():
     if distributed:
         table = broadcast_cost_table(table, dist, dev)
     level_cost = make_level_cost(table)
-    plan = FrontierPlan(nl, world, balance=args.plan == "balanced", cost=level_cost)
+    plan = FrontierPlan(nl, world, balance=args.plan != "asap", cost=level_cost, spread=args.plan != "nospread")   # nospread: without round 6's capped candidates (A/B)
     if distributed:
         assert_same_plan(plan, dist, dev)
     be = HipBackend(plan.num_slots, p, dev)
@@ -193,7 +193,7 @@ def main():
         print(json.dumps({"net": args.net, "n_gpus": world, "rccl_world_size": dist.get_world_size() if distributed else None, "levels": len(plan.levels), "rotations_per_clock": rot,
                           "s_per_clock": best, "s_per_clock_back_to_back": burst_s, "burst": args.burst, "rotations_per_s": rot / best, "collectives_per_clock": ex.collectives // (args.clocks + 1 + args.burst),
                           "outputs_match_plaintext": ok, "ntt_path": hip.ntt_path(), "plan": args.plan, "cost_table": level_cost.table,
-                          "model_s_per_clock": sum(level_cost(r) for r in level_rotations(nl, [L["boot"] for L in plan.levels], world)) / 1e3}))
+                          "model_s_per_clock": sum(with_sub_pass_shape(level_cost)(r) for r in level_rotations(nl, [L["boot"] for L in plan.levels], world)) / 1e3}))
     be.close()
     hip.cleanup()
     if distributed:

@@ -10,7 +10,7 @@
 # (/root/reference/src/main.cpp:147-148).  GPUS="1 2" restricts the counts (e.g. a 2-GPU box).
 #   DRY_RUN=1 bash tools/scale_all.sh      # print the exact commands, in order, and run nothing (no GPU needed; tests/test_scale_model.py)
 # When the table exists, compare it with the model's prediction: python tools/scale_model.py --check <outfile>
-# (profiles/r05_scale_model.json: flat batches >= 0.97 efficiency at N = 8, config #4 <= 0.115 s per clock at N = 8).
+# (profiles/r06_scale_model.json: flat batches >= 0.97 efficiency at N = 8, config #4 <= 0.115 s per clock at N = 8).
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 out=${1:-gpurun_out/scale_all.jsonl}
 mkdir -p "$(dirname "$out")"; : > "$out"

@@ -17,8 +17,8 @@ with --measure, see below) and the netlists under tests/golden/.  Everything the
       exchange = exch_lat_us + bytes / exch_GBps: ONE in-place all_gather of the level's output ciphertexts over RCCL / xGMI.
       exch_* are ASSUMPTIONS (no multi-GPU box has run this yet): 40 us, 45 GB/s (a third of one xGMI link's ~153 GB/s).
 
-  python tools/scale_model.py --inputs gpurun_out/r05_model_inputs.json --out profiles/r05_scale_model.json
-  python tools/scale_model.py --measure gpurun_out/r05_model_inputs.json      (on a GPU box: calibrates both parameter sets)
+  python tools/scale_model.py --inputs profiles/r06_final_model_inputs.json --out profiles/r06_scale_model.json     (the defaults)
+  python tools/scale_model.py --measure gpurun_out/r06_model_inputs.json      (on a GPU box: calibrates both parameter sets)
 """
 import argparse
 import json
@@ -97,7 +97,7 @@ def interp(points, x):
 
 def model(inputs, exch_lat_us, exch_gbps):
     from iyokan_amd import netlist as N
-    from iyokan_amd.frontier import BINARY, FrontierPlan, level_rotations, make_level_cost
+    from iyokan_amd.frontier import BINARY, FrontierPlan, level_rotations, make_level_cost, with_sub_pass_shape
     from iyokan_amd.params import params_128bit
     from netlist_util import gold
 
@@ -130,6 +130,7 @@ def model(inputs, exch_lat_us, exch_gbps):
 
     rec = inputs["128bit"]
     cost = make_level_cost(rec["cost_table"])
+    price = with_sub_pass_shape(cost)   # a narrow level by how full its one pass is (round 6: what plan_levels compares plans by)
     p = params_128bit()
     ct_bytes = (p.n + 1) * 4
     # fixed cost of a level = what a narrow step costs beyond its two kernels (staging copy, events, launch gaps)
@@ -152,7 +153,7 @@ def model(inputs, exch_lat_us, exch_gbps):
                 gates = sum(1 for i in lv if nl.kinds[i] == "MUX" or nl.kinds[i] in BINARY)
                 mine = -(-gates // w)
                 if r:
-                    t_rot += cost(r)
+                    t_rot += price(r)
                     t_ks += interp(rec["ks_ms"], mine)
                     t_fix += max(fixed, 0.0)
                 if w > 1 and gates:
@@ -214,8 +215,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", default=None, help="a measured table (scale_all.sh's .jsonl or SCALE_rNN.json) to compare with --out's model")
     ap.add_argument("--measure", default=None, help="GPU box: write the model's inputs to this file")
-    ap.add_argument("--inputs", default=os.path.join(ROOT, "gpurun_out", "r05_model_inputs.json"))
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_scale_model.json"))
+    ap.add_argument("--inputs", default=os.path.join(ROOT, "profiles", "r06_final_model_inputs.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06_scale_model.json"))
     ap.add_argument("--exch-lat-us", type=float, default=40.0)
     ap.add_argument("--exch-gbps", type=float, default=45.0)
     args = ap.parse_args()
