@@ -507,6 +507,15 @@ inline double levelCostMs(const iyk_level_cost& c, long rot)
     if (rem <= (long)c.max_passes * c.pass) return t + c.pass_ms[(rem + c.pass - 1) / c.pass - 1];
     return t + c.round_ms;
 }
+// What plans are COMPARED by (round 6; iyokan_amd/frontier.py: with_sub_pass_shape): levelCostMs with the first pass of the
+// narrow-frontier kernel priced by how full it is — up to a quarter of the CUs busy it runs at the part's full clock, with all of
+// them busy into the power limit (2.466 / 2.497 / 2.554 / 2.635 ms at 64 / 128 / 192 / 256 rotations, profiles/r06_plan_ab.txt).
+inline double levelPriceMs(const iyk_level_cost& c, long rot)
+{
+    static constexpr double SUB_PASS_SHAPE[4] = {0.936, 0.947, 0.969, 1.0};
+    if (rot > 0 && rot <= c.pass) return levelCostMs(c, c.pass) * SUB_PASS_SHAPE[std::min(3L, (4 * rot - 1) / c.pass)];
+    return levelCostMs(c, rot);
+}
 inline long rotationRound() { return (long)levelCostTable().round; }
 inline long rotationPass() { return (long)levelCostTable().pass; }
 inline double levelCostMs(long rot) { return levelCostMs(levelCostTable(), rot); }
@@ -768,6 +777,84 @@ inline std::vector<int> planLevels(const PlanGraph& pg, int G, int width, double
     return round;
 }
 
+// List scheduling with a CAP (iyokan_amd/frontier.py: capped_levels): frontier k takes the gates that must run now and, by latest
+// frontier and node number, as many other ready gates as keep it at `cap` rotations per GPU.  A netlist whose depth, not its width,
+// sets the clock gets its rotations spread over all its frontiers instead of piled into full passes at the front.
+inline std::vector<int> cappedLevels(const PlanGraph& pg, int G, long cap)
+{
+    const int n = (int)pg.rot.size(), depth = pg.depth;
+    std::vector<int> pending = pg.indeg0, round(n, -1), ready;
+    for (int i = 0; i < n; ++i)
+        if (pending[i] == 0) ready.push_back(i);
+    for (int k = 0; k < depth; ++k) {
+        std::vector<int> nxt, boots;
+        auto release = [&](int id) {
+            for (int d : pg.succ[id])
+                if (--pending[d] == 0) nxt.push_back(d);
+        };
+        for (int id : ready) {
+            if (pg.rot[id] == 0) {
+                round[id] = k;
+                release(id);
+            }
+            else {
+                boots.push_back(id);
+            }
+        }
+        std::sort(boots.begin(), boots.end(), [&](int a, int b) { return pg.alap[a] != pg.alap[b] ? pg.alap[a] < pg.alap[b] : a < b; });
+        long acc = 0;
+        for (int id : boots) {
+            if (pg.alap[id] <= k || k + 1 == depth || acc + pg.rot[id] <= cap * G) {
+                acc += pg.rot[id];
+                round[id] = k;
+                release(id);
+            }
+            else {
+                nxt.push_back(id);
+            }
+        }
+        ready.swap(nxt);
+    }
+    for (int i = 0; i < n; ++i)
+        if (round[i] < 0) return {};
+    return round;
+}
+// price of a complete schedule: levelPriceMs of every frontier's rotations per GPU
+inline double planPriceMs(const PlanGraph& pg, const std::vector<int>& round, int G, const iyk_level_cost& T)
+{
+    std::vector<long> rots(pg.depth, 0);
+    for (size_t i = 0; i < round.size(); ++i) rots[round[i]] += pg.rot[i];
+    double ms = 0;
+    for (long r : rots) ms += levelPriceMs(T, (r + G - 1) / G);
+    return ms;
+}
+// The plan the runner uses: the cheaper beam search (both tie-breaks) or — round 6 — a capped list schedule at eighths of a pass up
+// to a whole one, whichever planPriceMs makes cheapest (frontier.plan_levels' candidates that matter at run time).
+inline std::vector<int> planBest(const PlanGraph& pg, int G, int width, double* priceMs = nullptr)
+{
+    const iyk_level_cost T = levelCostTable();
+    std::vector<int> best;
+    double bestMs = 0;
+    auto offer = [&](std::vector<int> r) {
+        if (r.empty()) return;
+        const double ms = planPriceMs(pg, r, G, T);
+        if (best.empty() || ms < bestMs - 1e-9) {
+            best = std::move(r);
+            bestMs = ms;
+        }
+    };
+    offer(planLevels(pg, G, width));
+    offer(planLevels(pg, G, width, nullptr, true));
+    long last = 0;
+    for (int e = 2; e <= 8; ++e) {
+        const long cap = std::max(1L, (long)T.pass * e / 8);
+        if (cap != last) offer(cappedLevels(pg, G, cap));
+        last = cap;
+    }
+    if (priceMs) *priceMs = bestMs;
+    return best;
+}
+
 inline std::vector<int> planFrontiers(TaskNetwork<HIPWorkerInfo>& net, int G, int width)
 {
     const int n = (int)net.numNodes();
@@ -785,9 +872,7 @@ inline std::vector<int> planFrontiers(TaskNetwork<HIPWorkerInfo>& net, int G, in
         for (int d : t.dependents)
             if (net.node(d).kind != GateKind::DFF) pg.succ[i].push_back(d);
     }
-    double msId = 0, msFan = 0;
-    std::vector<int> byId = planLevels(pg, G, width, &msId), byFan = planLevels(pg, G, width, &msFan, true);
-    return !byFan.empty() && (byId.empty() || msFan < msId - 1e-9) ? byFan : byId;
+    return planBest(pg, G, width);
 }
 
 // numWorkers is accepted for signature parity with the reference and ignored: ONE batching worker drives every GPU

@@ -26,10 +26,11 @@
 //                                   (/root/reference/src/iyokan-packet.cpp:144-178) on this repository's KeyArchive
 //   test0_hip --do-hip BP.toml --bkey EK.bin --in REQ.bin --out RES.bin -c N [--gpus G] [--snapshot F] [--resume F]
 //                                   doHIP(opt): everything from files, like `iyokan tfhe --enable-gpu` (/root/reference/src/main.cpp)
-//   test0_hip --plan-graph FILE [--gpus G] [--tie-fanout]
+//   test0_hip --plan-graph FILE [--gpus G] [--tie-fanout | --capped CAP | --plan-best]
 //                                   planLevels (the search behind planFrontiers) on a DAG given as text — "n depth width", then
 //                                   per node "rot alap indeg nsucc succ..." — with the library's compiled-in cost table (no
-//                                   GPU): prints the schedule's milliseconds and every node's frontier
+//                                   GPU): prints the schedule's milliseconds and every node's frontier; --capped: cappedLevels at CAP
+//                                   rotations per GPU (priced by planPriceMs); --plan-best: planBest, what planFrontiers runs
 //   test0_hip --hip-run BP.toml IN.toml -c N [--expect OUT.toml] [--gpus G] [--mux-ram-dir DIR] [--snapshot-at K]
 //                                   the same, ENCRYPTED, through HIPFrontend (keys made in-process, request packet
 //                                   encrypted here, result decrypted and compared); with --snapshot-at the run is cut at
@@ -621,13 +622,16 @@ static int hipRun(const std::string& bp, const std::string& in, int cycles, cons
 
 int main(int argc, char** argv)
 {
-    bool with_hip = false, use80 = false, skipReset = false, tieFanout = false;
+    bool with_hip = false, use80 = false, skipReset = false, tieFanout = false, planBestMode = false;
+    long planCap = 0;
     int gpus = 1, cycles = -2, snapshotAt = 0;
     std::string mode, bpFile, inFile, expect, muxRamDir, bkey, outFile, snapshotFile, resumeFile;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--hip") with_hip = true;
         else if (a == "--tie-fanout") tieFanout = true;
+        else if (a == "--plan-best") planBestMode = true;
+        else if (a == "--capped" && i + 1 < argc) planCap = std::atol(argv[++i]);
         else if (a == "--80bit") use80 = true;
         else if (a == "--skip-reset") skipReset = true;
         else if (a == "--fixtures" && i + 1 < argc) g_fixtures = argv[++i];
@@ -793,7 +797,10 @@ int main(int argc, char** argv)
                 if (!(in >> d) || d < 0 || d >= n) die("--plan-graph: bad successor");
         }
         double ms = 0;
-        const std::vector<int> round = planLevels(pg, gpus, width, &ms, tieFanout);
+        const std::vector<int> round = planCap > 0    ? cappedLevels(pg, gpus, planCap)
+                                       : planBestMode ? planBest(pg, gpus, width, &ms)
+                                                      : planLevels(pg, gpus, width, &ms, tieFanout);
+        if (planCap > 0 && !round.empty()) ms = planPriceMs(pg, round, gpus, levelCostTable());
         std::printf("ms %.9f\n", ms);
         for (int r : round) std::printf("%d\n", r);
         return round.empty() ? 1 : 0;

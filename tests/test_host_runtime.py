@@ -197,6 +197,57 @@ def test_hostile_size_tags_are_refused_before_allocation(tmp_path):
         assert text in out.stdout + out.stderr, (name, out.stdout, out.stderr)
 
 
+def _plan_graph_file(nl, tmp_path):
+    from iyokan_amd import frontier as F
+
+    depth, order, succ, npred, alap, rot = F._slack_graph(nl)
+    lines = [f"{nl.num_nodes} {depth} 6"]
+    placed = set(order)
+    for i in range(nl.num_nodes):
+        if i in placed:
+            lines.append(" ".join(map(str, [rot[i], alap[i] - 1, npred[i], len(succ[i])] + succ[i])))
+        else:
+            lines.append("0 0 0 0")
+    f = tmp_path / "graph.txt"
+    f.write_text("\n".join(lines) + "\n")
+    return f
+
+
+@pytest.mark.parametrize("world", [1, 8])
+def test_cpp_spread_plan_equals_the_python_one(world, tmp_path):
+    """Round 6's capped list schedule and the choice among the candidates, C++ (host/iyokan_hip.hpp: cappedLevels, planBest — what
+    planFrontiers runs) against Python (frontier.capped_levels, plan_levels) on the CAHP core: the same frontier for every node at a
+    cap of 128 rotations per GPU, the same price, and planBest spreads the core exactly as plan_levels does."""
+    from iyokan_amd import frontier as F
+    from iyokan_amd import netlist as N
+    from netlist_util import gold
+
+    nl = N.load_yosys_json(gold("cahp-ruby-core-yosys.json"))
+    f = _plan_graph_file(nl, tmp_path)
+    price = F.with_sub_pass_shape(F.mi355x_level_cost)
+    total = lambda lv: sum(price(r) for r in F.level_rotations(nl, lv, world))
+
+    def run(*extra):
+        out = subprocess.run([_exe(), "--plan-graph", str(f), "--gpus", str(world), *extra], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout[-500:] + out.stderr[-2000:]
+        rows = out.stdout.split()
+        return float(rows[1]), [int(x) for x in rows[2:]]
+
+    ms, rnd = run("--capped", "128")
+    levels = F.capped_levels(nl, world, 128)
+    for k, lv in enumerate(levels):
+        for i in lv:
+            assert rnd[i] == k, (i, k, rnd[i])
+    assert ms == pytest.approx(total(levels), rel=1e-9)
+    ms, rnd = run("--plan-best")
+    best = F.plan_levels(nl, world)
+    assert ms <= total(best) * (1 + 1e-9)                    # C++ offers fewer candidates than Python, never a dearer choice here
+    if world == 1:
+        for k, lv in enumerate(best):
+            for i in lv:
+                assert rnd[i] == k, (i, k, rnd[i])
+
+
 @pytest.mark.parametrize("name,kind", [("cahp-ruby-core-yosys.json", "yosys"), ("mux-ram-8-16-16.min.json", "l1"),
                                        ("cahp-ruby-mux.toml", "blueprint")])
 @pytest.mark.parametrize("world", [1, 2])
