@@ -349,7 +349,8 @@ const char* iyk_hip_init_profile(void);
 
 /* Bytes of device memory holding keys on one GPU: the key spectra (FFT path) or the NTT-domain BK (field / integer paths), the
  * padded KSK and the tables — 179.8 MB at the 128-bit set on the default path — plus, once a cross-check kernel has asked for
- * it, the field form of the BK (62.5 MB; round 5 built and kept it at init: 242.3 MB). */
+ * it, the field form of the BK (62.5 MB; round 5 built and kept it at init: 242.3 MB) and, once a batch wider than 4 096 gates has
+ * run, the key switch's table of pre-added rows (136 MB; IYK_HIP_KS_KERNEL above). */
 int iyk_hip_resident_key_bytes(uint64_t* out);
 
 #ifdef __cplusplus

@@ -441,8 +441,13 @@ int launch_keyswitch_wave(iyk_hip_stream* st, u32* d_arena, const KsJob* d_jobs,
         const char* swg = std::getenv("IYK_HIP_KS_SHARED_WG");   // workgroups a launch is sliced up to (A/B: profiles/r05_ks_small_ab.txt)
         const int min_wg = swg ? std::max(1, std::atoi(swg)) : 512;
         const int groups = (njobs + GW - 1) / GW;
+        // From four groups on a workgroup keeps at least 16 coefficients (64 slices), from two on at least 8 (128): cut finer, a launch
+        // of 17 .. 127 gates spends its time on the atomics of its slices — 96 gates: 89 -> 68 us, 48 gates: 70 -> 48.5 us, 32 gates:
+        // 49 -> 43 us, 64 gates: 59.5 -> 56 us (profiles/r06_plan_ab.txt; round 6's level plans make ~100-gate levels the common
+        // case of a depth-bound netlist).
+        const int max_slices = groups >= 4 ? 64 : groups >= 2 ? 128 : 256;
         int slices = 1;
-        while (slices < 256 && groups * slices < min_wg) slices *= 2;
+        while (slices < max_slices && groups * slices < min_wg) slices *= 2;
         const u32 i_per_slice = (u32)NTT_N / (u32)slices;   // per workgroup: >= 4, one i per wave at least
         hipLaunchKernelGGL((keyswitch_wave_kernel<T, NC, GW, true>), dim3((unsigned)groups, (unsigned)slices), dim3(256),
                            (size_t)4 * GW * KS2_CHUNK * 2 + (size_t)GW * NC * 128 * 4, st->s, (const u32*)st->d_rot, d_jobs, njobs,
