@@ -1,3 +1,7 @@
+#!/bin/bash
+# Same-box A/B of two whole libraries on the netlist benches: iyokan_amd/lib/variant_old.so against variant_new.so (build them first: e.g.
+# `git archive <rev> iyokan_amd/csrc include tools/src_hash.py | tar -x -C /tmp/old` + hipcc there for the old one, a copy of libiyokan_hip.so for
+# the new one).  Two repetitions, mux-ram and the CAHP system, single clocks and a back-to-back burst.  -> gpurun_out/r06b_nl_ab.txt
 cd /root/repo
 cp iyokan_amd/lib/libiyokan_hip.so /tmp/keep.so
 for rep in 1 2; do for v in old new; do
